@@ -1,0 +1,125 @@
+"""ctypes binding of libmi355x_recsys.so (the C-ABI in include/mi355x_recsys.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback behind
+these calls.  If the shared object has not been built, or a tensor is not on a
+ROCm device, the caller gets a loud error (never a silent slow path).
+"""
+import ctypes
+import os
+import threading
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355x_recsys.so")
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+
+# name -> argtypes; every entry point returns int unless listed in _RESTYPES.
+# tests/test_abi.py cross-checks this table against include/mi355x_recsys.h.
+SIGNATURES = {
+    "mi_abi_version": [],
+    "mi_strerror": [ctypes.c_int],
+    "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
+    "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
+    "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
+    "mi_gather_rows_fwd": [_p, _p, _p, _i64, _i32, _i64, _p, _p],
+    "mi_scatter_add_rows": [_p, _p, _p, _i64, _i32, _i64, _p],
+    "mi_prof_enable": [_i32],
+    "mi_prof_count": [],
+    "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
+}
+_RESTYPES = {"mi_strerror": ctypes.c_char_p}
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+
+class MI355XLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MI355XLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C recsys-benchmark_amd/csrc`). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        if lib.mi_abi_version() != 1:
+            raise MI355XLibraryError("libmi355x_recsys.so ABI version mismatch; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mi_strerror(rc).decode()
+        raise MI355XLibraryError(f"{what or 'mi355x_recsys call'} failed: {msg} ({rc})")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on one ROCm device; the kernels have no CPU path."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise MI355XLibraryError(
+                "recsys_benchmark_amd runs its hot path as HIP kernels on an MI355X; got a tensor on "
+                f"'{t.device}'. Move the module and its inputs to 'cuda' (there is no CPU fallback)."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise MI355XLibraryError(f"tensors on different devices: {dev} vs {t.device}")
+    assert dev is not None
+    return dev
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---- sticky out-of-range flag (one int32 word per device) ---------------------
+_err_words: Dict[int, torch.Tensor] = {}
+
+
+def err_word(device: torch.device) -> torch.Tensor:
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    w = _err_words.get(i)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", i))
+        _err_words[i] = w
+    return w
+
+
+def check_index_errors(device: Optional[torch.device] = None) -> None:
+    """Synchronise and raise IndexError if any lookup since the last check was out of range.
+
+    Mirrors what nn.Embedding does eagerly on CPU in the reference
+    (src/models/embeddings/base.py:74-75); here it is deferred so the hot path never syncs.
+    """
+    words = _err_words.values() if device is None else [err_word(device)]
+    for w in words:
+        if int(w.item()) != 0:
+            w.zero_()
+            raise IndexError("index out of range in embedding lookup (mi355x_recsys)")

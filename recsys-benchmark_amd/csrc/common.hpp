@@ -1,0 +1,73 @@
+// common.hpp — shared helpers for the gfx950 kernels of libmi355x_recsys.so.
+// Wave = 64 lanes everywhere (CDNA4); nothing here is portable to 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355x_recsys.h"
+
+namespace mi {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;            // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxGrid = 256 * 8;      // 256 CUs x 8 resident 256-thread workgroups
+
+// ---- profiling ring (mi_prof_*) --------------------------------------------
+struct ProfScope {
+  int slot;
+  hipStream_t s;
+  ProfScope(const char *name, hipStream_t stream);
+  ~ProfScope();
+};
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
+}
+
+inline int grid_for_waves(int64_t n_wave_items) {
+  int64_t g = (n_wave_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// sum over the lanes that differ only in bits >= log2(lo) (lo a power of two):
+// i.e. over the "row slot" index r = lane / lo, keeping q = lane % lo apart.
+template <int LO>
+__device__ __forceinline__ float4 slot_sum(float4 v) {
+#pragma unroll
+  for (int m = LO; m < kWave; m <<= 1) {
+    v.x += __shfl_xor(v.x, m);
+    v.y += __shfl_xor(v.y, m);
+    v.z += __shfl_xor(v.z, m);
+    v.w += __shfl_xor(v.w, m);
+  }
+  return v;
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+}  // namespace mi
+
+// Launch `kernel` on `stream` with an optional event pair around it.
+#define MI_LAUNCH(name, kernel, grid, block, stream, ...)                         \
+  do {                                                                            \
+    mi::ProfScope _mi_prof(name, (hipStream_t)(stream));                          \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), \
+                       __VA_ARGS__);                                              \
+  } while (0)

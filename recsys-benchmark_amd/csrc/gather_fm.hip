@@ -1,0 +1,575 @@
+// gather_fm.hip — DeepFM's embedding gather fused with the FM second-order term
+// and the first-order (EmbeddingBag(N,1,sum)) term, forward and backward.
+//
+// Reference arithmetic: src/models/deepfm.py:88-98 and
+// src/models/embeddings/base.py:74-75 (see include/mi355x_recsys.h).
+//
+// Mapping (CDNA4, wave = 64): ONE WAVE PER SAMPLE.  A row of D = 4*LPR floats is
+// read by LPR adjacent lanes as one float4 each (16 B per lane, the widest
+// coalesced access), so a wave-instruction moves RS = 64/LPR rows = 1 KiB.
+// lane = r*LPR + q  (r = row slot, q = which float4 of the row).  The F rows of
+// the sample are covered in NIT = ceil(F/RS) unrolled steps whose loads are all
+// issued before the first use, so each wave has NIT row gathers in flight.
+// sum_f e (per d) is a shuffle-xor reduction over the r bits of the lane id;
+// the per-sample scalar is one 64-lane reduction.  emb[b] is F*D contiguous
+// floats, so the stores of a step are one contiguous <=1 KiB run.
+//
+// HBM-bound integer/copy work: no LDS staging is needed in the forward (each
+// byte is used once); the dense backward stages a 1 KiB tile per wave in LDS to
+// turn 16-B-strided float4 fragments into 256-B contiguous atomic instructions.
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+// ---------------------------------------------------------------- forward ----
+template <int LPR, int NIT>
+__global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+    const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
+    float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
+    int64_t B, int F, int64_t N, int *err) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float bv = bias ? bias[0] : 0.f;
+  int bad = 0;
+
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ss = 0.f, lin = 0.f;
+    const int64_t base = b * F;
+    if constexpr (NIT > 0) {
+      int64_t row[NIT];
+      bool act[NIT], ok[NIT];
+      float4 v[NIT];
+      float l[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int f = r + k * RS;
+        act[k] = f < F;
+        row[k] = act[k] ? idx[base + f] + offsets[f] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        ok[k] = act[k] && (uint64_t)row[k] < (uint64_t)N;
+        bad |= (act[k] && !ok[k]);
+        v[k] = ok[k] ? ld4(W + row[k] * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        l[k] = (ok[k] && q == 0) ? w1[row[k]] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int f = r + k * RS;
+        if (act[k]) {
+          st4(emb + (base + f) * D + q * 4, v[k]);
+          if (rows_out && q == 0) rows_out[base + f] = row[k];
+        }
+        S.x += v[k].x; S.y += v[k].y; S.z += v[k].z; S.w += v[k].w;
+        ss += dot4(v[k], v[k]);
+        lin += l[k];
+      }
+    } else {
+      for (int f = r; f < F; f += RS) {
+        const int64_t row = idx[base + f] + offsets[f];
+        const bool ok = (uint64_t)row < (uint64_t)N;
+        bad |= !ok;
+        const float4 v = ok ? ld4(W + row * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && q == 0) lin += w1[row];
+        st4(emb + (base + f) * D + q * 4, v);
+        if (rows_out && q == 0) rows_out[base + f] = row;
+        S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
+        ss += dot4(v, v);
+      }
+    }
+    S = slot_sum<LPR>(S);
+    float t = (r == 0 ? dot4(S, S) : 0.f) - ss;
+    t = wave_sum(0.5f * t + lin);
+    if (lane == 0) yfm[b] = t + bv;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// Any D (scalar accesses): wave per sample, lanes stride over d.
+__global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+    const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
+    float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
+    int64_t B, int F, int D, int64_t N, int *err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float bv = bias ? bias[0] : 0.f;
+  int bad = 0;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    float t = 0.f;
+    for (int d0 = 0; d0 < D || d0 == 0; d0 += kWave) {
+      const int d = d0 + lane;
+      float S = 0.f, ss = 0.f;
+      for (int f = 0; f < F; ++f) {
+        const int64_t row = idx[base + f] + offsets[f];
+        const bool ok = (uint64_t)row < (uint64_t)N;
+        bad |= !ok;
+        if (d0 == 0 && lane == 0) {
+          if (ok) t += w1[row];
+          if (rows_out) rows_out[base + f] = row;
+        }
+        if (d < D) {
+          const float v = ok ? W[row * D + d] : 0.f;
+          emb[(base + f) * D + d] = v;
+          S += v;
+          ss += v * v;
+        }
+      }
+      t += 0.5f * (S * S - ss);
+    }
+    t = wave_sum(t);
+    if (lane == 0) yfm[b] = t + bv;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// ----------------------------------------------------- backward, row form ----
+template <int LPR, int NIT>
+__global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
+    const float *__restrict__ emb, const float *__restrict__ g_y,
+    const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
+    int64_t B, int F) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    const float gy = g_y[b];
+    float4 S = z;
+    if constexpr (NIT > 0) {
+      float4 e[NIT], ge[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int f = r + k * RS;
+        const bool act = f < F;
+        const int64_t o = (base + f) * D + q * 4;
+        e[k] = act ? ld4(emb + o) : z;
+        ge[k] = (act && g_emb) ? ld4(g_emb + o) : z;
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        S.x += e[k].x; S.y += e[k].y; S.z += e[k].z; S.w += e[k].w;
+      }
+      S = slot_sum<LPR>(S);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int f = r + k * RS;
+        if (f < F) {
+          float4 o4;
+          o4.x = ge[k].x + gy * (S.x - e[k].x);
+          o4.y = ge[k].y + gy * (S.y - e[k].y);
+          o4.z = ge[k].z + gy * (S.z - e[k].z);
+          o4.w = ge[k].w + gy * (S.w - e[k].w);
+          st4(gvals + (base + f) * D + q * 4, o4);
+          if (q == 0) g1vals[base + f] = gy;
+        }
+      }
+    } else {
+      for (int f = r; f < F; f += RS) {
+        const float4 e = ld4(emb + (base + f) * D + q * 4);
+        S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+      }
+      S = slot_sum<LPR>(S);
+      for (int f = r; f < F; f += RS) {
+        const int64_t o = (base + f) * D + q * 4;
+        const float4 e = ld4(emb + o);
+        const float4 ge = g_emb ? ld4(g_emb + o) : z;
+        float4 o4;
+        o4.x = ge.x + gy * (S.x - e.x);
+        o4.y = ge.y + gy * (S.y - e.y);
+        o4.z = ge.z + gy * (S.z - e.z);
+        o4.w = ge.w + gy * (S.w - e.w);
+        st4(gvals + o, o4);
+        if (q == 0) g1vals[base + f] = gy;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows_anyD(
+    const float *__restrict__ emb, const float *__restrict__ g_y,
+    const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
+    int64_t B, int F, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    const float gy = g_y[b];
+    for (int f = lane; f < F; f += kWave) g1vals[base + f] = gy;
+    for (int d = lane; d < D; d += kWave) {
+      float S = 0.f;
+      for (int f = 0; f < F; ++f) S += emb[(base + f) * D + d];
+      for (int f = 0; f < F; ++f) {
+        const int64_t o = (base + f) * D + d;
+        gvals[o] = (g_emb ? g_emb[o] : 0.f) + gy * (S - emb[o]);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------- backward, dense form ----
+// Same gradient rows, scatter-added into gW / gw1.  The wave's RS x D tile of a
+// step (256 floats = the lanes' float4 fragments back to back) goes through a
+// wave-private 1 KiB LDS slab so that each of the 4 atomic wave-instructions
+// covers 64 CONSECUTIVE floats of the tile: whole 256-B runs per row (D >= 64)
+// or 64/D whole rows (D < 64) — the shape global float atomics run fastest at
+// (MI355X_MICROARCH.md, "Global float atomics").
+template <int LPR, int NIT>
+__global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense(
+    const int64_t *__restrict__ rows, const float *__restrict__ emb,
+    const float *__restrict__ g_y, const float *__restrict__ g_emb,
+    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int64_t N) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  __shared__ float slab[kWavesPerBlock][kWave * 4];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float *my = slab[wib];
+  constexpr int NSTEP = NIT > 0 ? NIT : 1;
+
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    const float gy = g_y[b];
+    float4 S = z;
+    for (int f = r; f < F; f += RS) {
+      const float4 e = ld4(emb + (base + f) * D + q * 4);
+      S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+    }
+    S = slot_sum<LPR>(S);
+    const int nsteps = NIT > 0 ? NSTEP : (F + RS - 1) / RS;
+    for (int k = 0; k < nsteps; ++k) {
+      const int f = r + k * RS;
+      const bool act = f < F;
+      int64_t row = -1;
+      float4 o4 = z;
+      if (act) {
+        const int64_t o = (base + f) * D + q * 4;
+        const float4 e = ld4(emb + o);
+        const float4 ge = g_emb ? ld4(g_emb + o) : z;
+        row = rows[base + f];
+        if ((uint64_t)row >= (uint64_t)N) row = -1;
+        o4.x = ge.x + gy * (S.x - e.x);
+        o4.y = ge.y + gy * (S.y - e.y);
+        o4.z = ge.z + gy * (S.z - e.z);
+        o4.w = ge.w + gy * (S.w - e.w);
+        if (q == 0 && row >= 0) atomicAdd(gw1 + row, gy);
+      }
+      st4(my + lane * 4, o4);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int el = j * kWave + lane;  // element of the RS x D tile
+        const int tr = el / D, tc = el % D;
+        const int64_t trow = __shfl(row, tr * LPR);
+        const float val = my[el];
+        if (trow >= 0) atomicAdd(gW + trow * D + tc, val);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense_anyD(
+    const int64_t *__restrict__ rows, const float *__restrict__ emb,
+    const float *__restrict__ g_y, const float *__restrict__ g_emb,
+    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int D, int64_t N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    const float gy = g_y[b];
+    for (int f = lane; f < F; f += kWave) {
+      const int64_t row = rows[base + f];
+      if ((uint64_t)row < (uint64_t)N) atomicAdd(gw1 + row, gy);
+    }
+    for (int d = lane; d < D; d += kWave) {
+      float S = 0.f;
+      for (int f = 0; f < F; ++f) S += emb[(base + f) * D + d];
+      for (int f = 0; f < F; ++f) {
+        const int64_t o = (base + f) * D + d;
+        const int64_t row = rows[base + f];
+        if ((uint64_t)row < (uint64_t)N)
+          atomicAdd(gW + row * D + d, (g_emb ? g_emb[o] : 0.f) + gy * (S - emb[o]));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------- plain row gather ----
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_gather_rows(
+    const int64_t *__restrict__ idx, const float *__restrict__ W, float *__restrict__ out,
+    int64_t n, int64_t N, int *err) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  constexpr int U = 4;  // row gathers in flight per lane
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + (int64_t)RS * U - 1) / ((int64_t)RS * U);
+  int bad = 0;
+  for (int64_t t = wave0; t < ntiles; t += nwaves) {
+    int64_t row[U];
+    bool act[U], ok[U];
+    float4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t i = (t * U + k) * RS + r;
+      act[k] = i < n;
+      row[k] = act[k] ? idx[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      ok[k] = act[k] && (uint64_t)row[k] < (uint64_t)N;
+      bad |= (act[k] && !ok[k]);
+      v[k] = ok[k] ? ld4(W + row[k] * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t i = (t * U + k) * RS + r;
+      if (act[k]) st4(out + i * D + q * 4, v[k]);
+    }
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_rows_anyD(
+    const int64_t *__restrict__ idx, const float *__restrict__ W, float *__restrict__ out,
+    int64_t n, int D, int64_t N, int *err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  int bad = 0;
+  for (int64_t i = wave0; i < n; i += nwaves) {
+    const int64_t row = idx[i];
+    const bool ok = (uint64_t)row < (uint64_t)N;
+    bad |= !ok;
+    for (int d = lane; d < D; d += kWave) out[i * D + d] = ok ? W[row * D + d] : 0.f;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// gW[idx[i],:] += g[i,:]; same LDS re-tiling as the dense FM backward.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_scatter_add_rows(
+    const int64_t *__restrict__ idx, const float *__restrict__ g, float *__restrict__ gW,
+    int64_t n, int64_t N) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  __shared__ float slab[kWavesPerBlock][kWave * 4];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + RS - 1) / RS;
+  float *my = slab[wib];
+  for (int64_t t = wave0; t < ntiles; t += nwaves) {
+    const int64_t i = t * RS + r;
+    int64_t row = -1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+      row = idx[i];
+      if ((uint64_t)row >= (uint64_t)N) row = -1;
+      // the tile's rows are consecutive in g: lane*4 floats from the tile start
+      v = ld4(g + t * RS * D + lane * 4);
+    }
+    st4(my + lane * 4, v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int el = j * kWave + lane;
+      const int tr = el / D, tc = el % D;
+      const int64_t trow = __shfl(row, tr * LPR);
+      const float val = my[el];
+      if (trow >= 0) atomicAdd(gW + trow * D + tc, val);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_add_rows_anyD(
+    const int64_t *__restrict__ idx, const float *__restrict__ g, float *__restrict__ gW,
+    int64_t n, int D, int64_t N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t i = wave0; i < n; i += nwaves) {
+    const int64_t row = idx[i];
+    if ((uint64_t)row >= (uint64_t)N) continue;
+    for (int d = lane; d < D; d += kWave) atomicAdd(gW + row * D + d, g[i * D + d]);
+  }
+}
+
+// ------------------------------------------------------------- dispatch ------
+inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0; }
+inline int nit_for(int F, int LPR) {
+  const int RS = kWave / LPR;
+  const int n = (F + RS - 1) / RS;
+  return n <= 4 ? n : 0;
+}
+
+// Expands `CALL(LPR, NIT)` for the run-time (lpr, nit) pair.
+#define MI_DISPATCH_LPR_NIT(lpr, nit, CALL)                               \
+  switch (lpr) {                                                          \
+    case 1: MI_DISPATCH_NIT(1, nit, CALL); break;                         \
+    case 2: MI_DISPATCH_NIT(2, nit, CALL); break;                         \
+    case 4: MI_DISPATCH_NIT(4, nit, CALL); break;                         \
+    case 8: MI_DISPATCH_NIT(8, nit, CALL); break;                         \
+    case 16: MI_DISPATCH_NIT(16, nit, CALL); break;                       \
+    case 32: MI_DISPATCH_NIT(32, nit, CALL); break;                       \
+    case 64: MI_DISPATCH_NIT(64, nit, CALL); break;                       \
+    default: return MI_ERR_UNSUPPORTED;                                   \
+  }
+#define MI_DISPATCH_NIT(LPR, nit, CALL) \
+  switch (nit) {                        \
+    case 1: CALL(LPR, 1); break;        \
+    case 2: CALL(LPR, 2); break;        \
+    case 3: CALL(LPR, 3); break;        \
+    case 4: CALL(LPR, 4); break;        \
+    default: CALL(LPR, 0); break;       \
+  }
+#define MI_DISPATCH_LPR(lpr, CALL)      \
+  switch (lpr) {                        \
+    case 1: CALL(1); break;             \
+    case 2: CALL(2); break;             \
+    case 4: CALL(4); break;             \
+    case 8: CALL(8); break;             \
+    case 16: CALL(16); break;           \
+    case 32: CALL(32); break;           \
+    case 64: CALL(64); break;           \
+    default: return MI_ERR_UNSUPPORTED; \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W, const float *w1,
+                     const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
+                     int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!idx || !offsets || !W || !w1 || !emb_out || !yfm_out) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  if (vec_ok(D) && aligned16(W) && aligned16(emb_out)) {
+    const int lpr = D / 4, nit = nit_for(F, lpr);
+#define CALL(LPR, NIT)                                                                       \
+  MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT>), grid, kBlock, stream, idx, offsets, \
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, err)
+    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+  } else {
+    MI_LAUNCH("gather_fm_fwd", k_gather_fm_fwd_anyD, grid, kBlock, stream, idx, offsets, W, w1,
+              bias, emb_out, yfm_out, rows_out, B, F, D, N, err);
+  }
+  return launch_status();
+}
+
+int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb, float *gvals,
+                          float *g1vals, int64_t B, int32_t F, int32_t D, void *stream) {
+  if (B < 0 || F < 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!emb || !g_y || !gvals || !g1vals) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  if (vec_ok(D) && aligned16(emb) && aligned16(gvals) && (!g_emb || aligned16(g_emb))) {
+    const int lpr = D / 4, nit = nit_for(F, lpr);
+#define CALL(LPR, NIT)                                                                      \
+  MI_LAUNCH("gather_fm_bwd_rows", (k_gather_fm_bwd_rows<LPR, NIT>), grid, kBlock, stream, emb, \
+            g_y, g_emb, gvals, g1vals, B, F)
+    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+  } else {
+    MI_LAUNCH("gather_fm_bwd_rows", k_gather_fm_bwd_rows_anyD, grid, kBlock, stream, emb, g_y,
+              g_emb, gvals, g1vals, B, F, D);
+  }
+  return launch_status();
+}
+
+int mi_gather_fm_bwd_dense(const int64_t *rows, const float *emb, const float *g_y,
+                           const float *g_emb, float *gW, float *gw1, int64_t B, int32_t F,
+                           int32_t D, int64_t N, void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!rows || !emb || !g_y || !gW || !gw1) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  if (vec_ok(D) && aligned16(emb) && (!g_emb || aligned16(g_emb))) {
+    const int lpr = D / 4, nit = nit_for(F, lpr);
+#define CALL(LPR, NIT)                                                                         \
+  MI_LAUNCH("gather_fm_bwd_dense", (k_gather_fm_bwd_dense<LPR, NIT>), grid, kBlock, stream, rows, \
+            emb, g_y, g_emb, gW, gw1, B, F, N)
+    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+  } else {
+    MI_LAUNCH("gather_fm_bwd_dense", k_gather_fm_bwd_dense_anyD, grid, kBlock, stream, rows, emb,
+              g_y, g_emb, gW, gw1, B, F, D, N);
+  }
+  return launch_status();
+}
+
+int mi_gather_rows_fwd(const int64_t *idx, const float *W, float *out, int64_t n, int32_t D,
+                       int64_t N, int32_t *err, void *stream) {
+  if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !W || !out) return MI_ERR_INVALID_ARG;
+  if (vec_ok(D) && aligned16(W) && aligned16(out)) {
+    const int lpr = D / 4;
+    const int64_t tiles = (n + (int64_t)(kWave / lpr) * 4 - 1) / ((int64_t)(kWave / lpr) * 4);
+    const int grid = grid_for_waves(tiles);
+#define CALL(LPR) \
+  MI_LAUNCH("gather_rows", (k_gather_rows<LPR>), grid, kBlock, stream, idx, W, out, n, N, err)
+    MI_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  } else {
+    MI_LAUNCH("gather_rows", k_gather_rows_anyD, grid_for_waves(n), kBlock, stream, idx, W, out,
+              n, D, N, err);
+  }
+  return launch_status();
+}
+
+int mi_scatter_add_rows(const int64_t *idx, const float *g, float *gW, int64_t n, int32_t D,
+                        int64_t N, void *stream) {
+  if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !g || !gW) return MI_ERR_INVALID_ARG;
+  if (vec_ok(D) && aligned16(g)) {
+    const int lpr = D / 4;
+    const int64_t tiles = (n + (kWave / lpr) - 1) / (kWave / lpr);
+    const int grid = grid_for_waves(tiles);
+#define CALL(LPR) \
+  MI_LAUNCH("scatter_add_rows", (k_scatter_add_rows<LPR>), grid, kBlock, stream, idx, g, gW, n, N)
+    MI_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  } else {
+    MI_LAUNCH("scatter_add_rows", k_scatter_add_rows_anyD, grid_for_waves(n), kBlock, stream, idx,
+              g, gW, n, D, N);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

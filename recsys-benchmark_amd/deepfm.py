@@ -1,0 +1,115 @@
+"""DeepFM with the gather + FM + first-order path as ONE HIP kernel each way.
+
+Drop-in for src/models/deepfm.py:11-134 of the reference: same constructor,
+same `state_dict` keys (`_bias, offsets, embedding.*, fc.weight, linear_layer.*,
+_deep_branch.*` — `linear_layer` is unused by forward there too), same
+`forward(x int[B,F]) -> logits[B]`, `get_ranks`, `load`.
+
+What runs where:
+  x + offsets, embedding gather, FM 2nd order, EmbeddingBag(N,1,sum) + bias
+      -> mi_gather_fm_fwd / mi_gather_fm_bwd_{rows,dense}  (vanilla table), or
+         IEmbedding.forward + mi_fm_fwd / mi_fm_bwd        (compressed tables)
+  the MLP tail (Linear/BatchNorm1d/ReLU/Dropout) stays a dense GEMM chain on
+      rocBLAS/hipBLASLt through PyTorch (a real contraction).
+"""
+from typing import Any, Dict, List, Optional, Union, cast
+
+import torch
+from torch import nn
+
+from . import _kernels
+from .embeddings import IEmbedding, VanillaEmbedding, get_embedding
+
+
+class DeepFM(nn.Module):
+    embedding: IEmbedding
+
+    def __init__(
+        self,
+        field_dims: List[int],
+        num_factor: int,
+        hidden_sizes: List[int],
+        p_dropout: float = 0.1,
+        use_batchnorm=False,
+        embedding_config: Optional[Dict] = None,
+        empty_embedding=False,
+        fc_sparse: bool = False,
+    ):
+        """Arguments as the reference's DeepFM.  Extra, optional:
+
+        fc_sparse: produce the first-order table's gradient in row (COO) form as
+            well.  Off by default because the reference's optimizer split
+            (src/models/deepfm.py:163-184) feeds `fc.weight` to dense Adam.
+        """
+        super().__init__()
+
+        if not embedding_config:
+            embedding_config = {"name": "vanilla"}
+
+        num_inputs = sum(field_dims)
+
+        if not empty_embedding:
+            self.embedding = get_embedding(
+                embedding_config, field_dims, num_factor, mode=None, field_name="deepfm"
+            )
+
+        self.fc = nn.EmbeddingBag(num_inputs, 1, mode="sum", sparse=fc_sparse)
+        self.linear_layer = nn.Linear(1, 1)
+        self._bias = nn.Parameter(torch.zeros(1))
+
+        deep_branch_inp = num_factor * len(field_dims)
+        layers: List[nn.Module] = []
+        for size in hidden_sizes:
+            layers.append(nn.Linear(deep_branch_inp, size))
+            if use_batchnorm:
+                layers.append(nn.BatchNorm1d(size))
+            layers.append(nn.ReLU())
+            layers.append(nn.Dropout(p_dropout))
+            deep_branch_inp = size
+        layers.append(nn.Linear(deep_branch_inp, 1))
+        self._deep_branch = nn.Sequential(*layers)
+
+        field_dims_tensor = torch.tensor(field_dims)
+        field_dims_tensor = torch.cat([torch.tensor([0], dtype=torch.long), field_dims_tensor])
+        offsets = torch.cumsum(field_dims_tensor[:-1], 0).unsqueeze(0)
+        self.register_buffer("offsets", offsets)
+
+    def _fm_and_embedding(self, x):
+        emb_mod = self.embedding
+        if isinstance(emb_mod, VanillaEmbedding) and emb_mod._mode is None:
+            return _kernels.gather_fm(
+                x, self.offsets, emb_mod.get_weight(), self.fc.weight, self._bias,
+                sparse_W=emb_mod.sparse_grad, sparse_w1=bool(self.fc.sparse),
+            )
+        rows = x + self.offsets
+        emb = emb_mod(rows)
+        return _kernels.fm_first_order(emb, rows, self.fc.weight, self._bias,
+                                       sparse_w1=bool(self.fc.sparse))
+
+    def forward(self, x):
+        """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
+        emb, y_fm = self._fm_and_embedding(x)
+        b = emb.shape[0]
+        scores = y_fm.unsqueeze(1) + self._deep_branch(emb.reshape(b, -1))
+        return scores.squeeze(-1)
+
+    def get_ranks(self, x) -> torch.Tensor:
+        scores = self(x)
+        return torch.argsort(scores, descending=True)
+
+    @classmethod
+    def load(
+        cls,
+        checkpoint: Union[str, Dict[str, Any]],
+        strict=True,
+        *,
+        empty_embedding=False,
+    ) -> "DeepFM":
+        if isinstance(checkpoint, str):
+            checkpoint = torch.load(checkpoint, map_location="cpu")
+        checkpoint = cast(Dict[str, Any], checkpoint)
+        model_config = checkpoint["model_config"]
+        field_dims = checkpoint["field_dims"]
+        model = cls(field_dims, **model_config, empty_embedding=empty_embedding)
+        model.load_state_dict(checkpoint["state_dict"], strict=strict)
+        return model

@@ -1,0 +1,61 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a gpu test must never silently pass on a box without a GPU
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no ROCm device")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden(dict):
+    """npz fixture with helpers: .t(key) -> torch tensor, .group(prefix) -> {suffix: tensor}."""
+
+    def t(self, key):
+        return torch.from_numpy(np.array(self[key]))
+
+    def group(self, prefix):
+        return {k[len(prefix):]: self.t(k) for k in self if k.startswith(prefix)}
+
+
+def load_golden(name: str) -> Golden:
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    with np.load(path) as z:
+        return Golden({k: z[k] for k in z.files})
+
+
+def golden_names(prefix: str):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def assert_close(actual, expected, rtol, atol, what=""):
+    actual = actual.detach().cpu() if isinstance(actual, torch.Tensor) else torch.as_tensor(actual)
+    expected = expected.detach().cpu() if isinstance(expected, torch.Tensor) else torch.as_tensor(expected)
+    if actual.is_sparse:
+        actual = actual.to_dense()
+    assert tuple(actual.shape) == tuple(expected.shape), f"{what}: shape {tuple(actual.shape)} vs {tuple(expected.shape)}"
+    torch.testing.assert_close(actual, expected.to(actual.dtype), rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares."""
+import ctypes
+import glob
+import os
+import re
+
+from conftest import ROOT
+
+import recsys_benchmark_amd as pkg
+from recsys_benchmark_amd import _lib
+
+DECL = re.compile(r"MI_API\s+(?:const\s+)?[\w\s\*]+?\b(mi_\w+)\s*\(([^;]*?)\)\s*;", re.S)
+
+
+def declared():
+    out = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        for name, args in DECL.findall(open(h).read()):
+            args = re.sub(r"/\*.*?\*/", "", args, flags=re.S).strip()
+            n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+            out[name] = n
+    return out
+
+
+def test_header_declares_entry_points():
+    d = declared()
+    assert "mi_gather_fm_fwd" in d and d["mi_gather_fm_fwd"] == 14
+    assert len(d) >= 10
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared():
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+
+
+def test_binding_table_matches_header():
+    d = declared()
+    assert set(d) == set(_lib.SIGNATURES), set(d) ^ set(_lib.SIGNATURES)
+    for name, n in d.items():
+        assert len(_lib.SIGNATURES[name]) == n, name
+
+
+def test_load_and_version():
+    lib = _lib.load()
+    assert lib.mi_abi_version() == 1
+    assert lib.mi_strerror(0) == b"ok"
+    assert b"invalid" in lib.mi_strerror(-1)
+
+
+def test_product_fails_loudly_without_gpu_tensor():
+    import pytest
+    import torch
+
+    m = pkg.DeepFM([3, 4], 4, [8])
+    with pytest.raises(pkg.MI355XLibraryError):
+        m(torch.tensor([[0, 1]]))
