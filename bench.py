@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — samples/sec of DeepFM fwd+bwd on the Criteo-26-field shape, B=4096 per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): F=26 Criteo-Kaggle categorical
+cardinalities (N=33,762,577 rows, D=16 fp32 = 2.16 GB table), MLP 400x3 + BatchNorm +
+dropout 0.5 (configs/deepfm/base_config.yaml of the reference), B=4096, seeded synthetic ids
+resident in HBM before the timed region.  A step = model(x) -> BCEWithLogits -> backward
+(the metric is fwd+bwd; no optimizer step), gradients of the two tables in row (COO) form.
+
+One JSON line on rank 0: the contract fields + `roofline` (the slower of the two gather+FM
+kernels, HIP-event timed inside the timed region, algorithmic bytes per SURVEY.md §8d) +
+`cpu_baseline` (the oracle's restatement of the reference op sequence on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CRITEO_KAGGLE_26 = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
+                    27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def alg_bytes_per_sample(F, D):
+    """fwd = 12F + 8FD + 4, bwd = 12F + 12FD + 4 (fp32 rows, int64 ids)."""
+    return 12 * F + 8 * F * D + 4, 12 * F + 12 * F * D + 4
+
+
+def synth_batch(dims, B, seed, device):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+    y = (torch.rand(B, generator=gen) < 0.25).float()
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
+    """Oracle (= reference op sequence in stock PyTorch CPU ops, dense grads like the
+    reference's default nn.Embedding) timed on the host cores; bounded sample."""
+    from oracle import reference_ops as ro
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(2023)
+    N = sum(dims)
+    bound = (6.0 / (N + D)) ** 0.5
+    p = {
+        "offsets": ro.field_offsets(dims),
+        "embedding._emb_module.weight": (torch.rand(N, D, generator=gen) * 2 - 1) * bound,
+        "fc.weight": torch.randn(N, 1, generator=gen),
+        "_bias": torch.zeros(1),
+    }
+    inp = len(dims) * D
+    i = 0
+    for h in hidden:
+        lin = torch.nn.Linear(inp, h)
+        p[f"_deep_branch.{i}.weight"], p[f"_deep_branch.{i}.bias"] = lin.weight.detach(), lin.bias.detach()
+        p[f"_deep_branch.{i+1}.weight"], p[f"_deep_branch.{i+1}.bias"] = torch.ones(h), torch.zeros(h)
+        p[f"_deep_branch.{i+1}.running_mean"], p[f"_deep_branch.{i+1}.running_var"] = torch.zeros(h), torch.ones(h)
+        inp = h
+        i += 4
+    lin = torch.nn.Linear(inp, 1)
+    p[f"_deep_branch.{i}.weight"], p[f"_deep_branch.{i}.bias"] = lin.weight.detach(), lin.bias.detach()
+    for k, v in p.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    x, y = synth_batch(dims, B, 2023, "cpu")
+    lossf = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        lossf(ro.deepfm_forward(x, p, len(hidden), True, True, p_dropout=p_dropout), y).backward()
+
+    step()  # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 10 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} fwd+bwd steps of the same B={B} workload (median {med*1e3:.1f} ms/step), "
+                      "oracle/reference_ops.py deepfm_forward on torch CPU, dense weight.grad as the reference"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-grads", action="store_true", help="reference-style dense weight.grad (atomic scatter)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import recsys_benchmark_amd as pkg
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    dims, D, hidden, p_drop = CRITEO_KAGGLE_26, 16, [400, 400, 400], 0.5
+    F, B = len(dims), args.batch
+    torch.manual_seed(2023)
+    sparse = not args.dense_grads
+    emb_cfg = {"name": "vanilla", "sparse": True} if sparse else {"name": "vanilla"}
+    if world > 1:
+        from recsys_benchmark_amd.sharded import ShardedDeepFM
+
+        model = ShardedDeepFM(dims, D, hidden, p_dropout=p_drop, use_batchnorm=True, device=dev)
+        parallelism = f"table row-sharded x{world} (RCCL all-to-all) + dp{world} MLP"
+    else:
+        model = pkg.DeepFM(dims, D, hidden, p_dropout=p_drop, use_batchnorm=True,
+                           embedding_config=emb_cfg, fc_sparse=sparse).to(dev)
+        parallelism = "single"
+    model.train()
+    x, y = synth_batch(dims, B, 2023 + rank, dev)
+    lossf = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = lossf(model(x), y)
+        loss.backward()
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    with KernelTimer(capacity=8 * args.steps + 64) as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    pkg.check_index_errors()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ks = kt.summary()
+        fb, bb = alg_bytes_per_sample(F, D)
+        alg = {"gather_fm_fwd": fb * B, "gather_fm_bwd_rows": bb * B, "gather_fm_bwd_dense": bb * B}
+        kernels = {}
+        for k, s in ks.items():
+            e = {"avg_us": round(s["avg_us"], 3), "min_us": round(s["min_us"], 3), "launches": s["count"]}
+            if k in alg:
+                e["alg_bytes"] = alg[k]
+                e["GBps"] = round(alg[k] / (s["avg_us"] * 1e-6) / 1e9, 1)
+            kernels[k] = e
+        cand = [k for k in kernels if k in alg]
+        dom = max(cand, key=lambda k: kernels[k]["avg_us"]) if cand else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if dom and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        roofline = None
+        if dom:
+            ach = kernels[dom]["GBps"]
+            pair_us = sum(kernels[k]["avg_us"] for k in cand)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "avg_us": kernels[dom]["avg_us"],
+                        "fwd_bwd_pair": {"us": round(pair_us, 3),
+                                         "GBps": round((fb + bb) * B / (pair_us * 1e-6) / 1e9, 1),
+                                         "frac": round((fb + bb) * B / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+        out = {
+            "metric": "samples/sec fwd+bwd, Criteo-26field DeepFM b=4096; HBM GB/s vs roofline",
+            "value": round(B * world * args.steps / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2 DeepFM Criteo-26field full embedding: F={F}, D={D}, N={sum(dims)} rows, "
+                                   f"MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, "
+                                   f"{'row-form (COO)' if sparse else 'dense'} table grads",
+                       "global_batch": B * world, "parallelism": parallelism},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(dims, D, hidden, B, p_drop)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,7 @@ def first_order(rows: torch.Tensor, fc_weight: torch.Tensor, bias: torch.Tensor)
 
 
 def mlp_tail(x: torch.Tensor, p: Params, prefix: str, hidden: int, use_bn: bool, training: bool,
-             bn_eps: float = 1e-5) -> torch.Tensor:
+             bn_eps: float = 1e-5, p_dropout: float = 0.0) -> torch.Tensor:
     """(Linear, [BatchNorm1d], ReLU, Dropout(p=0 here))xk + Linear(.,1)
     (src/models/deepfm.py:53-66; src/models/dcn.py:56-66).  Dropout must be off for parity
     (SURVEY.md §7 'BatchNorm + Dropout').  BatchNorm uses batch statistics when training
@@ -57,6 +57,8 @@ def mlp_tail(x: torch.Tensor, p: Params, prefix: str, hidden: int, use_bn: bool,
                 p[f"{prefix}.{i+1}.weight"], p[f"{prefix}.{i+1}.bias"], training=training, eps=bn_eps,
             )
         x = F.relu(x)
+        if p_dropout > 0.0:  # only the cpu_baseline timing leg uses this (RNG-dependent)
+            x = F.dropout(x, p_dropout, training)
         i += step
     return F.linear(x, p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"])
 
@@ -70,9 +72,11 @@ def deepfm_embed_fm(x: torch.Tensor, p: Params) -> Tuple[torch.Tensor, torch.Ten
     return emb, y_fm
 
 
-def deepfm_forward(x: torch.Tensor, p: Params, n_hidden: int, use_bn: bool, training: bool) -> torch.Tensor:
-    """DeepFM.forward, vanilla embedding, dropout off (src/models/deepfm.py:79-105)."""
+def deepfm_forward(x: torch.Tensor, p: Params, n_hidden: int, use_bn: bool, training: bool,
+                   p_dropout: float = 0.0) -> torch.Tensor:
+    """DeepFM.forward, vanilla embedding (src/models/deepfm.py:79-105); dropout off unless asked."""
     emb, y_fm = deepfm_embed_fm(x, p)
     b, nf, d = emb.shape
-    scores = y_fm + mlp_tail(emb.reshape(b, nf * d), p, "_deep_branch", n_hidden, use_bn, training)
+    scores = y_fm + mlp_tail(emb.reshape(b, nf * d), p, "_deep_branch", n_hidden, use_bn, training,
+                             p_dropout=p_dropout)
     return scores.squeeze(-1)
