@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere (CDNA4); nothing here is portable to 32-wide warps.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/mi355x_recsys.h"
@@ -14,12 +15,10 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxGrid = 256 * 8;      // 256 CUs x 8 resident 256-thread workgroups
 
 // ---- profiling ring (mi_prof_*) --------------------------------------------
-struct ProfScope {
-  int slot;
-  hipStream_t s;
-  ProfScope(const char *name, hipStream_t stream);
-  ~ProfScope();
-};
+// prof_acquire returns false when the ring is disarmed or full; otherwise the
+// event pair that hipExtLaunchKernelGGL stamps with the dispatch's own begin /
+// end timestamps (what rocprofv3 --kernel-trace reports), not stream markers.
+bool prof_acquire(const char *name, hipEvent_t *a, hipEvent_t *b);
 
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
@@ -64,10 +63,15 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 
 }  // namespace mi
 
-// Launch `kernel` on `stream` with an optional event pair around it.
-#define MI_LAUNCH(name, kernel, grid, block, stream, ...)                         \
-  do {                                                                            \
-    mi::ProfScope _mi_prof(name, (hipStream_t)(stream));                          \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), \
-                       __VA_ARGS__);                                              \
+// Launch `kernel` on `stream`; when the profiling ring is armed the dispatch is
+// timed by its own start/stop events.
+#define MI_LAUNCH(name, kernel, grid, block, stream, ...)                               \
+  do {                                                                                  \
+    hipEvent_t _ea, _eb;                                                                \
+    if (mi::prof_acquire(name, &_ea, &_eb))                                             \
+      hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream),  \
+                            _ea, _eb, 0, __VA_ARGS__);                                  \
+    else                                                                                \
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream),     \
+                         __VA_ARGS__);                                                  \
   } while (0)

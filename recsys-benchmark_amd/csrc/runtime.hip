@@ -18,20 +18,18 @@ std::atomic<int> g_cap{0};    // 0 = disabled
 }  // namespace
 
 namespace mi {
-ProfScope::ProfScope(const char *name, hipStream_t stream) : slot(-1), s(stream) {
+bool prof_acquire(const char *name, hipEvent_t *a, hipEvent_t *b) {
   int cap = g_cap.load(std::memory_order_relaxed);
-  if (cap <= 0) return;
+  if (cap <= 0) return false;
   int i = g_count.fetch_add(1, std::memory_order_relaxed);
   if (i >= cap) {
     g_count.store(cap, std::memory_order_relaxed);
-    return;
+    return false;
   }
-  slot = i;
   g_ring[i].name = name;
-  (void)hipEventRecord(g_ring[i].a, s);
-}
-ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_ring[slot].b, s);
+  *a = g_ring[i].a;
+  *b = g_ring[i].b;
+  return true;
 }
 }  // namespace mi
 
