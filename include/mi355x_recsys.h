@@ -101,6 +101,62 @@ MI_API int mi_gather_rows_fwd(const int64_t *idx, const float *W, float *out,
 MI_API int mi_scatter_add_rows(const int64_t *idx, const float *g, float *gW,
                                int64_t n, int32_t D, int64_t N, void *stream);
 
+/* ---- a3/a4 over an already gathered emb (DeepFM on a compressed table) -------
+ * y_fm[b] = 0.5*sum_d[(sum_f e)^2 - sum_f e^2] + sum_f w1[rows[b,f]] + bias
+ * (src/models/deepfm.py:91-98).  Its backward is mi_gather_fm_bwd_rows (gradient
+ * w.r.t. emb) plus mi_scatter_add_rows with D=1 (dense w1 gradient).
+ */
+MI_API int mi_fm_fwd(const float *emb, const int64_t *rows, const float *w1,
+                     const float *bias, float *yfm, int64_t B, int32_t F, int32_t D,
+                     int64_t N, int32_t *err, void *stream);
+
+/* ---- a6-a8: two-table compositional lookups, index math fused ---------------
+ *   i1 = idx % mod1  -> row of T1 fp32[n1,De]     i2 = idx / div2 -> row of T2 fp32[n2,De]
+ *   out = T1'[i1] (op) T2'[i2],  op: 0 mult, 1 add, 2 cat
+ *   xform 0: T' = T
+ *         1: T' = sign(T)*relu(|T| - sigmoid(S))   (S1,S2 fp32 threshold logits)
+ *         2: T' = T * M                            (M1,M2 bool masks, 1 byte each)
+ * QR hashing   (src/models/embeddings/qr_embedding.py:95-109): T1=emb1 (divider rows),
+ *              T2=emb2, mod1 = div2 = divider, xform 0.  For op=cat the output is
+ *              [n/F, 2F, De] (torch.cat(dim=1) on a [B,F] input), F=1 for 1-D input.
+ * CERP         (src/models/embeddings/cerp_embedding.py:142-175): T1=P, T2=Q,
+ *              mod1 = bucket_size, div2 = q_entity_per_row, op add, xform 1.
+ * CERP retrain (cerp_embedding.py:329-367): xform 2.
+ * idx int64[n]; negative ids and rows beyond n1/n2 are flagged in *err and yield zeros.
+ */
+MI_API int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2,
+                              const float *S1, const float *S2, const uint8_t *M1,
+                              const uint8_t *M2, float *out, int64_t n, int32_t F,
+                              int32_t De, int64_t n1, int64_t n2, int64_t mod1,
+                              int64_t div2, int32_t op, int32_t xform, int32_t *err,
+                              void *stream);
+
+/* Dense gradients of the above into caller-zeroed gT1/gT2 (and gS1/gS2 for xform 1),
+ * float atomics; tables of <= 4096 elements are pre-summed per workgroup in LDS. */
+MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1,
+                              const float *T2, const float *S1, const float *S2,
+                              const uint8_t *M1, const uint8_t *M2, float *gT1, float *gT2,
+                              float *gS1, float *gS2, int64_t n, int32_t F, int32_t De,
+                              int64_t n1, int64_t n2, int64_t mod1, int64_t div2,
+                              int32_t op, int32_t xform, void *stream);
+
+/* ---- a11: CSR-pruned table rows (numba kernels K1/K2) ------------------------
+ * src/models/embeddings/pruned_embedding.py:136-204: out[i,:] = dense row ids[i] of the
+ * CSR matrix (values fp32, crow/col int64).  out fp32[n,D] need not be pre-zeroed.
+ */
+MI_API int mi_csr_rows_fwd(const float *values, const int64_t *crow, const int64_t *col,
+                           const int64_t *ids, float *out, int64_t n, int32_t D,
+                           int64_t N, int32_t *err, void *stream);
+
+/* ---- a9: DHE universal hash features ------------------------------------------
+ * src/models/embeddings/dh_embedding.py:213-236:
+ *   out[i,k] = 2*(((slopes[k]*(ids[i]+prefix+1)+bias[k]) mod primes[k]) mod m)/(m-1) - 1
+ * int64 floor-mod (bit-exact with torch %), then fp32 in the reference's op order.
+ */
+MI_API int mi_dhe_hash(const int64_t *ids, const int64_t *slopes, const int64_t *bias,
+                       const int64_t *primes, float *out, int64_t n, int32_t K,
+                       int64_t prefix, int64_t m, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

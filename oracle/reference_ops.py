@@ -80,3 +80,91 @@ def deepfm_forward(x: torch.Tensor, p: Params, n_hidden: int, use_bn: bool, trai
     scores = y_fm + mlp_tail(emb.reshape(b, nf * d), p, "_deep_branch", n_hidden, use_bn, training,
                              p_dropout=p_dropout)
     return scores.squeeze(-1)
+
+
+# --------------------------------------------------------------------------- QR hashing
+def qr_table_sizes(num_item: int, divider: Optional[int]) -> Tuple[int, int, int]:
+    """(divider, rows of emb1, rows of emb2) — src/models/embeddings/qr_embedding.py:46-56."""
+    if divider is None:
+        divider = int(math.sqrt(num_item))
+    return divider, divider, (num_item - 1) // divider + 1
+
+
+def qr_forward(idx: torch.Tensor, emb1: torch.Tensor, emb2: torch.Tensor, divider: int, operation: str):
+    """src/models/embeddings/qr_embedding.py:95-109 (mode=None): emb1 by remainder, emb2 by
+    quotient; 'cat' concatenates on dim=1 (so [B,F] ids -> [B,2F,D/2])."""
+    e1 = F.embedding(idx % divider, emb1)
+    e2 = F.embedding(idx // divider, emb2)
+    if operation == "cat":
+        return torch.cat([e1, e2], dim=1)
+    if operation == "add":
+        return e1 + e2
+    if operation == "mult":
+        return e1 * e2
+    raise NotImplementedError(operation)
+
+
+# --------------------------------------------------------------------------- CERP
+def soft_threshold(w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """sign(w) * relu(|w| - sigmoid(s)) — src/models/embeddings/cerp_embedding.py:142-148."""
+    return torch.sign(w) * torch.relu(torch.abs(w) - torch.sigmoid(s))
+
+
+def cerp_forward(idx, p_weight, q_weight, p_threshold, q_threshold, bucket_size: int, q_entity_per_row: int):
+    """src/models/embeddings/cerp_embedding.py:150-162 (mode=None)."""
+    q_idx = torch.div(idx, q_entity_per_row, rounding_mode="trunc")
+    p_idx = idx % bucket_size
+    return F.embedding(q_idx, soft_threshold(q_weight, q_threshold)) + F.embedding(
+        p_idx, soft_threshold(p_weight, p_threshold))
+
+
+def cerp_retrain_forward(idx, p_weight, q_weight, p_mask, q_mask, bucket_size: int, q_entity_per_row: int):
+    """src/models/embeddings/cerp_embedding.py:329-352 (mode=None): fixed boolean masks."""
+    q_idx = torch.div(idx, q_entity_per_row, rounding_mode="trunc")
+    p_idx = idx % bucket_size
+    return F.embedding(q_idx, q_weight * q_mask) + F.embedding(p_idx, p_weight * p_mask)
+
+
+# --------------------------------------------------------------------------- DHE
+def dhe_hash(ids: torch.Tensor, slopes, bias, primes, prefix: int, m: int = 1000000) -> torch.Tensor:
+    """_get_universal_hash_batch — src/models/embeddings/dh_embedding.py:213-236.  torch's % on
+    int64 is floor-mod; int / int is true division in fp32."""
+    result = slopes.unsqueeze(0) * (ids.unsqueeze(1) + prefix + 1) + bias.unsqueeze(0)
+    result = result % primes.unsqueeze(0) % m
+    result = result / (m - 1)
+    return result * 2 - 1
+
+
+def dhe_mlp(x: torch.Tensor, p: Params, n_layers: int, use_bn: int, training: bool, prefix: str = "_seq"):
+    """The Linear / BatchNorm1d / Mish stack of DHEmbedding (dh_embedding.py:99-117)."""
+    i = 0
+    for _ in range(n_layers):
+        x = F.linear(x, p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"])
+        i += 1
+        if use_bn == 2:
+            x = F.batch_norm(x, p[f"{prefix}.{i}.running_mean"].clone(), p[f"{prefix}.{i}.running_var"].clone(),
+                             p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"], training=training)
+            x = F.mish(x)
+            i += 2
+        elif use_bn == 1:
+            x = F.mish(x)
+            x = F.batch_norm(x, p[f"{prefix}.{i+1}.running_mean"].clone(), p[f"{prefix}.{i+1}.running_var"].clone(),
+                             p[f"{prefix}.{i+1}.weight"], p[f"{prefix}.{i+1}.bias"], training=training)
+            i += 2
+        else:
+            x = F.mish(x)
+            i += 1
+    return x
+
+
+# --------------------------------------------------------------------------- CSR-pruned rows
+def csr_rows(values, crow, col, ids, hidden_size: int) -> torch.Tensor:
+    """csr_embedding_lookup_cpu — src/models/embeddings/pruned_embedding.py:187-204 (numba there;
+    numba is not installed here, so this is pinned by the dense-lookup equivalence the reference's own
+    test asserts, tests/test_emb.py:375-393).  Pure-Python loops: small cases only."""
+    flat = ids.flatten().tolist()
+    out = torch.zeros((len(flat), hidden_size), dtype=torch.float32)
+    for k, rowid in enumerate(flat):
+        for i in range(int(crow[rowid]), int(crow[rowid + 1])):
+            out[k, int(col[i])] = values[i]
+    return out.reshape(*ids.shape, hidden_size)

@@ -1,0 +1,460 @@
+// embed.hip — compressed-embedding lookups with the index math fused into the gather:
+//   * dual-table compositional lookups: QR (quotient-remainder) hashing and CERP
+//   * CSR-pruned table rows (the reference's numba kernels K1/K2)
+//   * DHE universal-hash feature generator
+//   * FM second-order + first-order term over an already gathered emb tensor
+//
+// Reference arithmetic:
+//   QR    src/models/embeddings/qr_embedding.py:95-109   (r = idx % divider, q = idx // divider,
+//         out = emb1[r] (*|+|cat) emb2[q]; cat is along dim=1 => [B,2F,D/2] for 2-D input)
+//   CERP  src/models/embeddings/cerp_embedding.py:142-175 (q = trunc(idx / q_entity_per_row),
+//         p = idx % bucket, out = S(Q)[q] + S(P)[p], S(w) = sign(w)*relu(|w| - sigmoid(s)));
+//         retrain variant :329-367 (w * mask)
+//   CSR   src/models/embeddings/pruned_embedding.py:136-204
+//   DHE   src/models/embeddings/dh_embedding.py:213-236
+//   FM    src/models/deepfm.py:91-98
+//
+// Lane mapping as in gather_fm.hip: a row of De = 4*LPR floats is LPR adjacent lanes x
+// float4; a wave-instruction covers RS = 64/LPR lookups.
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+enum { OP_MULT = 0, OP_ADD = 1, OP_CAT = 2 };
+enum { XF_NONE = 0, XF_SOFT = 1, XF_MASK = 2 };
+
+struct DualTables {
+  const float *T1, *T2;      // [n1,De], [n2,De]
+  const float *S1, *S2;      // XF_SOFT: threshold logits, same shapes
+  const uint8_t *M1, *M2;    // XF_MASK: bool masks, same shapes
+  int64_t n1, n2;
+  int64_t mod1;              // i1 = idx % mod1
+  int64_t div2;              // i2 = idx / div2
+};
+
+__device__ __forceinline__ float sigmoidf_(float s) { return 1.f / (1.f + expf(-s)); }
+__device__ __forceinline__ float signf_(float w) { return (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float soft_(float w, float s) {
+  const float u = fabsf(w) - sigmoidf_(s);
+  return signf_(w) * (u > 0.f ? u : 0.f);
+}
+
+template <int XF>
+__device__ __forceinline__ float4 load_row4(const float *T, const float *S, const uint8_t *M, int64_t o) {
+  float4 w = ld4(T + o);
+  if constexpr (XF == XF_SOFT) {
+    const float4 s = ld4(S + o);
+    w.x = soft_(w.x, s.x); w.y = soft_(w.y, s.y); w.z = soft_(w.z, s.z); w.w = soft_(w.w, s.w);
+  } else if constexpr (XF == XF_MASK) {
+    const uchar4 m = *reinterpret_cast<const uchar4 *>(M + o);
+    w.x = m.x ? w.x : 0.f; w.y = m.y ? w.y : 0.f; w.z = m.z ? w.z : 0.f; w.w = m.w ? w.w : 0.f;
+  }
+  return w;
+}
+
+// element offset of lookup i's output row(s); CAT puts table-1 rows at field f and table-2 rows at
+// field F+f of a [B,2F,De] tensor (torch.cat(dim=1) quirk).
+__device__ __forceinline__ void out_offsets(int op, int64_t i, int F, int De, int64_t &o1, int64_t &o2) {
+  if (op == OP_CAT) {
+    const int64_t b = i / F, f = i % F;
+    o1 = (b * 2 * F + f) * De;
+    o2 = o1 + (int64_t)F * De;
+  } else {
+    o1 = o2 = i * De;
+  }
+}
+
+template <int LPR, int XF>
+__global__ __launch_bounds__(kBlock) void k_dual_fwd(const int64_t *__restrict__ idx, DualTables t,
+                                                     float *__restrict__ out, int64_t n, int F, int op,
+                                                     int *err) {
+  constexpr int RS = kWave / LPR;
+  constexpr int De = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t ntiles = (n + RS - 1) / RS;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  int bad = 0;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t i = tile * RS + r;
+    if (i >= n) continue;
+    const int64_t id = idx[i];
+    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    const bool ok = id >= 0 && i1 < t.n1 && i2 < t.n2;
+    bad |= !ok;
+    float4 a = z, b = z;
+    if (ok) {
+      a = load_row4<XF>(t.T1, t.S1, t.M1, i1 * De + q * 4);
+      b = load_row4<XF>(t.T2, t.S2, t.M2, i2 * De + q * 4);
+    }
+    int64_t o1, o2;
+    out_offsets(op, i, F, De, o1, o2);
+    if (op == OP_CAT) {
+      st4(out + o1 + q * 4, a);
+      st4(out + o2 + q * 4, b);
+    } else if (op == OP_MULT) {
+      st4(out + o1 + q * 4, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
+    } else {
+      st4(out + o1 + q * 4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+__device__ __forceinline__ float load_el(int xf, const float *T, const float *S, const uint8_t *M, int64_t o) {
+  const float w = T[o];
+  if (xf == XF_SOFT) return soft_(w, S[o]);
+  if (xf == XF_MASK) return M[o] ? w : 0.f;
+  return w;
+}
+
+// any De: one thread per output element of the lookup.
+__global__ __launch_bounds__(kBlock) void k_dual_fwd_anyD(const int64_t *__restrict__ idx, DualTables t,
+                                                          float *__restrict__ out, int64_t n, int F, int De,
+                                                          int op, int xf, int *err) {
+  const int64_t total = n * De;
+  int bad = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / De;
+    const int d = (int)(e % De);
+    const int64_t id = idx[i];
+    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    const bool ok = id >= 0 && i1 < t.n1 && i2 < t.n2;
+    bad |= !ok;
+    const float a = ok ? load_el(xf, t.T1, t.S1, t.M1, i1 * De + d) : 0.f;
+    const float b = ok ? load_el(xf, t.T2, t.S2, t.M2, i2 * De + d) : 0.f;
+    int64_t o1, o2;
+    out_offsets(op, i, F, De, o1, o2);
+    if (op == OP_CAT) {
+      out[o1 + d] = a;
+      out[o2 + d] = b;
+    } else {
+      out[o1 + d] = (op == OP_MULT) ? a * b : a + b;
+    }
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// Backward: one thread per element; dense float-atomic scatter into the table gradients.
+// Tables whose gradient fits `lds_floats` are first summed per workgroup in LDS (ds_add_f32) and
+// flushed once: QR's remainder table can have as few as 2 rows, and every lookup adding into
+// one row of global memory runs an order of magnitude under the atomic rate
+// (MI355X_MICROARCH.md, "Global float atomics", contention row).
+struct DualGrads {
+  float *gT1, *gT2;  // [n1,De], [n2,De]
+  float *gS1, *gS2;  // XF_SOFT only
+};
+
+constexpr int kLdsAccFloats = 8192;  // 32 KiB
+
+__global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__ idx, DualTables t,
+                                                     const float *__restrict__ g, DualGrads gr, int64_t n,
+                                                     int F, int De, int op, int xf, int lds1, int lds2) {
+  __shared__ float acc[kLdsAccFloats];
+  // acc layout: [table-1 grads | table-2 grads] for whichever table is LDS-accumulated
+  const int n1e = lds1 ? (int)(t.n1 * De) : 0;
+  const int n2e = lds2 ? (int)(t.n2 * De) : 0;
+  for (int k = threadIdx.x; k < n1e + n2e; k += blockDim.x) acc[k] = 0.f;
+  if (n1e + n2e) __syncthreads();
+
+  const int64_t total = n * De;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / De;
+    const int d = (int)(e % De);
+    const int64_t id = idx[i];
+    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) continue;
+    int64_t o1, o2;
+    out_offsets(op, i, F, De, o1, o2);
+    const int64_t a1 = i1 * De + d, a2 = i2 * De + d;
+    float g1, g2, s1 = 0.f, s2 = 0.f;
+    if (op == OP_CAT) {
+      g1 = g[o1 + d];
+      g2 = g[o2 + d];
+    } else if (op == OP_MULT) {
+      const float go = g[o1 + d];
+      g1 = go * load_el(xf, t.T2, t.S2, t.M2, a2);
+      g2 = go * load_el(xf, t.T1, t.S1, t.M1, a1);
+    } else {
+      g1 = g2 = g[o1 + d];
+    }
+    if (xf == XF_SOFT) {
+      // y = sign(w) relu(|w| - sig(s)):  dy/dw = [|w| > sig(s)],  dy/ds = -sign(w) [..] sig (1 - sig)
+      const float w1 = t.T1[a1], w2 = t.T2[a2];
+      const float t1 = sigmoidf_(t.S1[a1]), t2 = sigmoidf_(t.S2[a2]);
+      const float k1 = (fabsf(w1) - t1 > 0.f) ? 1.f : 0.f, k2 = (fabsf(w2) - t2 > 0.f) ? 1.f : 0.f;
+      s1 = -g1 * signf_(w1) * k1 * t1 * (1.f - t1);
+      s2 = -g2 * signf_(w2) * k2 * t2 * (1.f - t2);
+      g1 *= k1;
+      g2 *= k2;
+    } else if (xf == XF_MASK) {
+      g1 = t.M1[a1] ? g1 : 0.f;
+      g2 = t.M2[a2] ? g2 : 0.f;
+    }
+    if (lds1) atomicAdd(&acc[a1], g1); else atomicAdd(gr.gT1 + a1, g1);
+    if (lds2) atomicAdd(&acc[n1e + a2], g2); else atomicAdd(gr.gT2 + a2, g2);
+    if (xf == XF_SOFT) {
+      atomicAdd(gr.gS1 + a1, s1);
+      atomicAdd(gr.gS2 + a2, s2);
+    }
+  }
+  if (n1e + n2e) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < n1e; k += blockDim.x)
+      if (acc[k] != 0.f) atomicAdd(gr.gT1 + k, acc[k]);
+    for (int k = threadIdx.x; k < n2e; k += blockDim.x)
+      if (acc[n1e + k] != 0.f) atomicAdd(gr.gT2 + k, acc[n1e + k]);
+  }
+}
+
+// ------------------------------------------------------------- CSR-pruned rows ------
+// K1/K2 of the reference: out[i,:] = 0; out[i, col[j]] = values[j] for j in the CSR row ids[i].
+// One thread per output element: lane d scans the (short) row for its own column, so the row is
+// written once, coalesced, with no zero-fill pass and no write race.  Later duplicates win, as in
+// the reference's serial loop.
+__global__ __launch_bounds__(kBlock) void k_csr_rows(const float *__restrict__ values,
+                                                     const int64_t *__restrict__ crow,
+                                                     const int64_t *__restrict__ col,
+                                                     const int64_t *__restrict__ ids, float *__restrict__ out,
+                                                     int64_t n, int D, int64_t N, int *err) {
+  const int64_t total = n * D;
+  int bad = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / D;
+    const int d = (int)(e % D);
+    const int64_t row = ids[i];
+    float v = 0.f;
+    if ((uint64_t)row < (uint64_t)N) {
+      const int64_t lo = crow[row], hi = crow[row + 1];
+      for (int64_t j = lo; j < hi; ++j)
+        if (col[j] == d) v = values[j];
+    } else {
+      bad = 1;
+    }
+    out[e] = v;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// ------------------------------------------------------------- DHE hash -------------
+// out[i,k] = 2 * (((a_k*(id_i+prefix+1) + b_k) mod p_k) mod m) / (m-1) - 1, int64 FLOOR mod as
+// torch's % (a_k, b_k may be negative), then the reference's fp32 op order: int -> float,
+// true-divide by float(m-1), *2, -1 (dh_embedding.py:229-234).
+__device__ __forceinline__ int64_t floormod(int64_t a, int64_t p) {
+  int64_t r = a % p;
+  return (r != 0 && ((r < 0) != (p < 0))) ? r + p : r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_dhe_hash(const int64_t *__restrict__ ids,
+                                                     const int64_t *__restrict__ slopes,
+                                                     const int64_t *__restrict__ bias,
+                                                     const int64_t *__restrict__ primes, float *__restrict__ out,
+                                                     int64_t n, int K, int64_t prefix, int64_t m) {
+  const int64_t total = n * K;
+  const float denom = (float)(m - 1);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / K;
+    const int k = (int)(e % K);
+    const int64_t v = slopes[k] * (ids[i] + prefix + 1) + bias[k];
+    const int64_t h = floormod(floormod(v, primes[k]), m);
+    float f = (float)h / denom;
+    f = f * 2.f;
+    out[e] = f - 1.f;
+  }
+}
+
+// ------------------------------------------------------------- FM over a given emb --
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_fm_fwd(const float *__restrict__ emb,
+                                                   const int64_t *__restrict__ rows,
+                                                   const float *__restrict__ w1, const float *__restrict__ bias,
+                                                   float *__restrict__ yfm, int64_t B, int F, int64_t N, int *err) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float bv = bias ? bias[0] : 0.f;
+  int bad = 0;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ss = 0.f, lin = 0.f;
+    for (int f = r; f < F; f += RS) {
+      const float4 v = ld4(emb + (base + f) * D + q * 4);
+      S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
+      ss += dot4(v, v);
+      if (q == 0) {
+        const int64_t row = rows[base + f];
+        if ((uint64_t)row < (uint64_t)N) lin += w1[row]; else bad = 1;
+      }
+    }
+    S = slot_sum<LPR>(S);
+    float t = (r == 0 ? dot4(S, S) : 0.f) - ss;
+    t = wave_sum(0.5f * t + lin);
+    if (lane == 0) yfm[b] = t + bv;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fm_fwd_anyD(const float *__restrict__ emb,
+                                                        const int64_t *__restrict__ rows,
+                                                        const float *__restrict__ w1,
+                                                        const float *__restrict__ bias, float *__restrict__ yfm,
+                                                        int64_t B, int F, int D, int64_t N, int *err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float bv = bias ? bias[0] : 0.f;
+  int bad = 0;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t base = b * F;
+    float t = 0.f;
+    for (int f = lane; f < F; f += kWave) {
+      const int64_t row = rows[base + f];
+      if ((uint64_t)row < (uint64_t)N) t += w1[row]; else bad = 1;
+    }
+    for (int d = lane; d < D; d += kWave) {
+      float S = 0.f, ss = 0.f;
+      for (int f = 0; f < F; ++f) {
+        const float v = emb[(base + f) * D + d];
+        S += v;
+        ss += v * v;
+      }
+      t += 0.5f * (S * S - ss);
+    }
+    t = wave_sum(t);
+    if (lane == 0) yfm[b] = t + bv;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0; }
+inline int grid_for_elems(int64_t total) {
+  int64_t g = (total + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2, const float *S1,
+                       const float *S2, const uint8_t *M1, const uint8_t *M2, float *out, int64_t n,
+                       int32_t F, int32_t De, int64_t n1, int64_t n2, int64_t mod1, int64_t div2, int32_t op,
+                       int32_t xform, int32_t *err, void *stream) {
+  if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
+  if (op < OP_MULT || op > OP_CAT || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !T1 || !T2 || !out) return MI_ERR_INVALID_ARG;
+  if (xform == XF_SOFT && (!S1 || !S2)) return MI_ERR_INVALID_ARG;
+  if (xform == XF_MASK && (!M1 || !M2)) return MI_ERR_INVALID_ARG;
+  if (op == OP_CAT && n % F != 0) return MI_ERR_INVALID_ARG;
+  DualTables t{T1, T2, S1, S2, M1, M2, n1, n2, mod1, div2};
+  const bool al = aligned16(T1) && aligned16(T2) && aligned16(out) && (xform != XF_SOFT || (aligned16(S1) && aligned16(S2))) &&
+                  (xform != XF_MASK || (((uintptr_t)M1 & 3) == 0 && ((uintptr_t)M2 & 3) == 0));
+  if (vec_ok(De) && al) {
+    const int lpr = De / 4;
+    const int64_t tiles = (n + (kWave / lpr) - 1) / (kWave / lpr);
+    const int grid = grid_for_waves(tiles);
+#define CALL(LPR)                                                                                            \
+  do {                                                                                                       \
+    if (xform == XF_NONE) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_NONE>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
+    else if (xform == XF_SOFT) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_SOFT>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
+    else MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_MASK>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
+  } while (0)
+    switch (lpr) {
+      case 1: CALL(1); break;
+      case 2: CALL(2); break;
+      case 4: CALL(4); break;
+      case 8: CALL(8); break;
+      case 16: CALL(16); break;
+      case 32: CALL(32); break;
+      case 64: CALL(64); break;
+      default: return MI_ERR_UNSUPPORTED;
+    }
+#undef CALL
+  } else {
+    MI_LAUNCH("dual_gather_fwd", k_dual_fwd_anyD, grid_for_elems(n * De), kBlock, stream, idx, t, out, n, F,
+              De, op, xform, err);
+  }
+  return launch_status();
+}
+
+int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, const float *T2,
+                       const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *gT1,
+                       float *gT2, float *gS1, float *gS2, int64_t n, int32_t F, int32_t De, int64_t n1,
+                       int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform, void *stream) {
+  if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
+  if (op < OP_MULT || op > OP_CAT || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !g_out || !T1 || !T2 || !gT1 || !gT2) return MI_ERR_INVALID_ARG;
+  if (xform == XF_SOFT && (!S1 || !S2 || !gS1 || !gS2)) return MI_ERR_INVALID_ARG;
+  if (xform == XF_MASK && (!M1 || !M2)) return MI_ERR_INVALID_ARG;
+  DualTables t{T1, T2, S1, S2, M1, M2, n1, n2, mod1, div2};
+  DualGrads gr{gT1, gT2, gS1, gS2};
+  // LDS pre-aggregation for small tables; fewer, fatter workgroups then bound the flush traffic
+  int lds1 = (n1 * De <= kLdsAccFloats / 2), lds2 = (n2 * De <= kLdsAccFloats / 2);
+  int grid = grid_for_elems(n * De);
+  if ((lds1 || lds2) && grid > 512) grid = 512;
+  MI_LAUNCH("dual_gather_bwd", k_dual_bwd, grid, kBlock, stream, idx, t, g_out, gr, n, F, De, op, xform, lds1,
+            lds2);
+  return launch_status();
+}
+
+int mi_csr_rows_fwd(const float *values, const int64_t *crow, const int64_t *col, const int64_t *ids,
+                    float *out, int64_t n, int32_t D, int64_t N, int32_t *err, void *stream) {
+  if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!crow || !ids || !out) return MI_ERR_INVALID_ARG;  // values/col may be null for an all-zero table
+  MI_LAUNCH("csr_rows", k_csr_rows, grid_for_elems(n * D), kBlock, stream, values, crow, col, ids, out, n, D, N,
+            err);
+  return launch_status();
+}
+
+int mi_dhe_hash(const int64_t *ids, const int64_t *slopes, const int64_t *bias, const int64_t *primes,
+                float *out, int64_t n, int32_t K, int64_t prefix, int64_t m, void *stream) {
+  if (n < 0 || K <= 0 || m <= 1) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!ids || !slopes || !bias || !primes || !out) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("dhe_hash", k_dhe_hash, grid_for_elems(n * K), kBlock, stream, ids, slopes, bias, primes, out, n, K,
+            prefix, m);
+  return launch_status();
+}
+
+int mi_fm_fwd(const float *emb, const int64_t *rows, const float *w1, const float *bias, float *yfm,
+              int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!emb || !rows || !w1 || !yfm) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  if (vec_ok(D) && aligned16(emb)) {
+#define CALL(LPR) MI_LAUNCH("fm_fwd", (k_fm_fwd<LPR>), grid, kBlock, stream, emb, rows, w1, bias, yfm, B, F, N, err)
+    switch (D / 4) {
+      case 1: CALL(1); break;
+      case 2: CALL(2); break;
+      case 4: CALL(4); break;
+      case 8: CALL(8); break;
+      case 16: CALL(16); break;
+      case 32: CALL(32); break;
+      case 64: CALL(64); break;
+      default: return MI_ERR_UNSUPPORTED;
+    }
+#undef CALL
+  } else {
+    MI_LAUNCH("fm_fwd", k_fm_fwd_anyD, grid, kBlock, stream, emb, rows, w1, bias, yfm, B, F, D, N, err);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

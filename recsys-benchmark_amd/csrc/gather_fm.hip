@@ -359,15 +359,15 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(
 __global__ __launch_bounds__(kBlock) void k_gather_rows_anyD(
     const int64_t *__restrict__ idx, const float *__restrict__ W, float *__restrict__ out,
     int64_t n, int D, int64_t N, int *err) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  // one thread per output element: coalesced for any D (D = 1 included)
+  const int64_t total = n * D;
   int bad = 0;
-  for (int64_t i = wave0; i < n; i += nwaves) {
-    const int64_t row = idx[i];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx[e / D];
     const bool ok = (uint64_t)row < (uint64_t)N;
     bad |= !ok;
-    for (int d = lane; d < D; d += kWave) out[i * D + d] = ok ? W[row * D + d] : 0.f;
+    out[e] = ok ? W[row * D + e % D] : 0.f;
   }
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
 }
@@ -416,13 +416,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter_add_rows(
 __global__ __launch_bounds__(kBlock) void k_scatter_add_rows_anyD(
     const int64_t *__restrict__ idx, const float *__restrict__ g, float *__restrict__ gW,
     int64_t n, int D, int64_t N) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  for (int64_t i = wave0; i < n; i += nwaves) {
-    const int64_t row = idx[i];
-    if ((uint64_t)row >= (uint64_t)N) continue;
-    for (int d = lane; d < D; d += kWave) atomicAdd(gW + row * D + d, g[i * D + d]);
+  const int64_t total = n * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx[e / D];
+    if ((uint64_t)row < (uint64_t)N) atomicAdd(gW + row * D + e % D, g[e]);
   }
 }
 
@@ -546,8 +544,8 @@ int mi_gather_rows_fwd(const int64_t *idx, const float *W, float *out, int64_t n
     MI_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   } else {
-    MI_LAUNCH("gather_rows", k_gather_rows_anyD, grid_for_waves(n), kBlock, stream, idx, W, out,
-              n, D, N, err);
+    MI_LAUNCH("gather_rows", k_gather_rows_anyD, grid_for_waves(((int64_t)n * D + kWave - 1) / kWave),
+              kBlock, stream, idx, W, out, n, D, N, err);
   }
   return launch_status();
 }
@@ -566,8 +564,8 @@ int mi_scatter_add_rows(const int64_t *idx, const float *g, float *gW, int64_t n
     MI_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   } else {
-    MI_LAUNCH("scatter_add_rows", k_scatter_add_rows_anyD, grid_for_waves(n), kBlock, stream, idx,
-              g, gW, n, D, N);
+    MI_LAUNCH("scatter_add_rows", k_scatter_add_rows_anyD,
+              grid_for_waves(((int64_t)n * D + kWave - 1) / kWave), kBlock, stream, idx, g, gW, n, D, N);
   }
   return launch_status();
 }

@@ -10,9 +10,17 @@ import copy
 from typing import Any, Dict, List, Optional, Tuple, Union
 
 from .base import IEmbedding, VanillaEmbedding
+from .cerp_embedding import CerpEmbedding, RetrainCerpEmbedding
+from .dh_embedding import DHEmbedding
+from .pruned_embedding import PrunedEmbedding
+from .qr_embedding import QRHashingEmbedding
 
 NAME_TO_CLS: Dict[str, type] = {
     "vanilla": VanillaEmbedding,
+    "qr": QRHashingEmbedding,
+    "dhe": DHEmbedding,
+    "cerp": CerpEmbedding,
+    "cerp_retrain": RetrainCerpEmbedding,
 }
 
 # registry keys of the reference that this build deliberately does not cover
@@ -73,4 +81,5 @@ def detect_special(config: Dict[str, Any]) -> Tuple[Optional[str], bool]:
     return None, False
 
 
-__all__ = ["IEmbedding", "VanillaEmbedding", "NAME_TO_CLS", "get_embedding", "detect_special"]
+__all__ = ["IEmbedding", "VanillaEmbedding", "QRHashingEmbedding", "CerpEmbedding", "RetrainCerpEmbedding",
+           "DHEmbedding", "PrunedEmbedding", "NAME_TO_CLS", "get_embedding", "detect_special"]

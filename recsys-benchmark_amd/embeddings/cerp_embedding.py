@@ -1,0 +1,225 @@
+"""CERP compositional + soft-threshold-pruned embedding.
+
+Reference: src/models/embeddings/cerp_embedding.py:14-207 (CerpEmbedding) and :209-378
+(RetrainCerpEmbedding).  Same constructors, parameter names (`p_weight`, `q_weight`,
+`p_threshold`, `q_threshold`; masks `p_mask`, `q_mask`), initialisers and helper methods.
+The reference materialises the pruned copies of both tables on every forward and then does two
+F.embedding calls; here index math (trunc-div / mod), soft-threshold (or mask) and the add are
+fused into one HIP gather over the raw tables (mi_dual_gather_fwd, xform 1 / 2).
+"""
+import os
+from typing import List, Literal, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _kernels
+from .base import IEmbedding
+
+
+class CerpEmbedding(IEmbedding):
+    def __init__(
+        self,
+        field_dims: Union[List[int], int],
+        hidden_size: int,
+        mode: Optional[str] = None,
+        bucket_size: int = 8000,
+        threshold_init: float = -100.0,
+        threshold_init_method="all-ones",
+        field_name: str = "",
+    ):
+        super().__init__()
+        if isinstance(field_dims, int):
+            field_dims = [field_dims]
+        assert mode in [None, "sum", "mean", "max"]
+
+        num_item = sum(field_dims)
+        self._field_dims = torch.tensor(field_dims)
+        self._mode = mode
+        self.field_name: str = field_name
+
+        self.p_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
+        self.q_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
+        nn.init.xavier_uniform_(self.p_weight)
+        nn.init.xavier_uniform_(self.q_weight)
+
+        self.q_threshold = self.init_threshold(
+            "element-wise", threshold_init, row_size=bucket_size, col_size=hidden_size,
+            threshold_init_method=threshold_init_method,
+        )
+        self.p_threshold = self.init_threshold(
+            "element-wise", threshold_init, row_size=bucket_size, col_size=hidden_size,
+            threshold_init_method=threshold_init_method,
+        )
+
+        self._num_item = num_item
+        self._hidden_size = hidden_size
+        self._bucket_size = bucket_size
+        # Q's avg entities per row = ceil(#entities / bucket size)
+        self.q_entity_per_row = int(np.ceil(self._num_item / self._bucket_size))
+
+    @staticmethod
+    def init_threshold(
+        threshold_type: Literal["global", "element-wise"],
+        init: float,
+        row_size: int,
+        col_size: int,
+        threshold_init_method: str = "all_ones",
+    ) -> nn.Parameter:
+        """Same distributions and scaling as the reference (cerp_embedding.py:74-140)."""
+        requires_scaling = True
+        if threshold_type == "global":
+            mat = torch.ones(1)
+            if threshold_init_method == "uniform":
+                mat = mat * torch.rand(1)
+                requires_scaling = False
+            elif threshold_init_method == "normal":
+                mat = mat * torch.normal(mean=0.0, std=1.0, size=(1,))
+            elif threshold_init_method == "xavier_uniform":
+                raise NotImplementedError
+            else:
+                requires_scaling = False
+            if requires_scaling:
+                mat = torch.sigmoid(mat)
+            return nn.Parameter(mat * init)
+        elif threshold_type == "element-wise":
+            mat = torch.ones([row_size, col_size])
+            if threshold_init_method == "uniform":
+                mat = mat * torch.nn.init.uniform_(torch.zeros((row_size, col_size)))
+            elif threshold_init_method == "normal":
+                mat = mat * torch.normal(mean=0.0, std=1.0, size=mat.shape)
+            elif threshold_init_method == "xavier_uniform":
+                mat = mat * nn.init.xavier_uniform_(torch.zeros(size=mat.shape))
+            else:
+                requires_scaling = False
+            if requires_scaling:
+                mat_min, _ = mat.min(dim=1, keepdim=True)
+                mat_max, _ = mat.max(dim=1, keepdim=True)
+                mat = (mat - mat_min) / (mat_max - mat_min)
+            assert (0 <= mat).all() and (1 >= mat).all()
+            return nn.Parameter(init * mat)
+        raise ValueError("Invalid threshold_type: {}".format(threshold_type))
+
+    def apply_pruning(self):
+        """Materialised pruned tables, for the bookkeeping helpers only (the lookup fuses this)."""
+        self.sparse_q_weight = torch.sign(self.q_weight) * torch.relu(
+            torch.abs(self.q_weight) - torch.sigmoid(self.q_threshold)
+        )
+        self.sparse_p_weight = torch.sign(self.p_weight) * torch.relu(
+            torch.abs(self.p_weight) - torch.sigmoid(self.p_threshold)
+        )
+
+    def forward(self, x):
+        emb = _kernels.dual_gather(
+            x, self.p_weight, self.q_weight, mod1=self._bucket_size, div2=self.q_entity_per_row,
+            op="add", S1=self.p_threshold, S2=self.q_threshold,
+        )
+        # sum/mean of (Q rows + P rows) == sum/mean(Q rows) + sum/mean(P rows); max is taken
+        # over the summed rows in the reference as well (cerp_embedding.py:160-175)
+        return _kernels.bag_reduce(emb, self._mode)
+
+    def get_sparsity(self, get_n_params=False):
+        total_params = self._num_item * self._hidden_size
+        n_params = self.get_num_params()
+        if get_n_params:
+            return (1 - n_params / total_params), n_params
+        return 1 - n_params / total_params
+
+    def get_weight(self):
+        all_idxes = torch.arange(self._num_item, device=self.p_weight.data.device)
+        return self(all_idxes)
+
+    def get_num_params(self):
+        self.apply_pruning()
+        n_params = 0
+        for w in [self.sparse_p_weight, self.sparse_q_weight]:
+            n_params += torch.count_nonzero(w).item()
+        return n_params
+
+    def get_prune_loss(self, K=100):
+        self.apply_pruning()
+        emb = self.sparse_p_weight + self.sparse_q_weight
+        return -torch.tanh(emb * K).norm(2) ** 2
+
+
+class RetrainCerpEmbedding(IEmbedding):
+    """Fixed-mask retraining variant; weights/masks come from
+    {checkpoint_weight_dir}/{field_name}/{initial,<weight_name>}.pth exactly as in the reference."""
+
+    def __init__(
+        self,
+        field_dims: Union[List[int], int],
+        hidden_size: int,
+        mode: Optional[str],
+        checkpoint_weight_dir: str,
+        field_name: str = "",
+        weight_name: str = "target",
+        bucket_size: int = 8000,
+        sparse: bool = False,
+    ):
+        super().__init__()
+        if isinstance(field_dims, int):
+            field_dims = [field_dims]
+
+        mask_weight_path = os.path.join(checkpoint_weight_dir, field_name, f"{weight_name}.pth")
+        init_weight_path = os.path.join(checkpoint_weight_dir, field_name, "initial.pth")
+        assert os.path.exists(mask_weight_path), f"Weight not found at {mask_weight_path} to re-init mask"
+        assert os.path.exists(
+            init_weight_path
+        ), f"Weight not found at {init_weight_path} to re-init original weight"
+
+        num_item = sum(field_dims)
+        self._field_dims = torch.tensor(field_dims)
+        self._mode = mode
+        self.field_name: str = field_name
+        self._bucket_size = bucket_size
+        self._hidden_size = hidden_size
+
+        self.p_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
+        self.q_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
+        init_weight = torch.load(init_weight_path, map_location="cpu")
+
+        self.q_mask, self.p_mask = None, None
+        assert init_weight["q_weight"].shape == (bucket_size, hidden_size), (
+            f"{init_weight['q_weight'].shape} != {(bucket_size, hidden_size)}")
+        assert init_weight["p_weight"].shape == (bucket_size, hidden_size)
+        self.q_weight.data = init_weight["q_weight"]
+        self.p_weight.data = init_weight["p_weight"]
+        self.q_mask, self.p_mask = self.load_mask(mask_weight_path)
+
+        self._num_item = num_item
+        self.q_entity_per_row = int(np.ceil(self._num_item / self._bucket_size))
+        self._sparse = sparse
+        if sparse:
+            raise NotImplementedError("RetrainCerpEmbedding(sparse=True): row-form grads of the two "
+                                      "bucket tables are not built; use the dense form")
+
+    def load_mask(self, weight_path: str) -> List[nn.Parameter]:
+        checkpoint = torch.load(weight_path, map_location="cpu")
+        names: Tuple[Tuple[str, str], Tuple[str, str]] = (
+            ("q_weight", "q_threshold"),
+            ("p_weight", "p_threshold"),
+        )
+        masks = []
+        for weight_name, threshold_name in names:
+            weight = checkpoint[weight_name]
+            threshold = checkpoint[threshold_name]
+            mask = (weight.abs() - torch.sigmoid(threshold)) > 0
+            assert mask.shape == (self._bucket_size, self._hidden_size)
+            masks.append(nn.Parameter(mask, False))
+        return masks
+
+    def get_weight(self):
+        all_idxes = torch.arange(self._num_item, device=self.p_weight.data.device)
+        return self(all_idxes)
+
+    def forward(self, x):
+        emb = _kernels.dual_gather(
+            x, self.p_weight, self.q_weight, mod1=self._bucket_size, div2=self.q_entity_per_row,
+            op="add", M1=self.p_mask, M2=self.q_mask,
+        )
+        return _kernels.bag_reduce(emb, self._mode)
+
+    def get_num_params(self):
+        return (torch.count_nonzero(self.q_mask) + torch.count_nonzero(self.p_mask)).item()
