@@ -157,6 +157,25 @@ MI_API int mi_dhe_hash(const int64_t *ids, const int64_t *slopes, const int64_t 
                        const int64_t *primes, float *out, int64_t n, int32_t K,
                        int64_t prefix, int64_t m, void *stream);
 
+/* ---- a14: LightGCN propagation step, CSR SpMM with fused layer-sum ----------
+ * src/models/lightgcn.py:82-88 (`step = matrix @ step; res = res + step; res / (L+1)`):
+ *   y        = A[row,:] . X                      A in CSR: crow int32[n_rows+1], col int32, val fp32
+ *   Y[row]   = y                                 (Y nullable: the last layer needs no `step`)
+ *   acc_out[row] = (acc_in[row] + y) * scale     (acc_out nullable; acc_in nullable = 0; in place ok)
+ * The reference hands over int64 crow/col (torch CSR); the host converts them to int32 once per
+ * matrix.  X fp32[n_cols,D] may be split in two row segments (Xa rows [0,x_split), Xb the rest;
+ * Xb null = one segment) so cat(user_table, item_table) (lightgcn.py:71-77) is never built;
+ * likewise acc_in.  short_rows / long_rows (nullable pair) list the rows handled one-per-wave
+ * and one-per-workgroup (hubs); null = every row one-per-wave.
+ * The backward of `matrix @ step` is the same call on the transposed CSR.
+ */
+MI_API int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val,
+                       const float *Xa, const float *Xb, int32_t x_split, float *Y,
+                       const float *acc_in_a, const float *acc_in_b, int32_t acc_split,
+                       float *acc_out, float scale, int32_t n_rows, int32_t D,
+                       const int32_t *short_rows, int32_t n_short,
+                       const int32_t *long_rows, int32_t n_long, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

@@ -168,3 +168,54 @@ def csr_rows(values, crow, col, ids, hidden_size: int) -> torch.Tensor:
         for i in range(int(crow[rowid]), int(crow[rowid + 1])):
             out[k, int(col[i])] = values[i]
     return out.reshape(*ids.shape, hidden_size)
+
+
+# --------------------------------------------------------------------------- LightGCN
+def adj_norm_csr(edge_user, edge_item, num_user: int, num_item: int) -> torch.Tensor:
+    """calculate_sparse_graph_adj_norm — src/graph_utils.py:47-98, from the (user,item) edge list in
+    file order (per user: all R entries, then all R^T entries, as the reference's loop emits them).
+    Degrees are column sums of the UN-coalesced COO, so a duplicate edge counts twice and its two
+    normalised entries are summed by to_sparse_csr()."""
+    eu = [int(u) for u in edge_user]
+    ei = [int(i) for i in edge_item]
+    rows: List[int] = []
+    cols: List[int] = []
+    k = 0
+    while k < len(eu):
+        j = k
+        while j < len(eu) and eu[j] == eu[k]:
+            j += 1
+        items = [it + num_user for it in ei[k:j]]
+        rows.extend([eu[k]] * len(items))
+        cols.extend(items)
+        cols.extend([eu[k]] * len(items))
+        rows.extend(items)
+        k = j
+    idx = torch.tensor([rows, cols])
+    n = num_user + num_item
+    adj = torch.sparse_coo_tensor(idx, torch.ones(len(rows)), size=(n, n))
+    degree = adj.sum(dim=0).pow(-0.5)
+    values = torch.index_select(degree, 0, idx[0]) * torch.index_select(degree, 0, idx[1])
+    return torch.sparse_coo_tensor(idx, values.coalesce().values(), size=(n, n)).to_sparse_csr()
+
+
+def lightgcn_propagate(matrix: torch.Tensor, embs: torch.Tensor, num_layers: int) -> torch.Tensor:
+    """res = mean_{k=0..L} A^k E0 — src/models/lightgcn.py:79-87 (same op order: running sum, one divide)."""
+    res = embs
+    step = embs
+    for _ in range(num_layers):
+        step = matrix @ step
+        res = res + step
+    return res / (num_layers + 1)
+
+
+def bpr_loss(user_embs, pos_embs, neg_embs) -> torch.Tensor:
+    """src/losses.py:6-22."""
+    y_pos = (user_embs * pos_embs).sum(1)
+    y_neg = (user_embs * neg_embs).sum(1)
+    return -F.logsigmoid(y_pos - y_neg).mean()
+
+
+def l2_reg_loss(user_rows, pos_rows, neg_rows) -> torch.Tensor:
+    """LightGCN.get_reg_loss — src/models/lightgcn.py:90-100."""
+    return (user_rows.norm(2).pow(2) + pos_rows.norm(2).pow(2) + neg_rows.norm(2).pow(2)) / (2 * len(user_rows))

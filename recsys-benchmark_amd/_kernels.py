@@ -340,3 +340,188 @@ def dhe_hash(ids, slopes, bias, primes, prefix: int, m: int) -> torch.Tensor:
         "mi_dhe_hash",
     )
     return out
+
+
+# --------------------------------------------------------------------------------------
+# LightGCN propagation: CSR SpMM with fused layer sum
+HUB_DEGREE = 256  # rows with more nonzeros than this get a whole workgroup
+
+
+class CsrPlan:
+    """int32 CSR of A and of A^T plus the short/hub row split, built once per sparsity pattern.
+
+    The reference passes a torch sparse-CSR tensor with int64 indices every call
+    (src/trainer/lightgcn.py:36-40); the plan is cached on its index tensors.  Values are read
+    fresh on every call (SparseDropout changes them, src/models/layers.py:15-37).
+    """
+
+    def __init__(self, crow: torch.Tensor, col: torch.Tensor, shape):
+        n_rows, n_cols = shape
+        nnz = col.numel()
+        if nnz >= 2 ** 31 or max(n_rows, n_cols) >= 2 ** 31:
+            raise ValueError("matrix too large for int32 CSR indices")
+        self.shape = (n_rows, n_cols)
+        self.nnz = nnz
+        dev = crow.device
+        self.crow = crow.to(torch.int32).contiguous()
+        self.col = col.to(torch.int32).contiguous()
+        deg = (crow[1:] - crow[:-1])
+        self.short_rows, self.long_rows = self._split(deg)
+        # transpose: sort entries by (col, row); perm maps transposed entry -> original entry
+        rows = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
+        key = col.to(torch.int64) * n_rows + rows
+        perm = torch.argsort(key, stable=True)
+        self.perm = perm
+        self.col_t = rows[perm].to(torch.int32).contiguous()
+        cnt = torch.bincount(col.to(torch.int64), minlength=n_cols)
+        crow_t = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+        crow_t[1:] = torch.cumsum(cnt, 0)
+        self.crow_t = crow_t.to(torch.int32).contiguous()
+        self.short_rows_t, self.long_rows_t = self._split(cnt)
+        self.pattern_symmetric = (n_rows == n_cols and torch.equal(self.crow_t, self.crow)
+                                  and torch.equal(self.col_t, self.col))
+        self._sym_vals_key = None
+        self._sym_vals = False
+
+    @staticmethod
+    def _split(deg):
+        hub = deg > HUB_DEGREE
+        return (torch.nonzero(~hub).flatten().to(torch.int32).contiguous(),
+                torch.nonzero(hub).flatten().to(torch.int32).contiguous())
+
+    def transposed_values(self, val: torch.Tensor) -> torch.Tensor:
+        if self.pattern_symmetric:
+            key = (val.data_ptr(), val._version)
+            if key != self._sym_vals_key:
+                self._sym_vals = bool(torch.equal(val.index_select(0, self.perm), val))
+                self._sym_vals_key = key
+            if self._sym_vals:
+                return val
+        return val.index_select(0, self.perm)
+
+
+_plans = {}
+
+
+def csr_plan(matrix: torch.Tensor) -> CsrPlan:
+    crow, col = matrix.crow_indices(), matrix.col_indices()
+    key = (crow.data_ptr(), col.data_ptr(), col.numel(), tuple(matrix.shape), str(crow.device))
+    plan = _plans.get(key)
+    if plan is None:
+        if len(_plans) > 16:
+            _plans.clear()
+        plan = CsrPlan(crow, col, tuple(matrix.shape))
+        _plans[key] = plan
+    return plan
+
+
+def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D):
+    lib = _lib.load()
+    if transposed:
+        crow, col, sr, lr, n_rows = plan.crow_t, plan.col_t, plan.short_rows_t, plan.long_rows_t, plan.shape[1]
+    else:
+        crow, col, sr, lr, n_rows = plan.crow, plan.col, plan.short_rows, plan.long_rows, plan.shape[0]
+    dev = val.device
+    _lib.check(
+        lib.mi_spmm_csr(crow.data_ptr(), col.data_ptr(), val.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split,
+                        _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale),
+                        n_rows, D, sr.data_ptr() if sr.numel() else None, sr.numel(),
+                        lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.stream_ptr(dev)),
+        "mi_spmm_csr",
+    )
+
+
+def _propagate(plan, transposed, val, Xa, Xb, num_layers):
+    """res = (sum_{k=0..L} A^k X) / (L+1) with X = [Xa; Xb] (Xb may be None)."""
+    dev = Xa.device
+    D = Xa.shape[1]
+    n = Xa.shape[0] + (Xb.shape[0] if Xb is not None else 0)
+    x_split = Xa.shape[0] if Xb is not None else 0
+    if num_layers == 0:
+        return torch.cat([Xa, Xb]) if Xb is not None else Xa.clone()
+    acc = torch.empty((n, D), dtype=torch.float32, device=dev)
+    bufs = [torch.empty((n, D), dtype=torch.float32, device=dev) for _ in range(min(2, num_layers - 1))]
+    cur_a, cur_b, cur_split = Xa, Xb, x_split
+    for k in range(1, num_layers + 1):
+        last = k == num_layers
+        Y = None if last else bufs[(k - 1) % len(bufs)]
+        scale = 1.0 / (num_layers + 1) if last else 1.0
+        if k == 1:
+            _spmm(plan, transposed, val, cur_a, cur_b, cur_split, Y, Xa, Xb, x_split, acc, scale, D)
+        else:
+            _spmm(plan, transposed, val, cur_a, None, 0, Y, acc, None, 0, acc, scale, D)
+        cur_a, cur_b, cur_split = Y, None, 0
+    return acc
+
+
+class LightGCNPropagate(torch.autograd.Function):
+    """(sum_{k=0..L} A^k [Xa;Xb]) / (L+1) — src/models/lightgcn.py:79-87.  Backward is the same
+    propagation with A^T applied to the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, val, Xa, Xb, plan, num_layers: int):
+        _lib.require_gpu(val, Xa, Xb)
+        if val.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the adjacency values are not provided")
+        if plan.shape[0] != plan.shape[1]:
+            raise ValueError("propagation needs a square adjacency")
+        valc, Xac = _f32c(val), _f32c(Xa)
+        Xbc = None if Xb is None else _f32c(Xb)
+        n = Xac.shape[0] + (Xbc.shape[0] if Xbc is not None else 0)
+        if n != plan.shape[0]:
+            raise ValueError(f"adjacency is {plan.shape} but the embedding tables have {n} rows")
+        ctx.plan, ctx.num_layers = plan, num_layers
+        ctx.split = Xac.shape[0] if Xbc is not None else None
+        ctx.save_for_backward(valc)
+        return _propagate(plan, False, valc, Xac, Xbc, num_layers)
+
+    @staticmethod
+    def backward(ctx, g):
+        (valc,) = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32c(g)
+        val_t = plan.transposed_values(valc)
+        gX = _propagate(plan, True, val_t, g, None, ctx.num_layers)
+        if ctx.num_layers == 0:
+            gX = g / 1.0
+        if ctx.split is None:
+            return None, gX, None, None, None
+        return None, gX[: ctx.split], gX[ctx.split:], None, None
+
+
+def lightgcn_propagate(matrix: torch.Tensor, Xa: torch.Tensor, Xb: Optional[torch.Tensor], num_layers: int):
+    if matrix.layout != torch.sparse_csr:
+        if matrix.layout == torch.sparse_coo:
+            matrix = matrix.coalesce().to_sparse_csr()
+        else:
+            raise ValueError(f"Not supported matrix layout: {matrix.layout}")
+    plan = csr_plan(matrix)
+    return LightGCNPropagate.apply(matrix.values(), Xa, Xb, plan, num_layers)
+
+
+def spmm(matrix: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+    """matrix @ X for a sparse-CSR matrix (rectangular allowed; src/models/hccf.py:56-57 shape)."""
+    return SpMM.apply(matrix.values(), X, csr_plan(matrix))
+
+
+class SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, val, X, plan):
+        _lib.require_gpu(val, X)
+        valc, Xc = _f32c(val), _f32c(X)
+        if Xc.shape[0] != plan.shape[1]:
+            raise ValueError("shape mismatch in sparse @ dense")
+        Y = torch.empty((plan.shape[0], Xc.shape[1]), dtype=torch.float32, device=Xc.device)
+        _spmm(plan, False, valc, Xc, None, 0, Y, None, None, 0, None, 1.0, Xc.shape[1])
+        ctx.plan = plan
+        ctx.save_for_backward(valc)
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        (valc,) = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32c(g)
+        gX = torch.empty((plan.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
+        _spmm(plan, True, plan.transposed_values(valc), g, None, 0, gX, None, None, 0, None, 1.0, g.shape[1])
+        return None, gX, None

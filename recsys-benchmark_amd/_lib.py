@@ -35,6 +35,7 @@ SIGNATURES = {
                            _i64, _i64, _i32, _i32, _p],
     "mi_csr_rows_fwd": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_dhe_hash": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _p],
+    "mi_spmm_csr": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _i32, _p, _i32, _p, _i32, _p],
     "mi_prof_enable": [_i32],
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],

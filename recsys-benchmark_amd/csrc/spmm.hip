@@ -1,0 +1,194 @@
+// spmm.hip — CSR SpMM for LightGCN propagation  E(k+1) = A_hat * E(k)
+// (src/models/lightgcn.py:82-85,166-170; operand built by src/graph_utils.py:47-98),
+// with the layer sum `res = res + step` and the final `res / (L+1)` fused as an epilogue.
+//
+// Mapping (wave = 64): a dense row of D = 4*LPR floats is LPR lanes x float4, so one
+// wave-instruction gathers NPW = 64/LPR neighbour rows (1 KiB); the loop is unrolled so 4 such
+// gathers are in flight per wave.  Partial sums live in registers and are combined across the
+// NPW neighbour slots with shuffle-xor.  Rows are split by degree on the host side once per
+// matrix: "short" rows get one wave each; "long" rows (power-law hubs) get a whole workgroup
+// whose 4 waves stride the row and combine through LDS — a hub of degree 4,000 otherwise
+// serialises ~250 dependent gathers on one wave while the rest of the chip has finished.
+// X (and the running sum) may be given as two row segments (user table | item table) so the
+// reference's torch.cat of the two weight tables is never materialised.
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+struct Seg2 {            // rows [0,split) live at a, rows [split, ..) at b (b may alias a + split*D)
+  const float *a, *b;
+  int split;
+};
+__device__ __forceinline__ const float *seg_row(const Seg2 &s, int row, int D) {
+  return row < s.split ? s.a + (int64_t)row * D : s.b + (int64_t)(row - s.split) * D;
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 row_dot(const int *__restrict__ col, const float *__restrict__ val,
+                                          const Seg2 &X, int lo, int hi, int slot, int nslots, int q) {
+  constexpr int D = LPR * 4;
+  constexpr int U = 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = lo + slot; j0 < hi; j0 += nslots * U) {
+    int c[U];
+    float v[U];
+    float4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * nslots;
+      const bool ok = j < hi;
+      c[u] = ok ? col[j] : 0;
+      v[u] = ok ? val[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, c[u], D) + q * 4);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a.x += v[u] * x[u].x; a.y += v[u] * x[u].y; a.z += v[u] * x[u].z; a.w += v[u] * x[u].w;
+    }
+  }
+  return a;
+}
+
+__device__ __forceinline__ void epilogue4(float4 y, int row, int q, int D, float *Y, const Seg2 &acc_in,
+                                          bool has_acc_in, float *acc_out, float scale) {
+  if (Y) st4(Y + (int64_t)row * D + q * 4, y);
+  if (acc_out) {
+    float4 r = y;
+    if (has_acc_in) {
+      const float4 p = ld4(seg_row(acc_in, row, D) + q * 4);
+      r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w;
+    }
+    r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+    st4(acc_out + (int64_t)row * D + q * 4, r);
+  }
+}
+
+// one wave per (short) row
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_spmm_wave_rows(
+    const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
+    float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
+    const int *__restrict__ rows, int n_items) {
+  constexpr int NPW = kWave / LPR;
+  constexpr int D = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, k = lane / LPR;
+  const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int it = wave0; it < n_items; it += nwaves) {
+    const int row = rows ? rows[it] : it;
+    const int lo = crow[row], hi = crow[row + 1];
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, k, NPW, q);
+    a = slot_sum<LPR>(a);
+    if (k == 0) epilogue4(a, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+  }
+}
+
+// one workgroup (4 waves) per long row
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_spmm_block_rows(
+    const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
+    float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
+    const int *__restrict__ rows, int n_items) {
+  constexpr int NPW = kWave / LPR;
+  constexpr int D = LPR * 4;
+  __shared__ float4 part[kWavesPerBlock][LPR];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int q = lane % LPR, k = lane / LPR;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int row = rows[it];
+    const int lo = crow[row], hi = crow[row + 1];
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kWavesPerBlock, q);
+    a = slot_sum<LPR>(a);
+    if (k == 0) part[w][q] = a;
+    __syncthreads();
+    if (w == 0 && k == 0) {
+      float4 s = part[0][q];
+#pragma unroll
+      for (int i = 1; i < kWavesPerBlock; ++i) {
+        const float4 p = part[i][q];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+      }
+      epilogue4(s, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+    }
+    __syncthreads();
+  }
+}
+
+// any D: one wave per row, lanes stride the columns of the dense operand
+__global__ __launch_bounds__(kBlock) void k_spmm_anyD(
+    const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
+    float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
+    int n_rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int row = wave0; row < n_rows; row += nwaves) {
+    const int lo = crow[row], hi = crow[row + 1];
+    for (int d = lane; d < D; d += kWave) {
+      float a = 0.f;
+      for (int j = lo; j < hi; ++j) a += val[j] * seg_row(X, col[j], D)[d];
+      if (Y) Y[(int64_t)row * D + d] = a;
+      if (acc_out) {
+        float r = a + (has_acc_in ? seg_row(acc_in, row, D)[d] : 0.f);
+        acc_out[(int64_t)row * D + d] = r * scale;
+      }
+    }
+  }
+}
+
+inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, const float *Xa,
+                const float *Xb, int32_t x_split, float *Y, const float *acc_in_a, const float *acc_in_b,
+                int32_t acc_split, float *acc_out, float scale, int32_t n_rows, int32_t D,
+                const int32_t *short_rows, int32_t n_short, const int32_t *long_rows, int32_t n_long,
+                void *stream) {
+  if (n_rows < 0 || D <= 0 || n_short < 0 || n_long < 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
+  if (n_rows == 0) return MI_OK;
+  if (!crow || !Xa || (!Y && !acc_out)) return MI_ERR_INVALID_ARG;
+  if ((n_short > 0 && !short_rows) || (n_long > 0 && !long_rows)) return MI_ERR_INVALID_ARG;
+  Seg2 X{Xa, Xb ? Xb : Xa + (int64_t)x_split * D, Xb ? x_split : 0x7fffffff};
+  const int has_acc = acc_in_a != nullptr;
+  Seg2 A{acc_in_a, acc_in_b ? acc_in_b : acc_in_a, acc_in_b ? acc_split : 0x7fffffff};
+  const bool planned = short_rows || long_rows;
+  const bool al = aligned16(Xa) && (!Xb || aligned16(Xb)) && (!Y || aligned16(Y)) &&
+                  (!acc_in_a || aligned16(acc_in_a)) && (!acc_in_b || aligned16(acc_in_b)) &&
+                  (!acc_out || aligned16(acc_out));
+  if (vec_ok(D) && al) {
+    const int ns = planned ? n_short : n_rows;
+#define CALL(LPR)                                                                                       \
+  do {                                                                                                  \
+    if (ns > 0)                                                                                         \
+      MI_LAUNCH("spmm_csr_rows", (k_spmm_wave_rows<LPR>), grid_for_waves(ns), kBlock, stream, crow, col, \
+                val, X, Y, A, has_acc, acc_out, scale, planned ? short_rows : nullptr, ns);             \
+    if (planned && n_long > 0)                                                                          \
+      MI_LAUNCH("spmm_csr_hubs", (k_spmm_block_rows<LPR>), (n_long < kMaxGrid ? n_long : kMaxGrid),     \
+                kBlock, stream, crow, col, val, X, Y, A, has_acc, acc_out, scale, long_rows, n_long);   \
+  } while (0)
+    switch (D / 4) {
+      case 1: CALL(1); break;
+      case 2: CALL(2); break;
+      case 4: CALL(4); break;
+      case 8: CALL(8); break;
+      case 16: CALL(16); break;
+      case 32: CALL(32); break;
+      case 64: CALL(64); break;
+      default: return MI_ERR_UNSUPPORTED;
+    }
+#undef CALL
+  } else {
+    MI_LAUNCH("spmm_csr_rows", k_spmm_anyD, grid_for_waves(n_rows), kBlock, stream, crow, col, val, X, Y, A,
+              has_acc, acc_out, scale, n_rows, D);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -115,9 +115,12 @@ def test_gather_fm_kernels_vs_oracle(B, dims, D, zipf):
         assert torch.equal(emb.cpu(), emb_ref.detach()), "gathered rows must be exact copies"
         assert_close(yfm, y_ref.squeeze(1), 2e-5, 2e-5, "y_fm")
         ((emb * g_emb.to(DEV)).sum() + (yfm * g_y.to(DEV)).sum()).backward()
-        assert_close(W.grad, p["embedding._emb_module.weight"].grad, 1e-4, 1e-5, f"gW sparse={sparse}")
-        assert_close(w1.grad, p["fc.weight"].grad, 1e-4, 1e-5, f"gw1 sparse={sparse}")
-        assert_close(bias.grad, p["_bias"].grad, 1e-4, 1e-5, "gbias")
+        # a hot row sums up to B addends of magnitude ~10 in an order that differs from the
+        # CPU's (float atomics / coalesce): the absolute tolerance scales with the addend count
+        atol = 1e-5 + 2e-7 * B * 10
+        assert_close(W.grad, p["embedding._emb_module.weight"].grad, 1e-4, atol, f"gW sparse={sparse}")
+        assert_close(w1.grad, p["fc.weight"].grad, 1e-4, atol, f"gw1 sparse={sparse}")
+        assert_close(bias.grad, p["_bias"].grad, 1e-4, atol, "gbias")
     _lib.check_index_errors()
 
 
