@@ -142,6 +142,8 @@ def main():
         model.zero_grad(set_to_none=True)
         loss = lossf(model(x), y)
         loss.backward()
+        if world > 1:
+            model.allreduce_dense_grads()
 
     def fence():
         torch.cuda.synchronize()
@@ -151,7 +153,8 @@ def main():
 
     # The step is ~60 short launches: replay it as ONE hipGraph (the captured work is the
     # identical kernel sequence; gradients land in the graph's static buffers each replay).
-    use_graph = not args.no_graph
+    # (the sharded path sizes its all-to-all splits on the host each step: not capturable)
+    use_graph = not args.no_graph and world == 1
     step = eager_step
     if use_graph:
         side = torch.cuda.Stream(dev)

@@ -55,7 +55,7 @@ def test_lightgcn_matches_reference_golden(name):
         assert_close(named[k].grad, ref, 1e-4, 1e-7, k)
 
 
-def _random_graph(U, I, nnz, seed, power=2.0):
+def _random_graph(U, I, nnz, seed, power=3.0):
     gen = torch.Generator().manual_seed(seed)
     u = torch.randint(0, U, (nnz,), generator=gen)
     i = (I * torch.rand(nnz, generator=gen).pow(power)).long().clamp_(max=I - 1)   # item power law -> hubs
@@ -69,7 +69,7 @@ def _random_graph(U, I, nnz, seed, power=2.0):
 
 
 @pytest.mark.parametrize("U,I,nnz,D,L", [
-    (300, 500, 4000, 64, 3),      # Yelp-like width, has hub rows (> 256 nnz) -> workgroup-per-row kernel
+    (1500, 500, 20000, 64, 3),    # Yelp-like width, has hub rows (> 256 nnz) -> workgroup-per-row kernel
     (50, 70, 300, 16, 2),
     (40, 30, 200, 7, 2),          # D not a multiple of 4: scalar kernel
     (2000, 3000, 60000, 64, 1),
@@ -95,7 +95,7 @@ def test_propagate_vs_oracle(U, I, nnz, D, L):
     if nnz:
         plan = _kernels.csr_plan(adj.to(DEV))
         assert plan.pattern_symmetric
-        if U == 300:
+        if U == 1500:
             assert plan.long_rows.numel() > 0, "test graph should contain hub rows"
 
 

@@ -1,0 +1,54 @@
+"""GPU: the row-sharded DeepFM through its default HIP lookup / FM kernels on a 1-rank RCCL
+group must reproduce the unsharded product DeepFM (same weights, dropout off)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import assert_close
+
+import recsys_benchmark_amd as pkg
+from recsys_benchmark_amd.sharded import ShardedDeepFM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+def test_sharded_world1_equals_unsharded(one_rank_group):
+    torch.manual_seed(3)
+    dims, D, B = [50, 7, 1000, 3], 16, 64
+    dev = torch.device("cuda", 0)
+    ref = pkg.DeepFM(dims, D, [32, 16], p_dropout=0.0, use_batchnorm=True,
+                     embedding_config={"name": "vanilla", "sparse": True}, fc_sparse=True).to(dev)
+    sh = ShardedDeepFM(dims, D, [32, 16], p_dropout=0.0, use_batchnorm=True, device=dev)
+    sh.load_full_tables(ref.embedding.get_weight().data, ref.fc.weight.data)
+    sh._deep_branch.load_state_dict(ref._deep_branch.state_dict())
+    with torch.no_grad():
+        ref._bias.fill_(0.25)
+        sh._bias.fill_(0.25)
+    x = torch.stack([torch.randint(0, d, (B,)) for d in dims], 1).to(dev)
+    y = (torch.rand(B) < 0.3).float().to(dev)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    a, b = ref(x), sh(x)
+    assert_close(b, a, 1e-5, 1e-6, "logits")
+    lossf(a, y).backward()
+    lossf(b, y).backward()
+    sh.allreduce_dense_grads()
+    assert_close(sh.embedding_shard.grad, ref.embedding.get_weight().grad.to_dense(), 1e-5, 1e-7, "table grad")
+    assert_close(sh.fc_shard.grad, ref.fc.weight.grad.to_dense(), 1e-5, 1e-7, "first-order grad")
+    assert_close(sh._bias.grad, ref._bias.grad, 1e-5, 1e-7)
+    for (k, p), (_, q) in zip(sh._deep_branch.named_parameters(), ref._deep_branch.named_parameters()):
+        assert_close(p.grad, q.grad, 1e-4, 1e-6, k)
+    pkg.check_index_errors()
