@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-grads", action="store_true", help="reference-style dense weight.grad (atomic scatter)")
+    ap.add_argument("--sharded", action="store_true", help="use the row-sharded model even on 1 GPU (exercises the N>1 path)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -114,8 +115,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    sharded = world > 1 or args.sharded
+    if sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import recsys_benchmark_amd as pkg
     from recsys_benchmark_amd.profiling import KernelTimer
@@ -125,7 +129,7 @@ def main():
     torch.manual_seed(2023)
     sparse = not args.dense_grads
     emb_cfg = {"name": "vanilla", "sparse": True} if sparse else {"name": "vanilla"}
-    if world > 1:
+    if sharded:
         from recsys_benchmark_amd.sharded import ShardedDeepFM
 
         model = ShardedDeepFM(dims, D, hidden, p_dropout=p_drop, use_batchnorm=True, device=dev)
@@ -142,7 +146,7 @@ def main():
         model.zero_grad(set_to_none=True)
         loss = lossf(model(x), y)
         loss.backward()
-        if world > 1:
+        if sharded:
             model.allreduce_dense_grads()
 
     def fence():
@@ -154,7 +158,7 @@ def main():
     # The step is ~60 short launches: replay it as ONE hipGraph (the captured work is the
     # identical kernel sequence; gradients land in the graph's static buffers each replay).
     # (the sharded path sizes its all-to-all splits on the host each step: not capturable)
-    use_graph = not args.no_graph and world == 1
+    use_graph = not args.no_graph and not sharded
     step = eager_step
     if use_graph:
         side = torch.cuda.Stream(dev)
@@ -196,6 +200,8 @@ def main():
         ks = kt.summary()
         fb, bb = alg_bytes_per_sample(F, D)
         alg = {"gather_fm_fwd": fb * B, "gather_fm_bwd_rows": bb * B, "gather_fm_bwd_dense": bb * B}
+        if sharded:  # emb arrives by all-to-all: FM runs over it, its backward has no MLP-grad input
+            alg = {"fm_fwd": (4 * F * D + 12 * F + 4) * B, "gather_fm_bwd_rows": (8 * F * D + 4 * F + 4) * B}
         kernels = {}
         for k, s in ks.items():
             e = {"avg_us": round(s["avg_us"], 3), "min_us": round(s["min_us"], 3), "launches": s["count"]}
@@ -240,7 +246,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
