@@ -7,8 +7,12 @@ from . import _lib
 from ._lib import MI355XLibraryError, check_index_errors
 from .deepfm import DeepFM
 from .embeddings import IEmbedding, NAME_TO_CLS, VanillaEmbedding, get_embedding
+from .factory import (get_ctr_model, get_graph_model, load_ctr_model, load_graph_model, save_cf_emb_checkpoint,
+                      save_ctr_checkpoint)
+from .lightgcn import LightGCN, SingleLightGCN
 
 __all__ = [
     "DeepFM", "IEmbedding", "VanillaEmbedding", "NAME_TO_CLS", "get_embedding",
-    "MI355XLibraryError", "check_index_errors",
+    "LightGCN", "SingleLightGCN", "get_ctr_model", "get_graph_model", "load_ctr_model", "load_graph_model",
+    "save_cf_emb_checkpoint", "save_ctr_checkpoint", "MI355XLibraryError", "check_index_errors",
 ]
