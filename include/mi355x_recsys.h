@@ -176,6 +176,40 @@ MI_API int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val
                        const int32_t *short_rows, int32_t n_short,
                        const int32_t *long_rows, int32_t n_long, void *stream);
 
+/* ---- a12/a13: fp32 MFMA GEMM with fused CrossNet epilogues ------------------
+ * C[M,N] = epi( sum_{g<kgroups} opA(A + g*gA)[M,K] . opB(B + g*gB)[K,N] ), batched over `batch`
+ * with element strides sA/sB/sC (and sR1/sR2/sC2).  transA=0: A[m*lda+k], 1: A[k*lda+m];
+ * transB=0: B[k*ldb+n], 1: B[n*ldb+k] (nn.Linear weight layout).  v_mfma_f32_32x32x2_f32, exact fp32.
+ * epi: 0 C=acc | 1 C=acc+bias[n] | 2 C=tanh(acc)
+ *      3 lin=acc+bias[n]*rs(m); C=R1+R2*lin; C2(opt)=lin   rs(m)=sum_{e<nrs} rowscale[m*nrs+e] (1 if null)
+ *        -> DCNHead `x_l + x_0*(W x_l + b)` (src/models/layer_dcn.py:137-139) and the DCN_MixHead
+ *           output `x_l + x_0 * sum_e g_e (U_e h_e + b)` (:102-113) with K = E*rank
+ *      4 C=R1+acc(+R2) | 5 C=acc*(1-R1^2) (tanh') | 6 h=tanh(acc); C=h; C2=h*rowscale[m*nrs+z] | 7 C+=acc
+ */
+MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N,
+                       int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transA,
+                       int32_t transB, int32_t batch, int64_t sA, int64_t sB, int64_t sC,
+                       int32_t kgroups, int64_t gA, int64_t gB, int32_t epi,
+                       const float *bias, const float *R1, int32_t ldr1, int64_t sR1,
+                       const float *R2, int32_t ldr2, int64_t sR2, const float *rowscale,
+                       int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, void *stream);
+
+/* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
+ *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
+ *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients)
+ *   mi_rowdot:        out[m]  = sum_n X[m,n]*v[n]
+ *   mi_mix_gate_bwd:  dgate[m,e] = sum_k dH2g*H2 + dgsum[m]; dZ2 = dH2g*gate[m,e]*(1-H2^2)   ([M,E*r] operands)
+ */
+MI_API int mi_cross_bwd_pre(const float *g, const float *x0, const float *lin, float *dlin,
+                            float *dx0, int64_t n, int32_t accumulate, void *stream);
+MI_API int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs,
+                     float *out, int32_t M, int32_t N, void *stream);
+MI_API int mi_rowdot(const float *X, int32_t ldx, const float *v, float *out, int32_t M,
+                     int32_t N, void *stream);
+MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate,
+                           const float *dgsum, float *dgate, float *dZ2, int32_t M, int32_t E,
+                           int32_t r, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

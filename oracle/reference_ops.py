@@ -219,3 +219,60 @@ def bpr_loss(user_embs, pos_embs, neg_embs) -> torch.Tensor:
 def l2_reg_loss(user_rows, pos_rows, neg_rows) -> torch.Tensor:
     """LightGCN.get_reg_loss — src/models/lightgcn.py:90-100."""
     return (user_rows.norm(2).pow(2) + pos_rows.norm(2).pow(2) + neg_rows.norm(2).pow(2)) / (2 * len(user_rows))
+
+
+# --------------------------------------------------------------------------- CrossNet heads
+def dcn_head(x0: torch.Tensor, p: Params, num_layers: int, prefix: str = "layers") -> torch.Tensor:
+    """DCNHead.forward — src/models/layer_dcn.py:129-140: x_{l+1} = x_l + x_0 * Linear_l(x_l)."""
+    x_l = x0
+    for l in range(num_layers):
+        x_l = x_l + x0 * F.linear(x_l, p[f"{prefix}.{l}.weight"], p[f"{prefix}.{l}.bias"])
+    return x_l
+
+
+def dcn_mix_head(x0: torch.Tensor, p: Params, num_layers: int, prefix: str = "") -> torch.Tensor:
+    """DCN_MixHead.forward + forward_mixture — src/models/layer_dcn.py:8-24,90-115 (tanh, identity gate)."""
+    x_l = x0
+    x0u = x0.unsqueeze(1)
+    for l in range(num_layers):
+        C, V, U, b = p[f"{prefix}C.{l}"], p[f"{prefix}V.{l}"], p[f"{prefix}U.{l}"], p[f"{prefix}biases.{l}"]
+        E_i = torch.tanh(x_l @ V)                              # [E, B, r]
+        E_i = E_i.permute(1, 0, 2)                             # [B, E, r]
+        E_i = torch.tanh(torch.einsum("ber,erq->beq", E_i, C))
+        E_i = torch.einsum("ber,erd->bed", E_i, U)             # [B, E, d]
+        E_i = x0u * (E_i + b)
+        gates = (x_l @ p[f"{prefix}gates"]).squeeze(2).permute(1, 0)   # [B, E]
+        x_l = torch.einsum("be,bed->bd", gates, E_i) + x_l
+    return x_l
+
+
+def bn_mlp(x, p: Params, prefix: str, n_hidden: int, training: bool) -> torch.Tensor:
+    """(Linear, BatchNorm1d, ReLU, Dropout(0)) x n — the `_dnn` stacks of src/models/dcn.py:56-66,179-186."""
+    for k in range(n_hidden):
+        i = 4 * k
+        x = F.linear(x, p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"])
+        x = F.batch_norm(x, p[f"{prefix}.{i+1}.running_mean"].clone(), p[f"{prefix}.{i+1}.running_var"].clone(),
+                         p[f"{prefix}.{i+1}.weight"], p[f"{prefix}.{i+1}.bias"], training=training)
+        x = F.relu(x)
+    return x
+
+
+def dcn_mix_forward(x, p: Params, emb: torch.Tensor, num_layers: int, n_hidden: int, training: bool) -> torch.Tensor:
+    """DCN_Mix.forward after the embedding lookup — src/models/dcn.py:89-96."""
+    h = dcn_mix_head(emb.reshape(x.shape[0], -1), p, num_layers, "cross_head.")
+    h = bn_mlp(h, p, "_dnn", n_hidden, training)
+    i = 4 * n_hidden
+    return F.linear(h, p[f"_dnn.{i}.weight"], p[f"_dnn.{i}.bias"]).squeeze(-1)
+
+
+def dcnv2_forward(x, p: Params, emb: torch.Tensor, num_layers: int, n_hidden: int, training: bool, structure: str):
+    """DCNv2.forward after the embedding lookup — src/models/dcn.py:205-222."""
+    rows = x + p["offsets"]
+    e = emb.reshape(x.shape[0], -1)
+    cross = dcn_head(e, p, num_layers, "cross_head.layers")
+    if structure == "Stacked":
+        logit = bn_mlp(cross, p, "_dnn", n_hidden, training)
+    else:
+        logit = torch.cat([cross, bn_mlp(e, p, "_dnn", n_hidden, training)], dim=1)
+    lin = F.embedding_bag(rows, p["linear_model.weight"], mode="sum")
+    return (F.linear(logit, p["_last_fc.weight"], p["_last_fc.bias"]) + lin).squeeze(-1)

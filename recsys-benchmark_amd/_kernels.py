@@ -525,3 +525,23 @@ class SpMM(torch.autograd.Function):
         gX = torch.empty((plan.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
         _spmm(plan, True, plan.transposed_values(valc), g, None, 0, gX, None, None, 0, None, 1.0, g.shape[1])
         return None, gX, None
+
+
+# --------------------------------------------------------------------------------------
+# fp32 MFMA GEMM with fused epilogues (building block of the CrossNet heads)
+EPI = {"none": 0, "bias": 1, "tanh": 2, "cross": 3, "add": 4, "mul_dtanh": 5, "tanh_gate": 6, "accum": 7}
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, sA=0, sB=0, sC=0,
+         kgroups=1, gA=0, gB=0, epi="none", bias=None, R1=None, ldr1=0, sR1=0, R2=None, ldr2=0, sR2=0,
+         rowscale=None, nrs=0, C2=None, ldc2=0, sC2=0):
+    """Raw launcher of mi_gemm_f32 over torch buffers (pointers may be offset views)."""
+    dev = _lib.require_gpu(A, B, C)
+    _lib.check(
+        _lib.load().mi_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, int(transA),
+                                int(transB), batch, sA, sB, sC, kgroups, gA, gB, EPI[epi], _lib.ptr(bias),
+                                _lib.ptr(R1), ldr1, sR1, _lib.ptr(R2), ldr2, sR2, _lib.ptr(rowscale), nrs,
+                                _lib.ptr(C2), ldc2, sC2, _lib.stream_ptr(dev)),
+        "mi_gemm_f32",
+    )
+    return C

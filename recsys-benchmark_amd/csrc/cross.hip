@@ -1,0 +1,132 @@
+// cross.hip — the memory-bound elementwise / reduction pieces of the CrossNet backward
+// (src/models/layer_dcn.py:90-140 differentiated by hand); the contractions are in gemm.hip.
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+// dlin = g * x0 ;  dx0 (+)= g * lin          (DCNHead / DCN_MixHead:  x_{l+1} = x_l + x_0 * lin)
+__global__ __launch_bounds__(kBlock) void k_cross_bwd_pre(const float *__restrict__ g, const float *__restrict__ x0,
+                                                          const float *__restrict__ lin, float *__restrict__ dlin,
+                                                          float *__restrict__ dx0, int64_t n, int accumulate) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float gv = g[e];
+    dlin[e] = gv * x0[e];
+    const float t = gv * lin[e];
+    dx0[e] = accumulate ? dx0[e] + t : t;
+  }
+}
+
+// out[n] += sum_m X[m,n] * rs(m),  rs(m) = sum_{e<nrs} rowscale[m*nrs+e] (1 if null).  out caller-zeroed.
+__global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int ldx, const float *__restrict__ rowscale,
+                                                   int nrs, float *__restrict__ out, int M, int N) {
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (n < N) {
+    for (int m = blockIdx.y * 4 + rl; m < M; m += gridDim.y * 4) {
+      float rs = 1.f;
+      if (rowscale) {
+        rs = 0.f;
+        for (int e = 0; e < nrs; ++e) rs += rowscale[(int64_t)m * nrs + e];
+      }
+      s += X[(int64_t)m * ldx + n] * rs;
+    }
+  }
+  part[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
+// out[m] = sum_n X[m,n] * v[n]
+__global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, int ldx, const float *__restrict__ v,
+                                                   float *__restrict__ out, int M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int m = wave0; m < M; m += nwaves) {
+    float s = 0.f;
+    for (int n = lane; n < N; n += kWave) s += X[(int64_t)m * ldx + n] * v[n];
+    s = wave_sum(s);
+    if (lane == 0) out[m] = s;
+  }
+}
+
+// DCN_MixHead gate/tanh backward for one layer, one wave per row m:
+//   dgate[m,e] = sum_k dH2g[m,e*r+k] * H2[m,e*r+k] + dgsum[m]
+//   dZ2[m,e*r+k] = dH2g[m,e*r+k] * gate[m,e] * (1 - H2^2)
+__global__ __launch_bounds__(kBlock) void k_mix_gate_bwd(const float *__restrict__ dH2g, const float *__restrict__ H2,
+                                                         const float *__restrict__ gate, const float *__restrict__ dgsum,
+                                                         float *__restrict__ dgate, float *__restrict__ dZ2, int M, int E,
+                                                         int r) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  const int ld = E * r;
+  for (int m = wave0; m < M; m += nwaves) {
+    const float dgs = dgsum[m];
+    for (int e = 0; e < E; ++e) {
+      const float gt = gate[(int64_t)m * E + e];
+      float s = 0.f;
+      for (int k = lane; k < r; k += kWave) {
+        const int64_t o = (int64_t)m * ld + e * r + k;
+        const float dh = dH2g[o], h = H2[o];
+        s += dh * h;
+        dZ2[o] = dh * gt * (1.f - h * h);
+      }
+      s = wave_sum(s);
+      if (lane == 0) dgate[(int64_t)m * E + e] = s + dgs;
+    }
+  }
+}
+
+inline int grid_for_elems(int64_t total) {
+  int64_t g = (total + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_cross_bwd_pre(const float *g, const float *x0, const float *lin, float *dlin, float *dx0, int64_t n,
+                     int32_t accumulate, void *stream) {
+  if (n < 0) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!g || !x0 || !lin || !dlin || !dx0) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("cross_bwd_pre", k_cross_bwd_pre, grid_for_elems(n), kBlock, stream, g, x0, lin, dlin, dx0, n, accumulate);
+  return launch_status();
+}
+
+int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, float *out, int32_t M, int32_t N,
+              void *stream) {
+  if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MI_OK;
+  if (!X || !out) return MI_ERR_INVALID_ARG;
+  int rb = (M + 127) / 128;
+  if (rb > 64) rb = 64;
+  dim3 grid((N + 63) / 64, rb);
+  hipLaunchKernelGGL(k_colsum, grid, dim3(kBlock), 0, (hipStream_t)stream, X, ldx, rowscale, nrs, out, M, N);
+  return launch_status();
+}
+
+int mi_rowdot(const float *X, int32_t ldx, const float *v, float *out, int32_t M, int32_t N, void *stream) {
+  if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (M == 0) return MI_OK;
+  if (!X || !v || !out) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, out, M, N);
+  return launch_status();
+}
+
+int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate, const float *dgsum, float *dgate,
+                    float *dZ2, int32_t M, int32_t E, int32_t r, void *stream) {
+  if (M < 0 || E <= 0 || r <= 0) return MI_ERR_INVALID_ARG;
+  if (M == 0) return MI_OK;
+  if (!dH2g || !H2 || !gate || !dgsum || !dgate || !dZ2) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("mix_gate_bwd", k_mix_gate_bwd, grid_for_waves(M), kBlock, stream, dH2g, H2, gate, dgsum, dgate, dZ2, M, E, r);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// gemm.hip — fp32 GEMM on the gfx950 matrix cores with fused epilogues, the building block of
+// the CrossNet heads (src/models/layer_dcn.py:8-140).  These ARE real contractions, so they go
+// on MFMA: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, exact fp32 — no xf32/TF32 on gfx950).
+//
+//   C[M,N] = epilogue( sum_{g<kgroups} opA(A + g*gA)[M,K] * opB(B + g*gB)[K,N] ),  batched over blockIdx.z
+//
+// Tiling: 64x64 output tile per 256-thread workgroup, 4 waves as 2x2, one 32x32 MFMA tile per
+// wave (M = 4096 with N = 352..416 gives 384..448 workgroups for 256 CUs; bigger tiles would
+// leave CUs idle at these shapes).  BK = 32.  Both operands are staged in LDS as [row][k] with k
+// contiguous (row stride 36 floats: conflict-free ds_read_b128), whatever their global layout —
+// a k-strided source is transposed on the way in.  A lane (i = lane&31, kh = lane>>5) reads one
+// float4 = k-slots {8c + 4kh + j}, j=0..3, per operand and issues 4 MFMAs: the k order inside a
+// chunk is permuted identically for A and B, which a sum over k does not see.  The next tile's
+// global loads are issued before the current tile's MFMAs (register-staged double buffering).
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum {
+  EPI_NONE = 0,       // C = acc
+  EPI_BIAS = 1,       // C = acc + bias[n]
+  EPI_TANH = 2,       // C = tanh(acc)
+  EPI_CROSS = 3,      // lin = acc + bias[n]*rs(m); C = R1 + R2*lin; C2 (opt) = lin     rs(m) = sum_e rowscale[m*nrs+e] or 1
+  EPI_ADD = 4,        // C = R1 + acc (+ R2 when given)
+  EPI_MUL_DTANH = 5,  // C = acc * (1 - R1^2)
+  EPI_TANH_GATE = 6,  // h = tanh(acc); C = h; C2 = h * rowscale[m*nrs + z]
+  EPI_ACCUM = 7,      // C = C + acc
+};
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int transA, transB;
+  long long sA, sB, sC;   // batch strides
+  int kgroups;
+  long long gA, gB;       // K-group strides
+  int epi;
+  const float *bias;
+  const float *R1, *R2;
+  int ldr1, ldr2;
+  long long sR1, sR2;
+  const float *rowscale;
+  int nrs;
+  float *C2;
+  int ldc2;
+  long long sC2;
+  int alignedA, alignedB;
+};
+
+constexpr int BM = 64, BN = 64, BK = 32, LDSS = BK + 4;
+
+// Stage a [64 rows][32 k] tile of an operand into LDS (row = output index, k contiguous).
+// trans == 0: global is [row][k] (k contiguous);  trans == 1: global is [k][row].
+struct Staged {
+  float4 v[2];
+};
+
+__device__ __forceinline__ float4 guarded4(const float *p, long long off, int nvalid, bool aligned) {
+  if (nvalid >= 4 && aligned) return *reinterpret_cast<const float4 *>(p + off);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[off];
+  if (nvalid > 1) r.y = p[off + 1];
+  if (nvalid > 2) r.z = p[off + 2];
+  if (nvalid > 3) r.w = p[off + 3];
+  return r;
+}
+
+__device__ __forceinline__ Staged stage_load(const float *P, int ld, int trans, int row0, int nrows, int k0,
+                                             int K, bool aligned) {
+  Staged s;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = t + i * 256;
+    if (!trans) {
+      const int row = f >> 3, kq = (f & 7) * 4;
+      const int r = row0 + row, k = k0 + kq;
+      const int nv = (r < nrows) ? (K - k) : 0;
+      s.v[i] = guarded4(P, (long long)r * ld + k, nv, aligned);
+    } else {
+      const int kk = f >> 4, mq = (f & 15) * 4;
+      const int k = k0 + kk, r = row0 + mq;
+      const int nv = (k < K) ? (nrows - r) : 0;
+      s.v[i] = guarded4(P, (long long)k * ld + r, nv, aligned);
+    }
+  }
+  return s;
+}
+
+__device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s, int trans) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = t + i * 256;
+    if (!trans) {
+      const int row = f >> 3, kq = (f & 7) * 4;
+      *reinterpret_cast<float4 *>(&T[row][kq]) = s.v[i];
+    } else {
+      const int kk = f >> 4, mq = (f & 15) * 4;
+      T[mq + 0][kk] = s.v[i].x;
+      T[mq + 1][kk] = s.v[i].y;
+      T[mq + 2][kk] = s.v[i].z;
+      T[mq + 3][kk] = s.v[i].w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDSS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int i = lane & 31, kh = lane >> 5;
+
+  const float *A = a.A + z * a.sA;
+  const float *B = a.B + z * a.sB;
+  // B as "rows = n": transB==1 means global [n][k] (k contiguous) -> stage as non-transposed
+  const int bt = a.transB ? 0 : 1;
+
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int ktiles = (a.K + BK - 1) / BK;
+  const int total = ktiles * a.kgroups;
+  Staged sa = stage_load(A, a.lda, a.transA, m0, a.M, 0, a.K, a.alignedA);
+  Staged sb = stage_load(B, a.ldb, bt, n0, a.N, 0, a.K, a.alignedB);
+  stage_store(As[0], sa, a.transA);
+  stage_store(Bs[0], sb, bt);
+  __syncthreads();
+
+  for (int it = 0; it < total; ++it) {
+    const int cur = it & 1;
+    const bool more = it + 1 < total;
+    if (more) {
+      const int g = (it + 1) / ktiles, kt = (it + 1) % ktiles;
+      sa = stage_load(A + g * a.gA, a.lda, a.transA, m0, a.M, kt * BK, a.K, a.alignedA);
+      sb = stage_load(B + g * a.gB, a.ldb, bt, n0, a.N, kt * BK, a.K, a.alignedB);
+    }
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      const float4 av = *reinterpret_cast<const float4 *>(&As[cur][wr * 32 + i][c * 8 + kh * 4]);
+      const float4 bv = *reinterpret_cast<const float4 *>(&Bs[cur][wc * 32 + i][c * 8 + kh * 4]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    if (more) {
+      stage_store(As[cur ^ 1], sa, a.transA);
+      stage_store(Bs[cur ^ 1], sb, bt);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of its 32x32 tile
+  const int n = n0 + wc * 32 + i;
+  if (n >= a.N) return;
+  float *C = a.C + z * a.sC;
+  const float *R1 = a.R1 ? a.R1 + z * a.sR1 : nullptr;
+  const float *R2 = a.R2 ? a.R2 + z * a.sR2 : nullptr;
+  float *C2 = a.C2 ? a.C2 + z * a.sC2 : nullptr;
+  const float bn = (a.bias && (a.epi == EPI_BIAS || a.epi == EPI_CROSS)) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (m >= a.M) continue;
+    const float v = acc[r];
+    const long long co = (long long)m * a.ldc + n;
+    switch (a.epi) {
+      case EPI_NONE: C[co] = v; break;
+      case EPI_BIAS: C[co] = v + bn; break;
+      case EPI_TANH: C[co] = tanhf(v); break;
+      case EPI_CROSS: {
+        float rs = 1.f;
+        if (a.rowscale) {
+          rs = 0.f;
+          for (int e = 0; e < a.nrs; ++e) rs += a.rowscale[(long long)m * a.nrs + e];
+        }
+        const float lin = v + bn * rs;
+        C[co] = R1[(long long)m * a.ldr1 + n] + R2[(long long)m * a.ldr2 + n] * lin;
+        if (C2) C2[(long long)m * a.ldc2 + n] = lin;
+        break;
+      }
+      case EPI_ADD:
+        C[co] = R1[(long long)m * a.ldr1 + n] + v + (R2 ? R2[(long long)m * a.ldr2 + n] : 0.f);
+        break;
+      case EPI_MUL_DTANH: {
+        const float h = R1[(long long)m * a.ldr1 + n];
+        C[co] = v * (1.f - h * h);
+        break;
+      }
+      case EPI_TANH_GATE: {
+        const float h = tanhf(v);
+        C[co] = h;
+        C2[(long long)m * a.ldc2 + n] = h * a.rowscale[(long long)m * a.nrs + z];
+        break;
+      }
+      case EPI_ACCUM: C[co] += v; break;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K, int32_t lda,
+                int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, int32_t batch, int64_t sA, int64_t sB,
+                int64_t sC, int32_t kgroups, int64_t gA, int64_t gB, int32_t epi, const float *bias,
+                const float *R1, int32_t ldr1, int64_t sR1, const float *R2, int32_t ldr2, int64_t sR2,
+                const float *rowscale, int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, void *stream) {
+  if (M < 0 || N < 0 || K < 0 || batch < 0 || kgroups < 1) return MI_ERR_INVALID_ARG;
+  if (epi < EPI_NONE || epi > EPI_ACCUM) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0 || batch == 0) return MI_OK;
+  if (!A || !B || !C) return MI_ERR_INVALID_ARG;
+  if ((epi == EPI_CROSS && (!R1 || !R2)) || ((epi == EPI_ADD || epi == EPI_MUL_DTANH) && !R1) ||
+      (epi == EPI_TANH_GATE && (!rowscale || !C2 || nrs < 1)))
+    return MI_ERR_INVALID_ARG;
+  if (batch > 65535) return MI_ERR_UNSUPPORTED;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.transA = transA ? 1 : 0; a.transB = transB ? 1 : 0;
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  a.kgroups = kgroups; a.gA = gA; a.gB = gB;
+  a.epi = epi; a.bias = bias;
+  a.R1 = R1; a.R2 = R2; a.ldr1 = ldr1; a.ldr2 = ldr2; a.sR1 = sR1; a.sR2 = sR2;
+  a.rowscale = rowscale; a.nrs = nrs;
+  a.C2 = C2; a.ldc2 = ldc2; a.sC2 = sC2;
+  a.alignedA = aligned16(A) && (lda % 4 == 0) && (sA % 4 == 0) && (gA % 4 == 0);
+  a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0) && (gB % 4 == 0);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+  if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
+  hipEvent_t ea, eb;
+  if (mi::prof_acquire("gemm_f32", &ea, &eb))
+    hipExtLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a);
+  else
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+}  // extern "C"

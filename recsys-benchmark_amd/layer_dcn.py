@@ -1,0 +1,209 @@
+"""CrossNet heads — reference: src/models/layer_dcn.py:8-140.
+
+`DCNHead`      x_{l+1} = x_l + x_0 * (W_l x_l + b_l)                                  (:118-140)
+`DCN_MixHead`  x_{l+1} = x_l + sum_e g_e(x_l) * x_0 * (U_e^T tanh(C_e tanh(V_e^T x_l)) + b_l), g_e = x_l . G_e   (:27-115)
+
+Same constructors, parameter containers (`layers.{l}.weight/bias`; `U.{l}`, `C.{l}`, `V.{l}`,
+`biases.{l}`, `gates`) and kaiming-normal / zero initialisation, so state_dicts interchange.
+Forward and backward are compositions of the fp32 MFMA GEMM with fused epilogues (mi_gemm_f32)
+plus a few memory-bound helpers (mi_cross_bwd_pre, mi_colsum, mi_rowdot, mi_mix_gate_bwd); no
+[B,E,d] intermediate is ever materialised (the expert sum is one GEMM with K = E*rank).
+The reference leans on torch.compile for this block (src/models/__init__.py:76-84).
+"""
+from typing import Literal, Optional
+
+import torch
+from torch import nn
+
+from . import _kernels, _lib
+from ._kernels import gemm
+
+
+def _new(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class _DCNHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, *wb):
+        dev = _lib.require_gpu(x0)
+        x0 = _kernels._f32c(x0)
+        M, d = x0.shape
+        L = len(wb) // 2
+        Ws = [_kernels._f32c(wb[2 * l]) for l in range(L)]
+        bs = [_kernels._f32c(wb[2 * l + 1]) for l in range(L)]
+        xs, lins = [x0], []
+        for l in range(L):
+            out, lin = _new((M, d), dev), _new((M, d), dev)
+            gemm(xs[-1], Ws[l], out, M, d, d, d, d, d, transB=True, epi="cross", bias=bs[l],
+                 R1=xs[-1], ldr1=d, R2=x0, ldr2=d, C2=lin, ldc2=d)
+            xs.append(out)
+            lins.append(lin)
+        ctx.save_for_backward(*xs[:-1], *lins, *Ws)
+        ctx.L = L
+        return xs[-1] if L else x0.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        xs, lins, Ws = saved[:L], saved[L:2 * L], saved[2 * L:3 * L]
+        g = _kernels._f32c(g)
+        if L == 0:
+            return (g,)
+        dev = g.device
+        M, d = g.shape
+        lib = _lib.load()
+        s = _lib.stream_ptr(dev)
+        x0 = xs[0]
+        dx0 = _new((M, d), dev)
+        grads = [None] * (2 * L)
+        for l in range(L - 1, -1, -1):
+            dlin = _new((M, d), dev)
+            _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), lins[l].data_ptr(), dlin.data_ptr(),
+                                            dx0.data_ptr(), M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
+            db = torch.zeros((d,), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, db.data_ptr(), M, d, s), "mi_colsum")
+            dW = _new((d, d), dev)
+            gemm(dlin, xs[l], dW, d, d, M, d, d, d, transA=True)                 # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
+            gn = _new((M, d), dev)
+            gemm(dlin, Ws[l], gn, M, d, d, d, d, d, epi="add", R1=g, ldr1=d,     # dx_l = g + dlin W  (+ dx0 at l=0)
+                 R2=dx0 if l == 0 else None, ldr2=d)
+            grads[2 * l], grads[2 * l + 1] = dW, db
+            g = gn
+        return (g, *grads)
+
+
+class DCNHead(nn.Module):
+    def __init__(self, num_layers, hidden_size):
+        super().__init__()
+        self.num_layers = num_layers
+        self.hidden_size = hidden_size
+        self.layers = nn.ModuleList([nn.Linear(hidden_size, hidden_size) for _ in range(num_layers)])
+
+    def forward(self, x_0):
+        """x_0: [B, hidden] -> x_L: [B, hidden]."""
+        wb = []
+        for layer in self.layers:
+            wb += [layer.weight, layer.bias]
+        return _DCNHeadFn.apply(x_0, *wb)
+
+
+class _DCNMixFn(torch.autograd.Function):
+    """args: x0, gates[E,d,1], then per layer U[E,r,d], C[E,r,r], V[E,d,r], b[1,d]."""
+
+    @staticmethod
+    def forward(ctx, x0, gates, *p):
+        dev = _lib.require_gpu(x0)
+        c = _kernels._f32c
+        x0, G = c(x0), c(gates)
+        M, d = x0.shape
+        E = G.shape[0]
+        L = len(p) // 4
+        Us, Cs, Vs, bs = ([c(p[4 * l + k]) for l in range(L)] for k in range(4))
+        r = Cs[0].shape[1] if L else 0
+        Er = E * r
+        xs, saved = [x0], []
+        for l in range(L):
+            xl = xs[-1]
+            gate = _new((M, E), dev)
+            gemm(xl, G, gate, M, E, d, d, d, E, transB=True)                                   # g_e = x_l . G_e
+            H1, H2, H2g = _new((M, Er), dev), _new((M, Er), dev), _new((M, Er), dev)
+            gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")        # tanh(x_l V_e)
+            gemm(H1, Cs[l], H2, M, r, r, Er, r, Er, batch=E, sA=r, sB=r * r, sC=r, epi="tanh_gate",
+                 rowscale=gate, nrs=E, C2=H2g, ldc2=Er, sC2=r)                                 # tanh(. C_e), * g_e
+            out, T = _new((M, d), dev), _new((M, d), dev)
+            gemm(H2g, Us[l], out, M, d, Er, Er, d, d, epi="cross", bias=bs[l], rowscale=gate, nrs=E,
+                 R1=xl, ldr1=d, R2=x0, ldr2=d, C2=T, ldc2=d)                                   # sum over experts: K = E*r
+            xs.append(out)
+            saved += [gate, H1, H2, H2g, T]
+        ctx.save_for_backward(G, *xs[:-1], *saved, *Us, *Cs, *Vs, *bs)
+        ctx.dims = (L, E, r)
+        return xs[-1] if L else x0.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L, E, r = ctx.dims
+        g = _kernels._f32c(g)
+        if L == 0:
+            return g, None
+        t = ctx.saved_tensors
+        G, xs, sv = t[0], t[1:1 + L], t[1 + L:1 + 6 * L]
+        Us, Cs, Vs, bs = (t[1 + 6 * L + k * L: 1 + 6 * L + (k + 1) * L] for k in range(4))
+        dev = g.device
+        M, d = g.shape
+        Er = E * r
+        lib = _lib.load()
+        s = _lib.stream_ptr(dev)
+        x0 = xs[0]
+        dx0 = _new((M, d), dev)
+        dG = torch.zeros((E, d), dtype=torch.float32, device=dev)
+        grads = [None] * (4 * L)
+        for l in range(L - 1, -1, -1):
+            gate, H1, H2, H2g, T = sv[5 * l: 5 * l + 5]
+            xl = xs[l]
+            dT = _new((M, d), dev)
+            _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), T.data_ptr(), dT.data_ptr(), dx0.data_ptr(),
+                                            M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
+            db = torch.zeros((1, d), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), M, d, s), "mi_colsum")
+            dgsum = _new((M,), dev)
+            _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), dgsum.data_ptr(), M, d, s), "mi_rowdot")
+            dH2g = _new((M, Er), dev)
+            gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)                             # dT U^T
+            dU = _new((E, r, d), dev)
+            gemm(H2g, dT, dU, Er, d, M, Er, d, d, transA=True)                                 # H2g^T dT
+            dgate, dZ2 = _new((M, E), dev), _new((M, Er), dev)
+            _lib.check(lib.mi_mix_gate_bwd(dH2g.data_ptr(), H2.data_ptr(), gate.data_ptr(), dgsum.data_ptr(),
+                                           dgate.data_ptr(), dZ2.data_ptr(), M, E, r, s), "mi_mix_gate_bwd")
+            dC = _new((E, r, r), dev)
+            gemm(H1, dZ2, dC, r, r, M, Er, Er, r, transA=True, batch=E, sA=r, sB=r, sC=r * r)   # H1_e^T dZ2_e
+            dZ1 = _new((M, Er), dev)
+            gemm(dZ2, Cs[l], dZ1, M, r, r, Er, r, Er, transB=True, batch=E, sA=r, sB=r * r, sC=r,
+                 epi="mul_dtanh", R1=H1, ldr1=Er, sR1=r)                                       # (dZ2_e C_e^T) * tanh'
+            dV = _new((E, d, r), dev)
+            gemm(xl, dZ1, dV, d, r, M, d, Er, r, transA=True, batch=E, sB=r, sC=d * r)          # x_l^T dZ1_e
+            gn = _new((M, d), dev)
+            gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,      # g + sum_e dZ1_e V_e^T
+                 epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d)
+            gemm(dgate, G, gn, M, d, E, E, d, d, epi="accum")                                   # + dgate G
+            gemm(dgate, xl, dG, E, d, M, E, d, d, transA=True, epi="accum")                     # dG += dgate^T x_l
+            grads[4 * l: 4 * l + 4] = [dU, dC, dV, db]
+            g = gn
+        return (g, dG.view(E, d, 1), *grads)
+
+
+class DCN_MixHead(nn.Module):
+    """DeepCross Mixture head (low-rank mixture of experts)."""
+
+    def __init__(self, num_experts: int, num_layers: int, rank: int, hidden_size: int,
+                 activation: Optional[str] = None, gate_act: Literal["softmax", "identity"] = "identity"):
+        super().__init__()
+        self.num_experts = num_experts
+        self.num_layers = num_layers
+        self.rank = rank
+        assert gate_act in ["softmax", "identity"]
+        if gate_act == "softmax":
+            raise NotImplementedError("softmax gating is never selected by the reference's DCN_Mix "
+                                      "(src/models/dcn.py:48-54); only the identity gate is built")
+        self.U = nn.ParameterList([self._init_parameters((num_experts, rank, hidden_size)) for _ in range(num_layers)])
+        self.C = nn.ParameterList([self._init_parameters((num_experts, rank, rank)) for _ in range(num_layers)])
+        self.V = nn.ParameterList([self._init_parameters((num_experts, hidden_size, rank)) for _ in range(num_layers)])
+        self.biases = nn.ParameterList([self._init_parameters((1, hidden_size), "zeros") for _ in range(num_layers)])
+        self.gates = self._init_parameters((num_experts, hidden_size, 1))
+        self.gate_act = nn.Identity()
+        self.act_name = "tanh"   # the reference hard-codes tanh whatever `activation` says
+        self.act = nn.Tanh()
+
+    def _init_parameters(self, shape, dist="he") -> nn.Parameter:
+        if dist == "zeros":
+            return nn.Parameter(torch.zeros(*shape))
+        tensor = torch.empty(*shape)
+        nn.init.kaiming_normal_(tensor)
+        return nn.Parameter(tensor)
+
+    def forward(self, x_0):
+        p = []
+        for l in range(self.num_layers):
+            p += [self.U[l], self.C[l], self.V[l], self.biases[l]]
+        return _DCNMixFn.apply(x_0, self.gates, *p)
