@@ -12,6 +12,11 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# a stale shared object (sources edited after the last build) must never be what gets tested
+import __graft_entry__  # noqa: E402
+
+__graft_entry__.build()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
