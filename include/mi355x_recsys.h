@@ -176,6 +176,22 @@ MI_API int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val
                        const int32_t *short_rows, int32_t n_short,
                        const int32_t *long_rows, int32_t n_long, void *stream);
 
+/* ---- a10: TT-Rec lookup (TTRecTorch semantics) --------------------------------
+ * src/models/embeddings/tensortrain_embeddings.py:100-150: mixed-radix split of idx over
+ * p_shapes, one slice per core (core c: fp32[1, p_c, r_c*q_c*r_{c+1}] viewed (p_c,r_c,q_c,r_{c+1})),
+ * chain contraction -> out fp32[n, D], D = prod(q_shapes).  `cores`, `gcores`, `p_shapes`,
+ * `q_shapes`, `ranks` (ncores+1 entries, first and last 1) are HOST arrays; cores[c]/gcores[c] are
+ * device pointers.  2 <= ncores <= 4.  Ids outside [0, N) are flagged and yield zeros.
+ * mi_tt_bwd adds the dense gradients of every core into caller-zeroed gcores[c] (float atomics).
+ */
+MI_API int mi_tt_fwd(const int64_t *idx, const float *const *cores, int32_t ncores,
+                     const int32_t *p_shapes, const int32_t *q_shapes, const int32_t *ranks,
+                     float *out, int64_t n, int32_t D, int64_t N, int32_t *err, void *stream);
+MI_API int mi_tt_bwd(const int64_t *idx, const float *g_out, const float *const *cores,
+                     float *const *gcores, int32_t ncores, const int32_t *p_shapes,
+                     const int32_t *q_shapes, const int32_t *ranks, int64_t n, int32_t D,
+                     int64_t N, void *stream);
+
 /* ---- a12/a13: fp32 MFMA GEMM with fused CrossNet epilogues ------------------
  * C[M,N] = epi( sum_{g<kgroups} opA(A + g*gA)[M,K] . opB(B + g*gB)[K,N] ), batched over `batch`
  * with element strides sA/sB/sC (and sR1/sR2/sC2).  transA=0: A[m*lda+k], 1: A[k*lda+m];

@@ -276,3 +276,27 @@ def dcnv2_forward(x, p: Params, emb: torch.Tensor, num_layers: int, n_hidden: in
         logit = torch.cat([cross, bn_mlp(e, p, "_dnn", n_hidden, training)], dim=1)
     lin = F.embedding_bag(rows, p["linear_model.weight"], mode="sum")
     return (F.linear(logit, p["_last_fc.weight"], p["_last_fc.bias"]) + lin).squeeze(-1)
+
+
+# --------------------------------------------------------------------------- TT-Rec (torch semantics)
+def tt_forward(indices: torch.Tensor, tt_p_shapes, tt_q_shapes, tt_ranks, cores) -> torch.Tensor:
+    """tt_rec_torch_forward — src/models/embeddings/tensortrain_embeddings.py:100-150.  cores[i] is
+    [1, p_i, r_i*q_i*r_{i+1}] (tt_ranks has ncores+1 entries); returns [n, prod(q)]."""
+    n = len(tt_p_shapes)
+    views = [cores[i].view(tt_p_shapes[i], tt_ranks[i], tt_q_shapes[i], tt_ranks[i + 1]).permute(1, 0, 2, 3)
+             for i in range(n)]                                    # [r_i, p_i, q_i, r_{i+1}]
+    big = 1
+    for p in tt_p_shapes:
+        big *= int(p)
+    res = None
+    for i, dim in enumerate(tt_p_shapes):
+        big //= int(dim)
+        v = indices // big
+        indices = indices % big
+        sl = views[i][:, v]                                        # [r_i, b, q_i, r_{i+1}]
+        if i == 0:
+            res = sl
+        else:
+            res = torch.einsum("abhj,jbkr->abhkr", res, sl)
+            res = res.reshape(res.shape[0], res.shape[1], res.shape[2] * res.shape[3], res.shape[4])
+    return res.squeeze(0).squeeze(-1)

@@ -545,3 +545,56 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, s
         "mi_gemm_f32",
     )
     return C
+
+
+# --------------------------------------------------------------------------------------
+# TT-Rec lookup
+import ctypes as _ct  # noqa: E402
+
+
+def _tt_host_args(cores, p_shapes, q_shapes, ranks):
+    n = len(cores)
+    ptrs = (_ct.c_void_p * n)(*[c.data_ptr() for c in cores])
+    return (ptrs, (_ct.c_int32 * n)(*p_shapes), (_ct.c_int32 * n)(*q_shapes), (_ct.c_int32 * (n + 1))(*ranks))
+
+
+class TTLookup(torch.autograd.Function):
+    """out[n, D] = TT-Rec rows (tensortrain_embeddings.py:128-150); dense core grads via atomics."""
+
+    @staticmethod
+    def forward(ctx, idx, num_item: int, p_shapes, q_shapes, ranks, *cores):
+        dev = _lib.require_gpu(idx, *cores)
+        idxc = _i64c(idx).view(-1)
+        cs = [_f32c(c) for c in cores]
+        D = 1
+        for q in q_shapes:
+            D *= q
+        out = torch.empty((idxc.numel(), D), dtype=torch.float32, device=dev)
+        ptrs, p, q, r = _tt_host_args(cs, p_shapes, q_shapes, ranks)
+        _lib.check(
+            _lib.load().mi_tt_fwd(idxc.data_ptr(), ptrs, len(cs), p, q, r, out.data_ptr(), idxc.numel(), D,
+                                  num_item, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+            "mi_tt_fwd",
+        )
+        ctx.save_for_backward(idxc, *cs)
+        ctx.meta = (num_item, list(p_shapes), list(q_shapes), list(ranks), D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idxc, *cs = ctx.saved_tensors
+        num_item, p_shapes, q_shapes, ranks, D = ctx.meta
+        g = _f32c(g)
+        gcs = [torch.zeros_like(c) for c in cs]
+        ptrs, p, q, r = _tt_host_args(cs, p_shapes, q_shapes, ranks)
+        gptrs = (_ct.c_void_p * len(gcs))(*[c.data_ptr() for c in gcs])
+        _lib.check(
+            _lib.load().mi_tt_bwd(idxc.data_ptr(), g.data_ptr(), ptrs, gptrs, len(cs), p, q, r, idxc.numel(), D,
+                                  num_item, _lib.stream_ptr(g.device)),
+            "mi_tt_bwd",
+        )
+        return (None, None, None, None, None, *gcs)
+
+
+def tt_lookup(idx, cores, num_item, p_shapes, q_shapes, ranks):
+    return TTLookup.apply(idx, num_item, tuple(p_shapes), tuple(q_shapes), tuple(ranks), *cores)

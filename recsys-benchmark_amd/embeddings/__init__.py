@@ -14,6 +14,7 @@ from .cerp_embedding import CerpEmbedding, RetrainCerpEmbedding
 from .dh_embedding import DHEmbedding
 from .pruned_embedding import PrunedEmbedding
 from .qr_embedding import QRHashingEmbedding
+from .tensortrain_embeddings import TTRecTorch
 
 NAME_TO_CLS: Dict[str, type] = {
     "vanilla": VanillaEmbedding,
@@ -21,6 +22,7 @@ NAME_TO_CLS: Dict[str, type] = {
     "dhe": DHEmbedding,
     "cerp": CerpEmbedding,
     "cerp_retrain": RetrainCerpEmbedding,
+    "tt_emb_torch": TTRecTorch,
 }
 
 # registry keys of the reference that this build deliberately does not cover
@@ -82,4 +84,4 @@ def detect_special(config: Dict[str, Any]) -> Tuple[Optional[str], bool]:
 
 
 __all__ = ["IEmbedding", "VanillaEmbedding", "QRHashingEmbedding", "CerpEmbedding", "RetrainCerpEmbedding",
-           "DHEmbedding", "PrunedEmbedding", "NAME_TO_CLS", "get_embedding", "detect_special"]
+           "DHEmbedding", "PrunedEmbedding", "TTRecTorch", "NAME_TO_CLS", "get_embedding", "detect_special"]
