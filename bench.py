@@ -157,22 +157,34 @@ def main():
 
     # The step is ~60 short launches: replay it as ONE hipGraph (the captured work is the
     # identical kernel sequence; gradients land in the graph's static buffers each replay).
-    # (the sharded path sizes its all-to-all splits on the host each step: not capturable)
-    use_graph = not args.no_graph and not sharded
+    # The sharded step (fixed-capacity all-to-all buckets, no host sync) is captured the same way,
+    # RCCL collectives included; if capture is refused the step falls back to eager launches.
+    use_graph = not args.no_graph
     step = eager_step
     if use_graph:
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        model.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            lossf(model(x), y).backward()
-        step = graph.replay
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            model.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                lossf(model(x), y).backward()
+                if sharded:
+                    model.allreduce_dense_grads()
+            step = graph.replay
+        except Exception as e:  # noqa: BLE001 - any capture failure means "launch eagerly"
+            if not sharded:
+                raise
+            print(f"[bench] rank {rank}: graph capture of the sharded step failed ({type(e).__name__}: {e}); "
+                  "running eagerly", file=sys.stderr, flush=True)
+            use_graph = False
+            torch.cuda.synchronize()
+            step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -183,6 +195,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     pkg.check_index_errors()
+    if sharded:
+        model.check_overflow()
 
     # roofline leg: the same step launched eagerly, every library kernel timed by its own
     # dispatch begin/end events (a graph replay cannot carry per-kernel events).

@@ -69,6 +69,82 @@ class _Route:
         return out
 
 
+class _FixedRoute:
+    """Static-shape routing: every rank sends exactly `cap` slots to every peer (padding slots carry
+    local row 0 forward and zero gradients backward), so there is no host sync, no data-dependent
+    shape, and the whole step can be captured in a hipGraph.  `cap` = ceil(n/world) * slack + 6 sigma;
+    a bucket that still overflows (pathological skew) drops the excess lookups to zeros and raises
+    the sticky `overflow` flag that `ShardedDeepFM.check_overflow()` turns into an error."""
+
+    def __init__(self, rows: torch.Tensor, world: int, group, slack: float, overflow: torch.Tensor):
+        flat = rows.reshape(-1)
+        n = flat.numel()
+        mean = -(-n // world)
+        cap = n if world == 1 else min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
+        self.cap, self.world, self.group, self.n = cap, world, group, n
+        owner = flat % world
+        order = torch.argsort(owner, stable=True)
+        owner_sorted = owner[order]
+        counts = torch.bincount(owner, minlength=world)
+        starts = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(n, device=flat.device) - starts[owner_sorted]
+        fits = pos < cap
+        overflow.logical_or_((~fits).any().view(1))
+        dump = world * cap                               # one extra slot swallows the overflow
+        slot_sorted = torch.where(fits, owner_sorted * cap + pos, torch.full_like(pos, dump))
+        # slot of every ORIGINAL lookup position (dump for dropped ones)
+        self.slot = torch.empty_like(slot_sorted)
+        self.slot[order] = slot_sorted
+        send = torch.zeros(world * cap + 1, dtype=flat.dtype, device=flat.device)
+        send[self.slot] = flat // world
+        self.send_rows = send[:-1]
+
+    def exchange(self, t: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(t)
+        dist.all_to_all_single(out, t.contiguous(), group=self.group)
+        return out
+
+    def scatter_to_slots(self, t: torch.Tensor) -> torch.Tensor:
+        """[n, ...] in lookup order -> [world*cap, ...] send buffer (zeros in padding slots)."""
+        buf = t.new_zeros((self.world * self.cap + 1,) + tuple(t.shape[1:]))
+        buf[self.slot] = t
+        return buf[:-1]
+
+    def gather_from_slots(self, buf: torch.Tensor) -> torch.Tensor:
+        """[world*cap, ...] returned buffer -> [n, ...] in lookup order (zeros for dropped lookups)."""
+        ext = torch.cat([buf, buf.new_zeros((1,) + tuple(buf.shape[1:]))])
+        return ext[self.slot]
+
+
+class ShardedLookupFixed(torch.autograd.Function):
+    """Same contract as ShardedLookup with the static-shape routing (the default on GPUs)."""
+
+    @staticmethod
+    def forward(ctx, rows, W_local, w1_local, world: int, group, gather: Callable, slack: float, overflow):
+        route = _FixedRoute(rows, world, group, slack, overflow)
+        local_rows = route.exchange(route.send_rows)                          # [world*cap]
+        emb = route.gather_from_slots(route.exchange(gather(W_local, local_rows)))
+        lin = route.gather_from_slots(route.exchange(gather(w1_local.view(-1, 1), local_rows))).view(-1)
+        ctx.route, ctx.local_rows = route, local_rows
+        ctx.shapes = (tuple(W_local.shape), tuple(w1_local.shape))
+        return emb, lin
+
+    @staticmethod
+    def backward(ctx, g_emb, g_lin):
+        route, local_rows = ctx.route, ctx.local_rows
+        Wshape, w1shape = ctx.shapes
+        inv = 1.0 / route.world
+        gW = gw1 = None
+        if ctx.needs_input_grad[1]:
+            g_rows = route.exchange(route.scatter_to_slots(g_emb.contiguous())).mul_(inv)
+            gW = torch.sparse_coo_tensor(local_rows.view(1, -1), g_rows, Wshape, check_invariants=False)
+        if ctx.needs_input_grad[2]:
+            g1 = route.exchange(route.scatter_to_slots(g_lin.contiguous().view(-1, 1))).mul_(inv)
+            gw1 = torch.sparse_coo_tensor(local_rows.view(1, -1), g1.view((-1,) + (1,) * (len(w1shape) - 1)),
+                                          w1shape, check_invariants=False)
+        return None, gW, gw1, None, None, None, None, None
+
+
 class ShardedLookup(torch.autograd.Function):
     """(emb[n,D], lin[n]) for n global rows from the row-sharded tables.
 
@@ -126,8 +202,12 @@ class ShardedDeepFM(nn.Module):
 
     def __init__(self, field_dims: List[int], num_factor: int, hidden_sizes: List[int], p_dropout: float = 0.1,
                  use_batchnorm=False, device=None, process_group=None, gather: Optional[Callable] = None,
-                 fm: Optional[Callable] = None):
+                 fm: Optional[Callable] = None, exact_routing: bool = False, bucket_slack: float = 1.25):
+        """exact_routing=True sizes the all-to-all splits exactly (one host sync per step);
+        the default pads every peer bucket to a fixed capacity (no sync, graph-capturable)."""
         super().__init__()
+        self.exact_routing = exact_routing
+        self.bucket_slack = bucket_slack
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
@@ -154,6 +234,7 @@ class ShardedDeepFM(nn.Module):
         self._deep_branch = nn.Sequential(*layers).to(device)
         fd = torch.cat([torch.tensor([0], dtype=torch.long), torch.tensor(field_dims)])
         self.register_buffer("offsets", torch.cumsum(fd[:-1], 0).unsqueeze(0).to(device))
+        self.register_buffer("bucket_overflow", torch.zeros(1, dtype=torch.bool, device=device), persistent=False)
         self.sync_dense_parameters()
 
     # ---- parameter plumbing ------------------------------------------------------------
@@ -179,6 +260,13 @@ class ShardedDeepFM(nn.Module):
             p.grad.copy_(flat[o:o + n].view_as(p.grad))
             o += n
 
+    def check_overflow(self):
+        """Synchronise; raise if any fixed-capacity bucket overflowed since the last check."""
+        if bool(self.bucket_overflow.item()):
+            self.bucket_overflow.zero_()
+            raise RuntimeError("sharded lookup: a peer bucket overflowed its fixed capacity (extreme id skew); "
+                               "raise bucket_slack or use exact_routing=True")
+
     @torch.no_grad()
     def load_full_tables(self, embedding_weight: torch.Tensor, fc_weight: torch.Tensor):
         self.embedding_shard.copy_(shard_rows(embedding_weight, self.rank, self.world))
@@ -198,8 +286,12 @@ class ShardedDeepFM(nn.Module):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
         B, F = x.shape
         rows = x + self.offsets
-        emb, lin = ShardedLookup.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
-                                       self._gather)
+        if self.exact_routing:
+            emb, lin = ShardedLookup.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
+                                           self._gather)
+        else:
+            emb, lin = ShardedLookupFixed.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
+                                                self._gather, self.bucket_slack, self.bucket_overflow)
         emb = emb.view(B, F, -1)
         y_fm = self._fm(emb, lin.view(B, F), self._bias)
         scores = y_fm.unsqueeze(1) + self._deep_branch(emb.reshape(B, -1))

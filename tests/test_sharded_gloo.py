@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, dims, D, hidden, B, out_q):
+def _worker(rank, world, port, dims, D, hidden, B, exact, out_q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,7 +43,8 @@ def _worker(rank, world, port, dims, D, hidden, B, out_q):
             return (ro.fm_second_order(emb) + lin.sum(1, keepdim=True) + bias).squeeze(1)
 
         torch.manual_seed(7)
-        model = ShardedDeepFM(dims, D, hidden, p_dropout=0.0, use_batchnorm=False, gather=gather, fm=fm)
+        model = ShardedDeepFM(dims, D, hidden, p_dropout=0.0, use_batchnorm=False, gather=gather, fm=fm,
+                              exact_routing=exact)
         assert model.embedding_shard.shape[0] == local_num_rows(N, rank, world)
         model.load_full_tables(W_full, w1_full)
         assert torch.equal(model.embedding_shard.data, shard_rows(W_full, rank, world))
@@ -55,6 +56,7 @@ def _worker(rank, world, port, dims, D, hidden, B, out_q):
         logits = model(x)
         torch.nn.BCEWithLogitsLoss()(logits, y).backward()
         model.allreduce_dense_grads()
+        model.check_overflow()
 
         # single-process oracle over the concatenated batch and the full tables
         p = {"offsets": ro.field_offsets(dims), "embedding._emb_module.weight": W_full.clone().requires_grad_(True),
@@ -83,12 +85,13 @@ def _worker(rank, world, port, dims, D, hidden, B, out_q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("dims,D,B", [([5, 7, 11, 2], 8, 6), ([40, 3, 1, 90, 17], 16, 33)])
-def test_sharded_deepfm_world2_matches_single_process_oracle(dims, D, B):
+def test_sharded_deepfm_world2_matches_single_process_oracle(dims, D, B, exact):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dims, D, [16, 8], B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dims, D, [16, 8], B, exact, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
