@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
+    # on stdout, so everything before the final print goes to stderr.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,34 +161,24 @@ def main():
 
     # The step is ~60 short launches: replay it as ONE hipGraph (the captured work is the
     # identical kernel sequence; gradients land in the graph's static buffers each replay).
-    # The sharded step (fixed-capacity all-to-all buckets, no host sync) is captured the same way,
-    # RCCL collectives included; if capture is refused the step falls back to eager launches.
-    use_graph = not args.no_graph
+    # The sharded step is NOT captured: recording RCCL collectives into a hipGraph hung on this
+    # stack (even with one rank), so N>1 launches eagerly — without any per-step host sync
+    # (fixed-capacity all-to-all buckets).
+    use_graph = not args.no_graph and not sharded
     step = eager_step
     if use_graph:
-        try:
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    eager_step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            model.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                lossf(model(x), y).backward()
-                if sharded:
-                    model.allreduce_dense_grads()
-            step = graph.replay
-        except Exception as e:  # noqa: BLE001 - any capture failure means "launch eagerly"
-            if not sharded:
-                raise
-            print(f"[bench] rank {rank}: graph capture of the sharded step failed ({type(e).__name__}: {e}); "
-                  "running eagerly", file=sys.stderr, flush=True)
-            use_graph = False
-            torch.cuda.synchronize()
-            step = eager_step
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        model.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            lossf(model(x), y).backward()
+        step = graph.replay
 
     for _ in range(args.warmup):
         step()
@@ -259,6 +253,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dims, D, hidden, B, p_drop)
         elif world == 1:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()

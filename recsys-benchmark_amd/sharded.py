@@ -85,7 +85,8 @@ class _FixedRoute:
         owner = flat % world
         order = torch.argsort(owner, stable=True)
         owner_sorted = owner[order]
-        counts = torch.bincount(owner, minlength=world)
+        # (torch.bincount reads its max back to the host: not capturable)
+        counts = (owner.unsqueeze(1) == torch.arange(world, device=flat.device).unsqueeze(0)).sum(0)
         starts = torch.cumsum(counts, 0) - counts
         pos = torch.arange(n, device=flat.device) - starts[owner_sorted]
         fits = pos < cap
