@@ -201,6 +201,9 @@ MI_API int mi_tt_bwd(const int64_t *idx, const float *g_out, const float *const 
  *        -> DCNHead `x_l + x_0*(W x_l + b)` (src/models/layer_dcn.py:137-139) and the DCN_MixHead
  *           output `x_l + x_0 * sum_e g_e (U_e h_e + b)` (:102-113) with K = E*rank
  *      4 C=R1+acc(+R2) | 5 C=acc*(1-R1^2) (tanh') | 6 h=tanh(acc); C=h; C2=h*rowscale[m*nrs+z] | 7 C+=acc
+ * splitk > 1 (epi 0 or 7 only; for epi 0 the caller zeroes C): the K loop is cut into `splitk` slices
+ * on separate workgroups that add into C with float atomics — for the weight-gradient products
+ * whose M x N is a handful of tiles while K is the batch (dW = dlin^T x_l, K = 4096).
  */
 MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N,
                        int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transA,
@@ -208,7 +211,8 @@ MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int3
                        int32_t kgroups, int64_t gA, int64_t gB, int32_t epi,
                        const float *bias, const float *R1, int32_t ldr1, int64_t sR1,
                        const float *R2, int32_t ldr2, int64_t sR2, const float *rowscale,
-                       int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, void *stream);
+                       int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, int32_t splitk,
+                       void *stream);
 
 /* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
  *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
@@ -225,6 +229,29 @@ MI_API int mi_rowdot(const float *X, int32_t ldx, const float *v, float *out, in
 MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate,
                            const float *dgsum, float *dgate, float *dZ2, int32_t M, int32_t E,
                            int32_t r, void *stream);
+
+/* ---- a5 (memory-bound part): BatchNorm1d + ReLU + Dropout around the MLP's Linears ---------
+ * src/models/deepfm.py:53-66 / src/models/dcn.py:56-66.  Z fp32[M,N] (row stride ldz) is a Linear's
+ * output.  has_bn=0 skips the normalisation (use_batchnorm=False).  training: batch statistics
+ * (biased variance for the normalisation, running stats updated with `momentum` and the unbiased
+ * variance, like nn.BatchNorm1d) — `stats` fp32[2,N] must be zeroed by the caller; eval: running
+ * stats.  Dropout keeps an element iff splitmix64(seed[0]+salt, index) >= p*2^32 and scales by
+ * 1/(1-p); the keep mask (1 byte/element) and save_mean/save_rstd fp32[N] feed the backward.
+ * Backward: dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
+ * dZ = gamma*rstd*(dyh - dbeta/M - zh*dgamma/M) in training.
+ */
+MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N,
+                                  int32_t has_bn, int32_t training, const float *gamma,
+                                  const float *beta, float *running_mean, float *running_var,
+                                  float momentum, float eps, float p, const int64_t *seed,
+                                  int64_t salt, float *stats, float *Y, uint8_t *keep,
+                                  float *save_mean, float *save_rstd, void *stream);
+MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M,
+                                  int32_t N, int32_t has_bn, int32_t training,
+                                  const uint8_t *keep, float p, const float *gamma,
+                                  const float *beta, const float *save_mean,
+                                  const float *save_rstd, float *dgamma_dbeta, float *dZ,
+                                  void *stream);
 
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the

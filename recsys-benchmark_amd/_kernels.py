@@ -534,17 +534,37 @@ EPI = {"none": 0, "bias": 1, "tanh": 2, "cross": 3, "add": 4, "mul_dtanh": 5, "t
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, sA=0, sB=0, sC=0,
          kgroups=1, gA=0, gB=0, epi="none", bias=None, R1=None, ldr1=0, sR1=0, R2=None, ldr2=0, sR2=0,
-         rowscale=None, nrs=0, C2=None, ldc2=0, sC2=0):
-    """Raw launcher of mi_gemm_f32 over torch buffers (pointers may be offset views)."""
+         rowscale=None, nrs=0, C2=None, ldc2=0, sC2=0, splitk=0):
+    """Raw launcher of mi_gemm_f32 over torch buffers (pointers may be offset views).
+
+    splitk=0 picks automatically: when the output is only a few 64x64 tiles but K is long (the
+    weight-gradient shapes) the K loop is spread over enough workgroups to fill the 256 CUs."""
     dev = _lib.require_gpu(A, B, C)
+    if splitk == 0:
+        splitk = 1
+        if epi in ("none", "accum"):
+            tiles = -(-M // 64) * -(-N // 64) * batch
+            ksteps = -(-K // 32) * kgroups
+            if tiles < 256 and ksteps >= 16:
+                splitk = max(1, min(ksteps // 4, -(-512 // tiles), 65535 // max(batch, 1)))
+        if splitk > 1 and epi == "none":
+            if C.is_contiguous() and C.numel() == batch * M * N:
+                C.zero_()
+            else:
+                _zero_strided(C, M, N, ldc, batch, sC)
     _lib.check(
         _lib.load().mi_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, int(transA),
                                 int(transB), batch, sA, sB, sC, kgroups, gA, gB, EPI[epi], _lib.ptr(bias),
                                 _lib.ptr(R1), ldr1, sR1, _lib.ptr(R2), ldr2, sR2, _lib.ptr(rowscale), nrs,
-                                _lib.ptr(C2), ldc2, sC2, _lib.stream_ptr(dev)),
+                                _lib.ptr(C2), ldc2, sC2, splitk, _lib.stream_ptr(dev)),
         "mi_gemm_f32",
     )
     return C
+
+
+def _zero_strided(C, M, N, ldc, batch, sC):
+    for z in range(batch):
+        torch.as_strided(C, (M, N), (ldc, 1), C.storage_offset() + z * sC).zero_()
 
 
 # --------------------------------------------------------------------------------------

@@ -37,13 +37,16 @@ SIGNATURES = {
     "mi_dhe_hash": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _p],
     "mi_spmm_csr": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _i32, _p, _i32, _p, _i32, _p],
     "mi_gemm_f32": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64,
-                    _i64, _i32, _p, _p, _i32, _i64, _p, _i32, _i64, _p, _i32, _p, _i32, _i64, _p],
+                    _i64, _i32, _p, _p, _i32, _i64, _p, _i32, _i64, _p, _i32, _p, _i32, _i64, _i32, _p],
     "mi_cross_bwd_pre": [_p, _p, _p, _p, _p, _i64, _i32, _p],
     "mi_colsum": [_p, _i32, _p, _i32, _p, _i32, _i32, _p],
     "mi_rowdot": [_p, _i32, _p, _p, _i32, _i32, _p],
     "mi_mix_gate_bwd": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
     "mi_tt_fwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_tt_bwd": [_p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i32, _i64, _p],
+    "mi_bn_relu_dropout_fwd": [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float,
+                               ctypes.c_float, _p, _i64, _p, _p, _p, _p, _p, _p],
+    "mi_bn_relu_dropout_bwd": [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p],
     "mi_prof_enable": [_i32],
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],

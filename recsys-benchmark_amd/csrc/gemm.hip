@@ -50,6 +50,7 @@ struct GemmArgs {
   int ldc2;
   long long sC2;
   int alignedA, alignedB;
+  int splitk;             // >1: blockIdx.z = batch*splitk + slice; slices add into C atomically (EPI_NONE/ACCUM only)
 };
 
 constexpr int BM = 64, BN = 64, BK = 32, LDSS = BK + 4;
@@ -113,7 +114,8 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s, i
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDSS];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / a.splitk;
+  const int slice = blockIdx.z % a.splitk;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -129,14 +131,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   const int ktiles = (a.K + BK - 1) / BK;
-  const int total = ktiles * a.kgroups;
-  Staged sa = stage_load(A, a.lda, a.transA, m0, a.M, 0, a.K, a.alignedA);
-  Staged sb = stage_load(B, a.ldb, bt, n0, a.N, 0, a.K, a.alignedB);
-  stage_store(As[0], sa, a.transA);
-  stage_store(Bs[0], sb, bt);
+  const int all = ktiles * a.kgroups;
+  // this slice's range of (group, k-tile) steps
+  const int per = (all + a.splitk - 1) / a.splitk;
+  const int first = slice * per;
+  const int total = (first + per <= all) ? first + per : all;
+  if (first >= total) return;   // uniform per workgroup: an empty slice adds nothing
+  Staged sa = stage_load(A + (first / ktiles) * a.gA, a.lda, a.transA, m0, a.M, (first % ktiles) * BK, a.K, a.alignedA);
+  Staged sb = stage_load(B + (first / ktiles) * a.gB, a.ldb, bt, n0, a.N, (first % ktiles) * BK, a.K, a.alignedB);
+  stage_store(As[first & 1], sa, a.transA);
+  stage_store(Bs[first & 1], sb, bt);
   __syncthreads();
 
-  for (int it = 0; it < total; ++it) {
+  for (int it = first; it < total; ++it) {
     const int cur = it & 1;
     const bool more = it + 1 < total;
     if (more) {
@@ -174,6 +181,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     if (m >= a.M) continue;
     const float v = acc[r];
     const long long co = (long long)m * a.ldc + n;
+    if (a.splitk > 1) {
+      atomicAdd(C + co, v);
+      continue;
+    }
     switch (a.epi) {
       case EPI_NONE: C[co] = v; break;
       case EPI_BIAS: C[co] = v + bn; break;
@@ -216,7 +227,8 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
                 int32_t ldb, int32_t ldc, int32_t transA, int32_t transB, int32_t batch, int64_t sA, int64_t sB,
                 int64_t sC, int32_t kgroups, int64_t gA, int64_t gB, int32_t epi, const float *bias,
                 const float *R1, int32_t ldr1, int64_t sR1, const float *R2, int32_t ldr2, int64_t sR2,
-                const float *rowscale, int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, void *stream) {
+                const float *rowscale, int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, int32_t splitk,
+                void *stream) {
   if (M < 0 || N < 0 || K < 0 || batch < 0 || kgroups < 1) return MI_ERR_INVALID_ARG;
   if (epi < EPI_NONE || epi > EPI_ACCUM) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0 || batch == 0) return MI_OK;
@@ -224,8 +236,11 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   if ((epi == EPI_CROSS && (!R1 || !R2)) || ((epi == EPI_ADD || epi == EPI_MUL_DTANH) && !R1) ||
       (epi == EPI_TANH_GATE && (!rowscale || !C2 || nrs < 1)))
     return MI_ERR_INVALID_ARG;
-  if (batch > 65535) return MI_ERR_UNSUPPORTED;
+  if (splitk < 1) return MI_ERR_INVALID_ARG;
+  if (splitk > 1 && epi != EPI_NONE && epi != EPI_ACCUM) return MI_ERR_INVALID_ARG;  // C must be pre-zeroed / accumulated
+  if ((long long)batch * splitk > 65535) return MI_ERR_UNSUPPORTED;
   GemmArgs a;
+  a.splitk = splitk;
   a.A = A; a.B = B; a.C = C;
   a.M = M; a.N = N; a.K = K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -238,7 +253,7 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   a.C2 = C2; a.ldc2 = ldc2; a.sC2 = sC2;
   a.alignedA = aligned16(A) && (lda % 4 == 0) && (sA % 4 == 0) && (gA % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0) && (gB % 4 == 0);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splitk);
   if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
   hipEvent_t ea, eb;
   if (mi::prof_acquire("gemm_f32", &ea, &eb))

@@ -86,29 +86,30 @@ __global__ __launch_bounds__(kBlock) void k_spmm_wave_rows(
   }
 }
 
-// one workgroup (4 waves) per long row
+// one 1024-thread workgroup (16 waves) per hub row: 16 x NPW neighbour slots stride the row
+constexpr int kHubWaves = 16;
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void k_spmm_block_rows(
+__global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_block_rows(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
     float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
     const int *__restrict__ rows, int n_items) {
   constexpr int NPW = kWave / LPR;
   constexpr int D = LPR * 4;
-  __shared__ float4 part[kWavesPerBlock][LPR];
+  __shared__ float4 part[kHubWaves][LPR];
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int q = lane % LPR, k = lane / LPR;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
     const int row = rows[it];
     const int lo = crow[row], hi = crow[row + 1];
-    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kWavesPerBlock, q);
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q);
     a = slot_sum<LPR>(a);
     if (k == 0) part[w][q] = a;
     __syncthreads();
     if (w == 0 && k == 0) {
       float4 s = part[0][q];
 #pragma unroll
-      for (int i = 1; i < kWavesPerBlock; ++i) {
+      for (int i = 1; i < kHubWaves; ++i) {
         const float4 p = part[i][q];
         s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
       }
@@ -171,7 +172,8 @@ int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, const
                 val, X, Y, A, has_acc, acc_out, scale, planned ? short_rows : nullptr, ns);             \
     if (planned && n_long > 0)                                                                          \
       MI_LAUNCH("spmm_csr_hubs", (k_spmm_block_rows<LPR>), (n_long < kMaxGrid ? n_long : kMaxGrid),     \
-                kBlock, stream, crow, col, val, X, Y, A, has_acc, acc_out, scale, long_rows, n_long);   \
+                kHubWaves * kWave, stream, crow, col, val, X, Y, A, has_acc, acc_out, scale, long_rows, \
+                n_long);                                                                                \
   } while (0)
     switch (D / 4) {
       case 1: CALL(1); break;

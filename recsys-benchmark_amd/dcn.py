@@ -10,6 +10,7 @@ from torch import nn
 from . import _kernels
 from .embeddings import IEmbedding, get_embedding
 from .layer_dcn import DCN_MixHead, DCNHead
+from .mlp import run_tail
 
 
 def _offsets(field_dims):
@@ -49,7 +50,7 @@ class DCN_Mix(nn.Module):
         emb = self.embedding(x)
         bs = x.shape[0]
         cross_logit = self.cross_head(emb.reshape(bs, -1))
-        return self._dnn(cross_logit).squeeze(-1)
+        return run_tail(self._dnn, cross_logit).squeeze(-1)
 
     @classmethod
     def load(cls, checkpoint: Union[str, Dict[str, Any]], strict=True, *, empty_embedding=False):
@@ -93,9 +94,9 @@ class DCNv2(nn.Module):
         emb = emb.reshape(bs, -1)
         cross_logit = self.cross_head(emb)
         if self.structure == "Stacked":
-            logit = self._dnn(cross_logit)
+            logit = run_tail(self._dnn, cross_logit)
         else:
-            logit = torch.concat([cross_logit, self._dnn(emb)], dim=1)
+            logit = torch.concat([cross_logit, run_tail(self._dnn, emb)], dim=1)
         # first-order term: EmbeddingBag(N,1,"sum") over the row ids = a D=1 row gather + bag sum
         linear = _kernels.gather_rows(x, self.linear_model.weight, bool(self.linear_model.sparse)).sum(1)
         return (self._last_fc(logit) + linear).squeeze(-1)

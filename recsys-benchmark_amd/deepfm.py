@@ -9,8 +9,8 @@ What runs where:
   x + offsets, embedding gather, FM 2nd order, EmbeddingBag(N,1,sum) + bias
       -> mi_gather_fm_fwd / mi_gather_fm_bwd_{rows,dense}  (vanilla table), or
          IEmbedding.forward + mi_fm_fwd / mi_fm_bwd        (compressed tables)
-  the MLP tail (Linear/BatchNorm1d/ReLU/Dropout) stays a dense GEMM chain on
-      rocBLAS/hipBLASLt through PyTorch (a real contraction).
+  the MLP tail: Linear contractions on rocBLAS/hipBLASLt through PyTorch (a
+      real GEMM); BatchNorm1d + ReLU + Dropout fused into one HIP pass each way (mlp.py).
 """
 from typing import Any, Dict, List, Optional, Union, cast
 
@@ -19,6 +19,7 @@ from torch import nn
 
 from . import _kernels
 from .embeddings import IEmbedding, VanillaEmbedding, get_embedding
+from .mlp import run_tail
 
 
 class DeepFM(nn.Module):
@@ -90,7 +91,7 @@ class DeepFM(nn.Module):
         """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
         emb, y_fm = self._fm_and_embedding(x)
         b = emb.shape[0]
-        scores = y_fm.unsqueeze(1) + self._deep_branch(emb.reshape(b, -1))
+        scores = y_fm.unsqueeze(1) + run_tail(self._deep_branch, emb.reshape(b, -1))
         return scores.squeeze(-1)
 
     def get_ranks(self, x) -> torch.Tensor:
