@@ -36,7 +36,19 @@ __global__ __launch_bounds__(kBlock) void k_col_stats(const float *__restrict__ 
   float a = 0.f, b = 0.f;
   if (n < N) {
     const float shift = Z[n];
-    for (int m = blockIdx.y * 4 + rl; m < M; m += gridDim.y * 4) {
+    const int stride = gridDim.y * 4;
+    int m = blockIdx.y * 4 + rl;
+    for (; m + 7 * stride < M; m += 8 * stride) {   // 8 independent row loads in flight
+      float d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = Z[(int64_t)(m + u * stride) * ld + n] - shift;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += d[u];
+        b += d[u] * d[u];
+      }
+    }
+    for (; m < M; m += stride) {
       const float d = Z[(int64_t)m * ld + n] - shift;
       a += d;
       b += d * d;
@@ -68,52 +80,108 @@ struct BnArgs {
   float *save_mean, *save_rstd;  // [N]
 };
 
+// VEC consecutive columns per thread; every stream (activation, mask, per-column parameters) is
+// read/written as one VEC-wide access so a wave-instruction stays a contiguous run.
+template <int VEC>
+struct Vec {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> ldv(const float *p) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 t = ld4(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> ldv_or(const float *p, int64_t off, float dflt) {
+  if (p) return ldv<VEC>(p + off);
+  Vec<VEC> r;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) r.v[j] = dflt;
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float *p, const Vec<VEC> &r) {
+  if constexpr (VEC == 4) st4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
+  else p[0] = r.v[0];
+}
+
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_bn_relu_drop_fwd(BnArgs a) {
-  const int64_t total = (int64_t)a.M * a.N;
+  const int nv = a.N / VEC;
+  const int64_t total = (int64_t)a.M * nv;
   const bool drop = a.training && a.p > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.p) : 1.f;
   const uint32_t thresh = drop ? (uint32_t)((double)a.p * 4294967296.0) : 0u;  // keep iff rng >= p * 2^32
   const uint64_t seed = drop ? (uint64_t)(a.seed[0] + a.salt) : 0ull;
   const float invM = 1.f / (float)a.M;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(e / a.N), n = (int)(e % a.N);
-    const float z = a.Z[(int64_t)m * a.ld + n];
-    float mean = 0.f, rstd = 1.f, g = 1.f, b = 0.f;
+  for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < total;
+       ev += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(ev / nv), n0 = (int)(ev % nv) * VEC;
+    const Vec<VEC> z = ldv<VEC>(a.Z + (int64_t)m * a.ld + n0);
+    Vec<VEC> mean, rstd, g, b, y;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mean.v[j] = 0.f; rstd.v[j] = 1.f; g.v[j] = 1.f; b.v[j] = 0.f; }
     if (a.has_bn) {
+      g = ldv_or<VEC>(a.gamma, n0, 1.f);
+      b = ldv_or<VEC>(a.beta, n0, 0.f);
       if (a.training) {
-        const float d1 = a.s1[n] * invM;
-        mean = a.Z[n] + d1;
-        const float var = fmaxf(a.s2[n] * invM - d1 * d1, 0.f);
-        rstd = rsqrtf(var + a.eps);
-        if (m == 0) {  // one thread per column owns the bookkeeping
-          a.save_mean[n] = mean;
-          a.save_rstd[n] = rstd;
+        const Vec<VEC> s1 = ldv<VEC>(a.s1 + n0), s2 = ldv<VEC>(a.s2 + n0), c = ldv<VEC>(a.Z + n0);
+        Vec<VEC> var;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d1 = s1.v[j] * invM;
+          mean.v[j] = c.v[j] + d1;
+          var.v[j] = fmaxf(s2.v[j] * invM - d1 * d1, 0.f);
+          rstd.v[j] = rsqrtf(var.v[j] + a.eps);
+        }
+        if (m == 0) {  // one thread per column group owns the bookkeeping
+          stv<VEC>(a.save_mean + n0, mean);
+          stv<VEC>(a.save_rstd + n0, rstd);
           if (a.running_mean) {
-            const float unbiased = a.M > 1 ? var * ((float)a.M / (float)(a.M - 1)) : var;
-            a.running_mean[n] = (1.f - a.momentum) * a.running_mean[n] + a.momentum * mean;
-            a.running_var[n] = (1.f - a.momentum) * a.running_var[n] + a.momentum * unbiased;
+            const float ub = a.M > 1 ? (float)a.M / (float)(a.M - 1) : 1.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              a.running_mean[n0 + j] = (1.f - a.momentum) * a.running_mean[n0 + j] + a.momentum * mean.v[j];
+              a.running_var[n0 + j] = (1.f - a.momentum) * a.running_var[n0 + j] + a.momentum * var.v[j] * ub;
+            }
           }
         }
       } else {
-        mean = a.running_mean[n];
-        rstd = rsqrtf(a.running_var[n] + a.eps);
+        mean = ldv<VEC>(a.running_mean + n0);
+        const Vec<VEC> rv = ldv<VEC>(a.running_var + n0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rstd.v[j] = rsqrtf(rv.v[j] + a.eps);
         if (m == 0) {
-          a.save_mean[n] = mean;
-          a.save_rstd[n] = rstd;
+          stv<VEC>(a.save_mean + n0, mean);
+          stv<VEC>(a.save_rstd + n0, rstd);
         }
       }
-      g = a.gamma ? a.gamma[n] : 1.f;
-      b = a.beta ? a.beta[n] : 0.f;
     }
-    float y = g * (z - mean) * rstd + b;
-    y = y > 0.f ? y : 0.f;
+    const int64_t e0 = (int64_t)m * a.N + n0;
+    uint8_t kv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = g.v[j] * (z.v[j] - mean.v[j]) * rstd.v[j] + b.v[j];
+      t = t > 0.f ? t : 0.f;
+      kv[j] = 1;
+      if (drop) {
+        const bool k = rng32(seed, (uint64_t)(e0 + j)) >= thresh;
+        kv[j] = k ? 1 : 0;
+        t = k ? t * keep_scale : 0.f;
+      }
+      y.v[j] = t;
+    }
+    stv<VEC>(a.Y + e0, y);
     if (drop) {
-      const bool k = rng32(seed, (uint64_t)e) >= thresh;
-      a.keep[e] = k ? 1 : 0;
-      y = k ? y * keep_scale : 0.f;
+      if constexpr (VEC == 4) *reinterpret_cast<uchar4 *>(a.keep + e0) = make_uchar4(kv[0], kv[1], kv[2], kv[3]);
+      else a.keep[e0] = kv[0];
     }
-    a.Y[e] = y;
   }
 }
 
@@ -150,7 +218,21 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce(BnBwdArgs a) {
   const int n = blockIdx.x * 64 + c;
   float sb = 0.f, sg = 0.f;
   if (n < a.N) {
-    for (int m = blockIdx.y * 4 + rl; m < a.M; m += gridDim.y * 4) {
+    const int stride = gridDim.y * 4;
+    int m = blockIdx.y * 4 + rl;
+    for (; m + 3 * stride < a.M; m += 4 * stride) {  // 4 x 3 independent loads in flight
+      float zz[4], zh[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) zz[u] = a.Z[(int64_t)(m + u * stride) * a.ld + n];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = bwd_dyh(a, (int64_t)(m + u * stride) * a.N + n, n, zz[u], zh[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sb += d[u];
+        sg += d[u] * zh[u];
+      }
+    }
+    for (; m < a.M; m += stride) {
       float zh;
       const float d = bwd_dyh(a, (int64_t)m * a.N + n, n, a.Z[(int64_t)m * a.ld + n], zh);
       sb += d;
@@ -166,21 +248,54 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce(BnBwdArgs a) {
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(BnBwdArgs a) {
-  const int64_t total = (int64_t)a.M * a.N;
+  const int nv = a.N / VEC;
+  const int64_t total = (int64_t)a.M * nv;
   const float invM = 1.f / (float)a.M;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(e / a.N), n = (int)(e % a.N);
-    float zh;
-    const float d = bwd_dyh(a, e, n, a.Z[(int64_t)m * a.ld + n], zh);
-    float dz = d;
-    if (a.has_bn) {
-      const float g = a.gamma ? a.gamma[n] : 1.f;
-      const float rstd = a.save_rstd[n];
-      dz = a.training ? g * rstd * (d - a.dbeta[n] * invM - zh * a.dgamma[n] * invM) : g * rstd * d;
+  const float keep_scale = a.keep ? 1.f / (1.f - a.p) : 1.f;
+  for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < total;
+       ev += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(ev / nv), n0 = (int)(ev % nv) * VEC;
+    const int64_t e0 = (int64_t)m * a.N + n0;
+    const Vec<VEC> z = ldv<VEC>(a.Z + (int64_t)m * a.ld + n0);
+    const Vec<VEC> dy = ldv<VEC>(a.dY + e0);
+    uint8_t kv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) kv[j] = 1;
+    if (a.keep) {
+      if constexpr (VEC == 4) {
+        const uchar4 k4 = *reinterpret_cast<const uchar4 *>(a.keep + e0);
+        kv[0] = k4.x; kv[1] = k4.y; kv[2] = k4.z; kv[3] = k4.w;
+      } else {
+        kv[0] = a.keep[e0];
+      }
     }
-    a.dZ[e] = dz;
+    Vec<VEC> mean, rstd, g, b, db, dg, out;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mean.v[j] = 0.f; rstd.v[j] = 1.f; g.v[j] = 1.f; b.v[j] = 0.f; db.v[j] = 0.f; dg.v[j] = 0.f; }
+    if (a.has_bn) {
+      mean = ldv<VEC>(a.save_mean + n0);
+      rstd = ldv<VEC>(a.save_rstd + n0);
+      g = ldv_or<VEC>(a.gamma, n0, 1.f);
+      b = ldv_or<VEC>(a.beta, n0, 0.f);
+      if (a.training) {
+        db = ldv<VEC>(a.dbeta + n0);
+        dg = ldv<VEC>(a.dgamma + n0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float zh = (z.v[j] - mean.v[j]) * rstd.v[j];
+      const float pre = g.v[j] * zh + b.v[j];
+      float d = kv[j] ? dy.v[j] * keep_scale : 0.f;
+      d = pre > 0.f ? d : 0.f;
+      float dz = d;
+      if (a.has_bn)
+        dz = a.training ? g.v[j] * rstd.v[j] * (d - db.v[j] * invM - zh * dg.v[j] * invM) : g.v[j] * rstd.v[j] * d;
+      out.v[j] = dz;
+    }
+    stv<VEC>(a.dZ + e0, out);
   }
 }
 
@@ -191,10 +306,13 @@ inline int grid_for_elems(int64_t total) {
   return (int)g;
 }
 inline dim3 col_grid(int M, int N) {
-  int rb = (M + 127) / 128;
-  if (rb > 64) rb = 64;
+  // enough row-blocks that (column blocks x row blocks) is a few workgroups per CU
+  const int cb = (N + 63) / 64;
+  int rb = (M + 31) / 32;
+  const int want = (1024 + cb - 1) / cb;
+  if (rb > want) rb = want;
   if (rb < 1) rb = 1;
-  return dim3((N + 63) / 64, rb);
+  return dim3(cb, rb);
 }
 
 }  // namespace
@@ -229,7 +347,12 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.momentum = momentum; a.eps = eps; a.p = p; a.seed = seed; a.salt = salt;
   a.Y = Y; a.keep = drop ? keep : nullptr; a.save_mean = save_mean; a.save_rstd = save_rstd;
-  MI_LAUNCH("bn_relu_dropout_fwd", k_bn_relu_drop_fwd, grid_for_elems((int64_t)M * N), kBlock, stream, a);
+  const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(Y) && (!a.keep || ((uintptr_t)a.keep & 3) == 0) &&
+                  (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && (!stats || aligned16(stats)) &&
+                  (!has_bn || (aligned16(save_mean) && aligned16(save_rstd))) &&
+                  (!running_mean || (aligned16(running_mean) && aligned16(running_var)));
+  if (v4) MI_LAUNCH("bn_relu_dropout_fwd", k_bn_relu_drop_fwd<4>, grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);
+  else MI_LAUNCH("bn_relu_dropout_fwd", k_bn_relu_drop_fwd<1>, grid_for_elems((int64_t)M * N), kBlock, stream, a);
   return launch_status();
 }
 
@@ -253,7 +376,11 @@ int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t
     else
       hipLaunchKernelGGL(k_bn_bwd_reduce, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, a);
   }
-  MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply, grid_for_elems((int64_t)M * N), kBlock, stream, a);
+  const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dZ) && aligned16(dY) &&
+                  (!keep || ((uintptr_t)keep & 3) == 0) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
+                  (!has_bn || (aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta)));
+  if (v4) MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply<4>, grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);
+  else MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply<1>, grid_for_elems((int64_t)M * N), kBlock, stream, a);
   return launch_status();
 }
 

@@ -64,3 +64,15 @@ def assert_close(actual, expected, rtol, atol, what=""):
         actual = actual.to_dense()
     assert tuple(actual.shape) == tuple(expected.shape), f"{what}: shape {tuple(actual.shape)} vs {tuple(expected.shape)}"
     torch.testing.assert_close(actual, expected.to(actual.dtype), rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+def assert_mostly_close(actual, expected, rtol, atol, max_bad_frac, what=""):
+    """For gradients through ReLU: a pre-activation within rounding of 0 can land on either side of
+    the kink on CPU vs GPU, flipping that element's gradient; all but `max_bad_frac` must agree."""
+    actual = actual.detach().cpu()
+    expected = expected.detach().cpu().to(actual.dtype)
+    assert tuple(actual.shape) == tuple(expected.shape), f"{what}: shape"
+    bad = (actual - expected).abs() > (atol + rtol * expected.abs())
+    frac = bad.float().mean().item() if bad.numel() else 0.0
+    assert frac <= max_bad_frac, f"{what}: {frac:.2e} of elements differ (allowed {max_bad_frac:.1e}); " \
+                                 f"max abs diff {(actual - expected).abs().max().item():.3e}"
