@@ -237,15 +237,18 @@ MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate
  * variance, like nn.BatchNorm1d) — `stats` fp32[2,N] must be zeroed by the caller; eval: running
  * stats.  Dropout keeps an element iff splitmix64(seed[0]+salt, index) >= p*2^32 and scales by
  * 1/(1-p); the keep mask (1 byte/element) and save_mean/save_rstd fp32[N] feed the backward.
+ * bump_seed (training BN only): the statistics launch first does seed[0] += 1 — one new dropout
+ * stream per pass without a separate launch; num_batches_tracked (nullable) gets += 1.
  * Backward: dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
  * dZ = gamma*rstd*(dyh - dbeta/M - zh*dgamma/M) in training.
  */
 MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N,
                                   int32_t has_bn, int32_t training, const float *gamma,
                                   const float *beta, float *running_mean, float *running_var,
-                                  float momentum, float eps, float p, const int64_t *seed,
-                                  int64_t salt, float *stats, float *Y, uint8_t *keep,
-                                  float *save_mean, float *save_rstd, void *stream);
+                                  float momentum, float eps, float p, int64_t *seed,
+                                  int64_t salt, int32_t bump_seed, int64_t *num_batches_tracked,
+                                  float *stats, float *Y, uint8_t *keep, float *save_mean,
+                                  float *save_rstd, void *stream);
 MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M,
                                   int32_t N, int32_t has_bn, int32_t training,
                                   const uint8_t *keep, float p, const float *gamma,

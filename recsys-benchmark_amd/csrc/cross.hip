@@ -25,7 +25,18 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
   const int n = blockIdx.x * 64 + c;
   float s = 0.f;
   if (n < N) {
-    for (int m = blockIdx.y * 4 + rl; m < M; m += gridDim.y * 4) {
+    const int stride = gridDim.y * 4;
+    int m = blockIdx.y * 4 + rl;
+    if (!rowscale) {
+      for (; m + 7 * stride < M; m += 8 * stride) {   // 8 independent row loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = X[(int64_t)(m + u * stride) * ldx + n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    }
+    for (; m < M; m += stride) {
       float rs = 1.f;
       if (rowscale) {
         rs = 0.f;
@@ -105,10 +116,13 @@ int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, f
   if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
   if (!X || !out) return MI_ERR_INVALID_ARG;
-  int rb = (M + 127) / 128;
-  if (rb > 64) rb = 64;
-  dim3 grid((N + 63) / 64, rb);
-  hipLaunchKernelGGL(k_colsum, grid, dim3(kBlock), 0, (hipStream_t)stream, X, ldx, rowscale, nrs, out, M, N);
+  const int cb = (N + 63) / 64;
+  int rb = (M + 31) / 32;
+  const int want = (1024 + cb - 1) / cb;
+  if (rb > want) rb = want;
+  if (rb < 1) rb = 1;
+  dim3 grid(cb, rb);
+  MI_LAUNCH("colsum", k_colsum, grid, kBlock, stream, X, ldx, rowscale, nrs, out, M, N);
   return launch_status();
 }
 

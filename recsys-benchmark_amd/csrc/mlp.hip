@@ -29,8 +29,10 @@ __device__ __forceinline__ uint32_t rng32(uint64_t seed, uint64_t idx) {
 
 // grid (ceil(N/64), RB); block 256 = 64 columns x 4 row lanes
 __global__ __launch_bounds__(kBlock) void k_col_stats(const float *__restrict__ Z, int ld, float *__restrict__ s1,
-                                                      float *__restrict__ s2, int M, int N) {
+                                                      float *__restrict__ s2, int M, int N, int64_t *bump) {
   __shared__ float p1[4][64], p2[4][64];
+  // stream order puts this launch before every apply kernel of the pass that reads the word
+  if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bump[0] += 1;
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
   float a = 0.f, b = 0.f;
@@ -78,6 +80,7 @@ struct BnArgs {
   float *Y;
   uint8_t *keep;                 // [M,N] when p > 0 and training
   float *save_mean, *save_rstd;  // [N]
+  int64_t *num_batches_tracked;  // nullable: += 1 (training BatchNorm bookkeeping)
 };
 
 // VEC consecutive columns per thread; every stream (activation, mask, per-column parameters) is
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_relu_drop_fwd(BnArgs a) {
           var.v[j] = fmaxf(s2.v[j] * invM - d1 * d1, 0.f);
           rstd.v[j] = rsqrtf(var.v[j] + a.eps);
         }
+        if (ev == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
         if (m == 0) {  // one thread per column group owns the bookkeeping
           stv<VEC>(a.save_mean + n0, mean);
           stv<VEC>(a.save_rstd + n0, rstd);
@@ -321,7 +325,8 @@ extern "C" {
 
 int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, int32_t has_bn, int32_t training,
                            const float *gamma, const float *beta, float *running_mean, float *running_var,
-                           float momentum, float eps, float p, const int64_t *seed, int64_t salt,
+                           float momentum, float eps, float p, int64_t *seed, int64_t salt, int32_t bump_seed,
+                           int64_t *num_batches_tracked,
                            float *stats /*[2,N] caller-zeroed; training BN only*/, float *Y, uint8_t *keep,
                            float *save_mean, float *save_rstd, void *stream) {
   if (M < 0 || N < 0 || p < 0.f || p >= 1.f) return MI_ERR_INVALID_ARG;
@@ -332,14 +337,16 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   if (has_bn && (!save_mean || !save_rstd)) return MI_ERR_INVALID_ARG;
   if (has_bn && training && !stats) return MI_ERR_INVALID_ARG;
   if (has_bn && !training && (!running_mean || !running_var)) return MI_ERR_INVALID_ARG;
+  if (bump_seed && !(has_bn && training)) return MI_ERR_INVALID_ARG;  // only the statistics launch can bump
   if (has_bn && training) {
+    int64_t *bump = bump_seed ? seed : nullptr;
     hipEvent_t ea, eb;
     if (mi::prof_acquire("bn_col_stats", &ea, &eb))
       hipExtLaunchKernelGGL(k_col_stats, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, ea, eb, 0, Z, ldz, stats,
-                            stats + N, M, N);
+                            stats + N, M, N, bump);
     else
       hipLaunchKernelGGL(k_col_stats, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, stats, stats + N,
-                         M, N);
+                         M, N, bump);
   }
   BnArgs a;
   a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = has_bn; a.training = training;
@@ -347,6 +354,7 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.momentum = momentum; a.eps = eps; a.p = p; a.seed = seed; a.salt = salt;
   a.Y = Y; a.keep = drop ? keep : nullptr; a.save_mean = save_mean; a.save_rstd = save_rstd;
+  a.num_batches_tracked = (has_bn && training) ? num_batches_tracked : nullptr;
   const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(Y) && (!a.keep || ((uintptr_t)a.keep & 3) == 0) &&
                   (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) && (!stats || aligned16(stats)) &&
                   (!has_bn || (aligned16(save_mean) && aligned16(save_rstd))) &&

@@ -4,11 +4,14 @@ Linear — reference: src/models/deepfm.py:53-66,100-102 and src/models/dcn.py:5
 The modules stay ordinary nn.Linear / nn.BatchNorm1d / nn.ReLU / nn.Dropout inside the same
 nn.Sequential (state_dict keys unchanged); `run_tail` walks the Sequential and executes every
 (Linear, [BatchNorm1d], ReLU, [Dropout]) group as: the contraction on hipBLASLt/rocBLAS through
-PyTorch (a real GEMM), then ONE fused BN+ReLU+Dropout HIP pass each way (mi_bn_relu_dropout_*),
-with the bias gradient from the library's column-sum kernel.  Anything that does not match the
-pattern is run as the plain module.
+PyTorch (a real GEMM), then ONE fused BN+ReLU+Dropout HIP pass each way (mi_bn_relu_dropout_*).
+Launch count matters at B=4096 (every kernel is a few microseconds), so: all reduction targets
+of a pass live in ONE zero-filled workspace, the dropout-seed and num_batches_tracked bumps ride
+inside the library's kernels, and the bias gradient of a Linear that feeds a training-mode
+BatchNorm is returned as the exact zero it is (sum_m dz = 0 when the batch mean is removed)
+instead of being reduced.  Anything that does not match the pattern runs as the plain module.
 """
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 from torch import nn
@@ -27,33 +30,41 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
     return w
 
 
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
 class _LinearFn(torch.autograd.Function):
-    """z = x W^T + b on rocBLAS/hipBLASLt; the bias gradient by the library's column sum."""
+    """z = x W^T + b on rocBLAS/hipBLASLt.  db: the library's column sum into `db_buf` (a zeroed
+    workspace slice), or — zero_db — that zeroed slice itself when z feeds a training BatchNorm."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        ctx.save_for_backward(x, W)
+    def forward(ctx, x, W, b, db_buf, zero_db: bool):
+        ctx.save_for_backward(x, W, db_buf)
         ctx.has_bias = b is not None
+        ctx.zero_db = zero_db
         return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, W, db_buf = ctx.saved_tensors
         g = g.contiguous()
         dx = g @ W if ctx.needs_input_grad[0] else None
         dW = g.t() @ x if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             M, N = g.shape
-            db = torch.zeros((N,), dtype=torch.float32, device=g.device)
-            _lib.check(_lib.load().mi_colsum(g.data_ptr(), N, None, 0, db.data_ptr(), M, N, _lib.stream_ptr(g.device)),
-                       "mi_colsum")
-        return dx, dW, db
+            db = db_buf if db_buf is not None else torch.zeros((N,), dtype=torch.float32, device=g.device)
+            if not ctx.zero_db:
+                _lib.check(_lib.load().mi_colsum(g.data_ptr(), N, None, 0, db.data_ptr(), M, N,
+                                                 _lib.stream_ptr(g.device)), "mi_colsum")
+        return dx, dW, db, None, None
 
 
 class _BNReLUDropFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, has_bn, training, momentum, eps, p, seed, salt):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, has_bn, training, momentum, eps, p, seed, salt,
+                bump_seed, stats, dgb):
         dev = _lib.require_gpu(z)
         z = _kernels._f32c(z)
         M, N = z.shape
@@ -61,28 +72,31 @@ class _BNReLUDropFn(torch.autograd.Function):
         drop = bool(training and p > 0.0)
         y = torch.empty_like(z)
         keep = torch.empty((M, N), dtype=torch.uint8, device=dev) if drop else None
-        stats = torch.zeros((2, N), dtype=torch.float32, device=dev) if bn_train else None
+        if bn_train and stats is None:
+            stats = torch.zeros((2 * N,), dtype=torch.float32, device=dev)
         save = torch.empty((2, N), dtype=torch.float32, device=dev) if has_bn else None
         _lib.check(
             _lib.load().mi_bn_relu_dropout_fwd(
                 z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(gamma), _lib.ptr(beta),
                 _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps), float(p if drop else 0.0),
-                _lib.ptr(seed), int(salt), _lib.ptr(stats), y.data_ptr(), _lib.ptr(keep),
+                _lib.ptr(seed), int(salt), int(bool(bump_seed and bn_train)), _lib.ptr(nbt) if bn_train else None,
+                _lib.ptr(stats) if bn_train else None, y.data_ptr(), _lib.ptr(keep),
                 save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None, _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_fwd",
         )
-        ctx.save_for_backward(z, gamma, beta, keep, save)
+        ctx.save_for_backward(z, gamma, beta, keep, save, dgb)
         ctx.meta = (M, N, bool(has_bn), bool(training), float(p if drop else 0.0))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        z, gamma, beta, keep, save = ctx.saved_tensors
+        z, gamma, beta, keep, save, dgb = ctx.saved_tensors
         M, N, has_bn, training, p = ctx.meta
         dev = z.device
         dy = _kernels._f32c(dy)
         dz = torch.empty_like(z)
-        dgb = torch.zeros((2, N), dtype=torch.float32, device=dev) if has_bn else None
+        if has_bn and dgb is None:
+            dgb = torch.zeros((2 * N,), dtype=torch.float32, device=dev)
         _lib.check(
             _lib.load().mi_bn_relu_dropout_bwd(
                 dy.data_ptr(), z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(keep), p, _lib.ptr(gamma),
@@ -90,12 +104,12 @@ class _BNReLUDropFn(torch.autograd.Function):
                 _lib.ptr(dgb), dz.data_ptr(), _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_bwd",
         )
-        dgamma = dgb[0] if (has_bn and gamma is not None and ctx.needs_input_grad[1]) else None
-        dbeta = dgb[1] if (has_bn and beta is not None and ctx.needs_input_grad[2]) else None
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        dgamma = dgb[:N] if (has_bn and gamma is not None and ctx.needs_input_grad[1]) else None
+        dbeta = dgb[N:2 * N] if (has_bn and beta is not None and ctx.needs_input_grad[2]) else None
+        return (dz, dgamma, dbeta) + (None,) * 13
 
 
-def _groups(seq: nn.Sequential) -> List[List[nn.Module]]:
+def _groups(seq: nn.Sequential) -> List[List]:
     """Split the Sequential into fusable (Linear, [BN], ReLU, [Dropout]) groups and single modules."""
     mods = list(seq)
     out, i = [], 0
@@ -123,24 +137,49 @@ def _groups(seq: nn.Sequential) -> List[List[nn.Module]]:
 def run_tail(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     dev = x.device
     seed = _seed_word(dev)
-    bumped = False
-    for k, grp in enumerate(_groups(seq)):
+    groups = _groups(seq)
+    # one zero-filled workspace for every reduction target of this pass (forward statistics,
+    # backward dgamma/dbeta, bias gradients): a single fill launch instead of one per buffer
+    need = 0
+    for grp in groups:
+        lin = grp[1]
+        if isinstance(lin, nn.Linear):
+            need += _pad4(lin.out_features) * (5 if grp[0] == "fused" else 1)
+    ws = torch.zeros((need,), dtype=torch.float32, device=dev) if (need and torch.is_grad_enabled()) else None
+    if ws is None and need:
+        ws = torch.zeros((need,), dtype=torch.float32, device=dev)
+    off = 0
+
+    def take(n: int) -> Optional[torch.Tensor]:
+        nonlocal off
+        t = ws[off:off + n]
+        off += _pad4(n)
+        return t
+
+    need_bump = True
+    for k, grp in enumerate(groups):
         if grp[0] == "plain":
             m = grp[1]
-            x = _LinearFn.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+            x = _LinearFn.apply(x, m.weight, m.bias, take(m.out_features), False) if isinstance(m, nn.Linear) else m(x)
             continue
         _, lin, bn, dp = grp
-        z = _LinearFn.apply(x, lin.weight, lin.bias)
+        N = lin.out_features
         training_bn = bn is not None and bn.training
         p = dp.p if (dp is not None and dp.training) else 0.0
-        if p > 0.0 and not bumped:
-            seed.add_(1)          # one new dropout stream per tail pass (graph-capture safe)
-            bumped = True
-        if training_bn:
-            bn.num_batches_tracked.add_(1)
+        z = _LinearFn.apply(x, lin.weight, lin.bias, take(N), bool(training_bn))
+        stats, dgb = take(2 * N), take(2 * N)
+        bump_in_kernel = False
+        if p > 0.0 and need_bump:
+            if training_bn:
+                bump_in_kernel = True      # the statistics launch does seed += 1
+            else:
+                seed.add_(1)               # no statistics launch to ride on
+            need_bump = False
         x = _BNReLUDropFn.apply(
             z, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
             bn.running_mean if bn is not None else None, bn.running_var if bn is not None else None,
-            bn is not None, bool(training_bn or p > 0.0) if bn is None else bool(bn.training),
-            bn.momentum if bn is not None else 0.0, bn.eps if bn is not None else 0.0, p, seed, 7919 * (k + 1))
+            bn.num_batches_tracked if bn is not None else None,
+            bn is not None, bool(p > 0.0) if bn is None else bool(bn.training),
+            bn.momentum if bn is not None else 0.0, bn.eps if bn is not None else 0.0, p, seed, 7919 * (k + 1),
+            bump_in_kernel, stats, dgb)
     return x

@@ -55,8 +55,11 @@ def test_fused_bn_relu_vs_cpu_modules(M, N, bn, training):
     rm.copy_(ref0.running_mean)
     rv.copy_(ref0.running_var)
     z2 = Z.to(DEV).requires_grad_(True)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
     y = _BNReLUDropFn.apply(z2, gamma if bn else None, beta if bn else None, rm if bn else None, rv if bn else None,
-                            bn, training, 0.1, 1e-5, 0.0, _seed_word(torch.device(DEV, 0)), 1)
+                            nbt if bn else None, bn, training, 0.1, 1e-5, 0.0, _seed_word(torch.device(DEV, 0)), 1,
+                            False, None, None)
+    assert int(nbt) == (1 if (bn and training) else 0)
     assert_mostly_close(y, y_ref, 2e-5, 2e-5, 1e-5, "y")
     (y * G.to(DEV)).sum().backward()
     assert_mostly_close(z2.grad, z1.grad, 1e-4, 2e-5, 1e-4, "dz")
@@ -79,7 +82,7 @@ def test_linear_fn_vs_cpu():
     W = lin.weight.detach().to(DEV).requires_grad_(True)
     b = lin.bias.detach().to(DEV).requires_grad_(True)
     x2 = X.to(DEV).requires_grad_(True)
-    out = _LinearFn.apply(x2, W, b)
+    out = _LinearFn.apply(x2, W, b, None, False)
     assert_close(out, lin(X), 1e-4, 1e-4, "z")
     (out * G.to(DEV)).sum().backward()
     assert_close(x2.grad, x1.grad, 1e-4, 1e-4)
