@@ -284,6 +284,37 @@ class ShardedDeepFM(nn.Module):
         _, y = _kernels.fm_first_order(emb, ident, lin.reshape(-1, 1), bias)
         return y
 
+    # ---- the compute between the collectives ------------------------------------------------
+    def _local_compute(self, emb, lin):
+        """emb [B,F,D], lin [B,F] (already exchanged) -> logits [B]: FM + first-order + MLP tail."""
+        B = emb.shape[0]
+        y_fm = self._fm(emb, lin, self._bias)
+        tail = run_tail if emb.is_cuda else (lambda seq, t: seq(t))   # CPU only in the injected gloo tests
+        return (y_fm.unsqueeze(1) + tail(self._deep_branch, emb.reshape(B, -1))).squeeze(-1)
+
+    def enable_graphs(self, batch_size: int):
+        """Capture the local compute (forward AND backward) for a fixed batch size as hipGraphs
+        (torch.cuda.make_graphed_callables).  The RCCL collectives stay outside the graphs —
+        recording them hung on this stack — so a step is: eager routing + all-to-alls, ONE graph
+        replay for FM+MLP forward, one for their backward, eager gradient all-to-all + all-reduce."""
+        F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
+        dev = self.embedding_shard.device
+        emb = torch.randn(batch_size, F, D, device=dev, requires_grad=True)
+        lin = torch.randn(batch_size, F, device=dev, requires_grad=True)
+
+        class _Local(nn.Module):
+            def __init__(inner, outer):
+                super().__init__()
+                inner.outer = [outer]            # not registered as a submodule (no param duplication)
+                inner._bias = outer._bias
+                inner._deep_branch = outer._deep_branch
+
+            def forward(inner, e, l):
+                return inner.outer[0]._local_compute(e, l)
+
+        self._graphed_local = torch.cuda.make_graphed_callables(_Local(self), (emb, lin), num_warmup_iters=3)
+        self._graphed_batch = batch_size
+
     def forward(self, x):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
         B, F = x.shape
@@ -294,8 +325,8 @@ class ShardedDeepFM(nn.Module):
         else:
             emb, lin = ShardedLookupFixed.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
                                                 self._gather, self.bucket_slack, self.bucket_overflow)
-        emb = emb.view(B, F, -1)
-        y_fm = self._fm(emb, lin.view(B, F), self._bias)
-        tail = run_tail if emb.is_cuda else (lambda seq, t: seq(t))   # CPU only in the injected gloo tests
-        scores = y_fm.unsqueeze(1) + tail(self._deep_branch, emb.reshape(B, -1))
-        return scores.squeeze(-1)
+        emb, lin = emb.view(B, F, -1), lin.view(B, F)
+        graphed = getattr(self, "_graphed_local", None)
+        if graphed is not None and B == self._graphed_batch and self.training:
+            return graphed(emb, lin)
+        return self._local_compute(emb, lin)
