@@ -312,8 +312,10 @@ class ShardedDeepFM(nn.Module):
             def forward(inner, e, l):
                 return inner.outer[0]._local_compute(e, l)
 
-        self._graphed_local = torch.cuda.make_graphed_callables(_Local(self), (emb, lin), num_warmup_iters=3)
-        self._graphed_batch = batch_size
+        # kept out of the module registry (it shares this module's parameters; state_dict must not change)
+        object.__setattr__(self, "_graphed_local",
+                           torch.cuda.make_graphed_callables(_Local(self), (emb, lin), num_warmup_iters=3))
+        object.__setattr__(self, "_graphed_batch", batch_size)
 
     def forward(self, x):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
@@ -326,7 +328,7 @@ class ShardedDeepFM(nn.Module):
             emb, lin = ShardedLookupFixed.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
                                                 self._gather, self.bucket_slack, self.bucket_overflow)
         emb, lin = emb.view(B, F, -1), lin.view(B, F)
-        graphed = getattr(self, "_graphed_local", None)
+        graphed = self.__dict__.get("_graphed_local")
         if graphed is not None and B == self._graphed_batch and self.training:
             return graphed(emb, lin)
         return self._local_compute(emb, lin)
