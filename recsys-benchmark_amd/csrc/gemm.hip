@@ -71,14 +71,30 @@ __device__ __forceinline__ float4 guarded4(const float *p, long long off, int nv
   return r;
 }
 
-__device__ __forceinline__ Staged stage_load(const float *P, int ld, int trans, int row0, int nrows, int k0,
-                                             int K, bool aligned) {
+// TRANS is a compile-time layout; `interior` (uniform per workgroup and tile) selects the
+// branch-free path: whole tile in bounds and 16-B aligned -> two unguarded float4 loads.
+template <int TRANS>
+__device__ __forceinline__ Staged stage_load(const float *P, int ld, int row0, int nrows, int k0, int K,
+                                             bool aligned) {
   Staged s;
   const int t = threadIdx.x;
+  const bool interior = aligned && (row0 + BM <= nrows) && (k0 + BK <= K);
+  if (interior) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = t + i * 256;
+      if constexpr (!TRANS) {
+        s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(row0 + (f >> 3)) * ld + k0 + (f & 7) * 4);
+      } else {
+        s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(k0 + (f >> 4)) * ld + row0 + (f & 15) * 4);
+      }
+    }
+    return s;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = t + i * 256;
-    if (!trans) {
+    if constexpr (!TRANS) {
       const int row = f >> 3, kq = (f & 7) * 4;
       const int r = row0 + row, k = k0 + kq;
       const int nv = (r < nrows) ? (K - k) : 0;
@@ -93,12 +109,13 @@ __device__ __forceinline__ Staged stage_load(const float *P, int ld, int trans, 
   return s;
 }
 
-__device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s, int trans) {
+template <int TRANS>
+__device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = t + i * 256;
-    if (!trans) {
+    if constexpr (!TRANS) {
       const int row = f >> 3, kq = (f & 7) * 4;
       *reinterpret_cast<float4 *>(&T[row][kq]) = s.v[i];
     } else {
@@ -111,6 +128,8 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s, i
   }
 }
 
+// TA: A is [k][m] in memory; BT: B is staged transposed, i.e. B is [k][n] in memory (transB == 0)
+template <int TA, int BT>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDSS];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
@@ -123,8 +142,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 
   const float *A = a.A + z * a.sA;
   const float *B = a.B + z * a.sB;
-  // B as "rows = n": transB==1 means global [n][k] (k contiguous) -> stage as non-transposed
-  const int bt = a.transB ? 0 : 1;
 
   floatx16 acc;
 #pragma unroll
@@ -137,19 +154,33 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   const int first = slice * per;
   const int total = (first + per <= all) ? first + per : all;
   if (first >= total) return;   // uniform per workgroup: an empty slice adds nothing
-  Staged sa = stage_load(A + (first / ktiles) * a.gA, a.lda, a.transA, m0, a.M, (first % ktiles) * BK, a.K, a.alignedA);
-  Staged sb = stage_load(B + (first / ktiles) * a.gB, a.ldb, bt, n0, a.N, (first % ktiles) * BK, a.K, a.alignedB);
-  stage_store(As[first & 1], sa, a.transA);
-  stage_store(Bs[first & 1], sb, bt);
+  // Two tiles of register prefetch: while tile `it` is multiplied out of LDS, tile it+1 sits in
+  // registers (issued one step ago, written to the other LDS buffer after this step's MFMAs) and
+  // the loads of tile it+2 are issued now — two MFMA phases (~0.9 us) cover the L2/HBM latency.
+  auto load_a = [&](int step) {
+    return stage_load<TA>(A + (step / ktiles) * a.gA, a.lda, m0, a.M, (step % ktiles) * BK, a.K, a.alignedA);
+  };
+  auto load_b = [&](int step) {
+    return stage_load<BT>(B + (step / ktiles) * a.gB, a.ldb, n0, a.N, (step % ktiles) * BK, a.K, a.alignedB);
+  };
+  Staged sa = load_a(first), sb = load_b(first);
+  stage_store<TA>(As[first & 1], sa);
+  stage_store<BT>(Bs[first & 1], sb);
+  Staged na, nb;                         // tile it+1
+  if (first + 1 < total) {
+    na = load_a(first + 1);
+    nb = load_b(first + 1);
+  }
   __syncthreads();
 
   for (int it = first; it < total; ++it) {
     const int cur = it & 1;
     const bool more = it + 1 < total;
-    if (more) {
-      const int g = (it + 1) / ktiles, kt = (it + 1) % ktiles;
-      sa = stage_load(A + g * a.gA, a.lda, a.transA, m0, a.M, kt * BK, a.K, a.alignedA);
-      sb = stage_load(B + g * a.gB, a.ldb, bt, n0, a.N, kt * BK, a.K, a.alignedB);
+    Staged fa, fb;                       // tile it+2
+    const bool more2 = it + 2 < total;
+    if (more2) {
+      fa = load_a(it + 2);
+      fb = load_b(it + 2);
     }
 #pragma unroll
     for (int c = 0; c < BK / 8; ++c) {
@@ -161,10 +192,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
     }
     if (more) {
-      stage_store(As[cur ^ 1], sa, a.transA);
-      stage_store(Bs[cur ^ 1], sb, bt);
+      stage_store<TA>(As[cur ^ 1], na);
+      stage_store<BT>(Bs[cur ^ 1], nb);
     }
     __syncthreads();
+    if (more2) {
+      na = fa;
+      nb = fb;
+    }
   }
 
   // ---- epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of its 32x32 tile
@@ -256,10 +291,15 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splitk);
   if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
   hipEvent_t ea, eb;
-  if (mi::prof_acquire("gemm_f32", &ea, &eb))
-    hipExtLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a);
-  else
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const bool prof = mi::prof_acquire("gemm_f32", &ea, &eb);
+#define GO(TA, BT)                                                                                      \
+  do {                                                                                                  \
+    if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
+    else hipLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, a);          \
+  } while (0)
+  if (a.transA) { if (a.transB) GO(1, 0); else GO(1, 1); }
+  else { if (a.transB) GO(0, 0); else GO(0, 1); }
+#undef GO
   return launch_status();
 }
 
