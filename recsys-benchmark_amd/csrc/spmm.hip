@@ -6,9 +6,9 @@
 // wave-instruction gathers NPW = 64/LPR neighbour rows (1 KiB); the loop is unrolled so 4 such
 // gathers are in flight per wave.  Partial sums live in registers and are combined across the
 // NPW neighbour slots with shuffle-xor.  Rows are split by degree on the host side once per
-// matrix: "short" rows get one wave each; "long" rows (power-law hubs) get a whole workgroup
-// whose 4 waves stride the row and combine through LDS — a hub of degree 4,000 otherwise
-// serialises ~250 dependent gathers on one wave while the rest of the chip has finished.
+// matrix: "short" rows get one wave each; "long" rows (power-law hubs) get a whole 16-wave
+// workgroup whose waves stride the row and combine through LDS — a hub of degree 5,000 otherwise
+// serialises ~300 dependent gathers on one wave while the rest of the chip has finished.
 // X (and the running sum) may be given as two row segments (user table | item table) so the
 // reference's torch.cat of the two weight tables is never materialised.
 #include "common.hpp"
@@ -86,21 +86,24 @@ __global__ __launch_bounds__(kBlock) void k_spmm_wave_rows(
   }
 }
 
-// one 1024-thread workgroup (16 waves) per hub row: 16 x NPW neighbour slots stride the row
+// ONE launch of 1024-thread workgroups (16 waves): workgroups [0, n_long) each take a hub row
+// (16 x NPW neighbour slots stride the row, combined through LDS); the remaining workgroups give
+// every wave its own short row.  Hubs start first and overlap with the short rows instead of
+// serialising behind them as a second kernel.
 constexpr int kHubWaves = 16;
 template <int LPR>
-__global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_block_rows(
+__global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
     float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
-    const int *__restrict__ rows, int n_items) {
+    const int *__restrict__ short_rows, int n_short, const int *__restrict__ long_rows, int n_long) {
   constexpr int NPW = kWave / LPR;
   constexpr int D = LPR * 4;
   __shared__ float4 part[kHubWaves][LPR];
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int q = lane % LPR, k = lane / LPR;
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const int row = rows[it];
+  if ((int)blockIdx.x < n_long) {
+    const int row = long_rows[blockIdx.x];
     const int lo = crow[row], hi = crow[row + 1];
     float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q);
     a = slot_sum<LPR>(a);
@@ -115,7 +118,15 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_block_rows(
       }
       epilogue4(s, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
     }
-    __syncthreads();
+    return;
+  }
+  const int nblk = gridDim.x - n_long;
+  for (int it = (blockIdx.x - n_long) * kHubWaves + w; it < n_short; it += nblk * kHubWaves) {
+    const int row = short_rows[it];
+    const int lo = crow[row], hi = crow[row + 1];
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, k, NPW, q);
+    a = slot_sum<LPR>(a);
+    if (k == 0) epilogue4(a, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
   }
 }
 
@@ -163,17 +174,19 @@ int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, const
   const bool al = aligned16(Xa) && (!Xb || aligned16(Xb)) && (!Y || aligned16(Y)) &&
                   (!acc_in_a || aligned16(acc_in_a)) && (!acc_in_b || aligned16(acc_in_b)) &&
                   (!acc_out || aligned16(acc_out));
+  if (planned && n_long > 60000) return MI_ERR_UNSUPPORTED;
   if (vec_ok(D) && al) {
-    const int ns = planned ? n_short : n_rows;
 #define CALL(LPR)                                                                                       \
   do {                                                                                                  \
-    if (ns > 0)                                                                                         \
-      MI_LAUNCH("spmm_csr_rows", (k_spmm_wave_rows<LPR>), grid_for_waves(ns), kBlock, stream, crow, col, \
-                val, X, Y, A, has_acc, acc_out, scale, planned ? short_rows : nullptr, ns);             \
-    if (planned && n_long > 0)                                                                          \
-      MI_LAUNCH("spmm_csr_hubs", (k_spmm_block_rows<LPR>), (n_long < kMaxGrid ? n_long : kMaxGrid),     \
-                kHubWaves * kWave, stream, crow, col, val, X, Y, A, has_acc, acc_out, scale, long_rows, \
-                n_long);                                                                                \
+    if (!planned) {                                                                                     \
+      MI_LAUNCH("spmm_csr_rows", (k_spmm_wave_rows<LPR>), grid_for_waves(n_rows), kBlock, stream, crow, \
+                col, val, X, Y, A, has_acc, acc_out, scale, nullptr, n_rows);                           \
+    } else {                                                                                            \
+      int sb = (n_short + kHubWaves - 1) / kHubWaves;                                                   \
+      if (sb > 1024) sb = 1024;                                                                         \
+      MI_LAUNCH("spmm_csr", (k_spmm_planned<LPR>), n_long + sb, kHubWaves * kWave, stream, crow, col,   \
+                val, X, Y, A, has_acc, acc_out, scale, short_rows, n_short, long_rows, n_long);         \
+    }                                                                                                   \
   } while (0)
     switch (D / 4) {
       case 1: CALL(1); break;
