@@ -197,7 +197,7 @@ def main():
     # roofline leg: the same step launched eagerly, every library kernel timed by its own
     # dispatch begin/end events (a graph replay cannot carry per-kernel events).
     n_prof = min(args.steps, 100)
-    with KernelTimer(capacity=8 * n_prof + 64) as kt:
+    with KernelTimer(capacity=32 * n_prof + 64) as kt:
         for _ in range(n_prof):
             eager_step()
         torch.cuda.synchronize()

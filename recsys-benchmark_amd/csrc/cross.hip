@@ -27,13 +27,16 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
   if (n < N) {
     const int stride = gridDim.y * 4;
     int m = blockIdx.y * 4 + rl;
-    if (!rowscale) {
+    if (!rowscale || nrs == 1) {
       for (; m + 7 * stride < M; m += 8 * stride) {   // 8 independent row loads in flight
-        float v[8];
+        float v[8], rs[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = X[(int64_t)(m + u * stride) * ldx + n];
+        for (int u = 0; u < 8; ++u) {
+          v[u] = X[(int64_t)(m + u * stride) * ldx + n];
+          rs[u] = rowscale ? rowscale[m + u * stride] : 1.f;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += v[u] * rs[u];
       }
     }
     for (; m < M; m += stride) {
@@ -50,9 +53,10 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
   if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
-// out[m] = sum_n X[m,n] * v[n]
+// out[m] = sum_n X[m,n] * v[n] (+ bias[0])
 __global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, int ldx, const float *__restrict__ v,
-                                                   float *__restrict__ out, int M, int N) {
+                                                   const float *__restrict__ bias, float *__restrict__ out, int M,
+                                                   int N) {
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * kWavesPerBlock;
@@ -60,7 +64,26 @@ __global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, 
     float s = 0.f;
     for (int n = lane; n < N; n += kWave) s += X[(int64_t)m * ldx + n] * v[n];
     s = wave_sum(s);
-    if (lane == 0) out[m] = s;
+    if (lane == 0) out[m] = s + (bias ? bias[0] : 0.f);
+  }
+}
+
+// out[m,n] = g[m] * w[n]   (backward of a 1-output Linear w.r.t. its input)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_outer(const float *__restrict__ g, const float *__restrict__ w,
+                                                  float *__restrict__ out, int M, int N) {
+  const int nv = N / VEC;
+  const int64_t total = (int64_t)M * nv;
+  for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < total;
+       ev += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(ev / nv), n0 = (int)(ev % nv) * VEC;
+    const float gm = g[m];
+    if constexpr (VEC == 4) {
+      const float4 wv = ld4(w + n0);
+      st4(out + (int64_t)m * N + n0, make_float4(gm * wv.x, gm * wv.y, gm * wv.z, gm * wv.w));
+    } else {
+      out[(int64_t)m * N + n0] = gm * w[n0];
+    }
   }
 }
 
@@ -126,11 +149,23 @@ int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, f
   return launch_status();
 }
 
-int mi_rowdot(const float *X, int32_t ldx, const float *v, float *out, int32_t M, int32_t N, void *stream) {
+int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias, float *out, int32_t M, int32_t N,
+              void *stream) {
   if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !v || !out) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, out, M, N);
+  MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, bias, out, M, N);
+  return launch_status();
+}
+
+int mi_outer(const float *g, const float *w, float *out, int32_t M, int32_t N, void *stream) {
+  if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MI_OK;
+  if (!g || !w || !out) return MI_ERR_INVALID_ARG;
+  if (N % 4 == 0 && aligned16(w) && aligned16(out))
+    MI_LAUNCH("outer", k_outer<4>, grid_for_elems((int64_t)M * N / 4), kBlock, stream, g, w, out, M, N);
+  else
+    MI_LAUNCH("outer", k_outer<1>, grid_for_elems((int64_t)M * N), kBlock, stream, g, w, out, M, N);
   return launch_status();
 }
 

@@ -61,6 +61,44 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+class _Linear1Fn(torch.autograd.Function):
+    """A Linear with ONE output (the tail's last layer): a rank-1 layer is three memory-bound passes
+    (row-dot; scaled column sum for dW; outer product for dx), not three GEMM launches —
+    hipBLASLt spent ~40 us per step on it at [4096, 400] (rocprof r01)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        dev = _lib.require_gpu(x, W)
+        x = _kernels._f32c(x)
+        M, N = x.shape
+        out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().mi_rowdot(x.data_ptr(), N, W.data_ptr(), _lib.ptr(b), out.data_ptr(), M, N,
+                                         _lib.stream_ptr(dev)), "mi_rowdot")
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        dev = x.device
+        M, N = x.shape
+        g = _kernels._f32c(g).view(M)
+        lib, s = _lib.load(), _lib.stream_ptr(dev)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, N), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_outer(g.data_ptr(), W.data_ptr(), dx.data_ptr(), M, N, s), "mi_outer")
+        red = torch.zeros((N + 1,), dtype=torch.float32, device=dev)
+        if ctx.needs_input_grad[1]:
+            _lib.check(lib.mi_colsum(x.data_ptr(), N, g.data_ptr(), 1, red.data_ptr(), M, N, s), "mi_colsum")
+            dW = red[:N].view(1, N)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            _lib.check(lib.mi_colsum(g.data_ptr(), 1, None, 0, red[N:].data_ptr(), M, 1, s), "mi_colsum")
+            db = red[N:]
+        return dx, dW, db
+
+
 class _BNReLUDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, has_bn, training, momentum, eps, p, seed, salt,
@@ -160,7 +198,13 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     for k, grp in enumerate(groups):
         if grp[0] == "plain":
             m = grp[1]
-            x = _LinearFn.apply(x, m.weight, m.bias, take(m.out_features), False) if isinstance(m, nn.Linear) else m(x)
+            if isinstance(m, nn.Linear) and m.out_features == 1 and x.dim() == 2:
+                take(1)
+                x = _Linear1Fn.apply(x, m.weight, m.bias)
+            elif isinstance(m, nn.Linear):
+                x = _LinearFn.apply(x, m.weight, m.bias, take(m.out_features), False)
+            else:
+                x = m(x)
             continue
         _, lin, bn, dp = grp
         N = lin.out_features
