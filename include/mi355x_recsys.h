@@ -259,6 +259,23 @@ MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, 
                                   const float *save_rstd, float *dgamma_dbeta, float *dZ,
                                   void *stream);
 
+/* ---- §8f rank 1: fused row-sparse optimizer steps on row-form gradients -------------------
+ * Reference: get_optimizers' sparse branch (src/models/deepfm.py:163-184): torch.optim.SparseAdam
+ * on the embedding (no weight decay) / SGD with weight_decay=0 on it.
+ * mi_sparse_adam_sorted: rows_sorted int64[n] ascending, perm int64[n] (sorted position -> entry of
+ *   vals fp32[n,D]); duplicates are summed (== grad.coalesce()), then for each touched row
+ *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); W -= step_size * m/(sqrt(v)+eps),
+ *   step_size = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host (torch/optim/sparse_adam.py).
+ * mi_scatter_axpy_rows: W[idx[i],:] += alpha*g[i,:] (row-sparse SGD, alpha = -lr; float atomics).
+ */
+MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm,
+                                 const float *vals, float *W, float *exp_avg,
+                                 float *exp_avg_sq, int64_t n, int32_t D, int64_t N,
+                                 float step_size, float beta1, float beta2, float eps,
+                                 void *stream);
+MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
+                                int64_t n, int32_t D, int64_t N, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

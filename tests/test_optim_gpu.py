@@ -1,0 +1,69 @@
+"""GPU: the fused row-sparse optimizer steps vs torch.optim.SparseAdam / SGD on CPU (the optimizer
+the reference's sparse config uses, src/models/deepfm.py:173-184).  fp32; duplicate-row sums differ
+only in order: rtol 1e-5 / atol 1e-6 after 3 steps."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+import recsys_benchmark_amd as pkg
+from recsys_benchmark_amd.optim import SparseAdam, SparseSGD, get_optimizers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("N,D,n", [(1000, 16, 4096), (50, 16, 2000), (300, 7, 500), (100000, 64, 3000), (64, 1, 700)])
+def test_sparse_adam_matches_torch(N, D, n):
+    gen = torch.Generator().manual_seed(N + D)
+    W0 = torch.randn(N, D, generator=gen)
+    ref = torch.nn.Parameter(W0.clone())
+    mine = torch.nn.Parameter(W0.clone().to(DEV))
+    oref = torch.optim.SparseAdam([ref], lr=0.01)
+    omine = SparseAdam([mine], lr=0.01)
+    for step in range(3):
+        rows = (N * torch.rand(n, generator=gen).pow(3)).long().clamp_(max=N - 1)    # skewed: many duplicates
+        vals = torch.randn(n, D, generator=gen)
+        ref.grad = torch.sparse_coo_tensor(rows.view(1, -1), vals, (N, D))
+        mine.grad = torch.sparse_coo_tensor(rows.view(1, -1).to(DEV), vals.to(DEV), (N, D), check_invariants=False)
+        oref.step()
+        omine.step()
+    # a hot row sums hundreds of duplicates in a different order than coalesce(): rtol 1e-4
+    assert_close(mine, ref, 1e-4, 1e-5, "param")
+    assert_close(omine.state[mine]["exp_avg"], oref.state[ref]["exp_avg"], 1e-4, 1e-5, "exp_avg")
+    assert_close(omine.state[mine]["exp_avg_sq"], oref.state[ref]["exp_avg_sq"], 1e-4, 1e-6, "exp_avg_sq")
+    untouched = torch.ones(N, dtype=torch.bool)
+    untouched[rows] = False
+    assert omine.state[mine]["step"] == 3
+
+
+def test_sparse_sgd_and_factory_end_to_end():
+    torch.manual_seed(0)
+    dims = [20, 30, 5]
+    model = pkg.DeepFM(dims, 16, [32], p_dropout=0.0, use_batchnorm=True,
+                       embedding_config={"name": "vanilla", "sparse": True}).to(DEV)
+    cfg = {"sparse": True, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    opts = get_optimizers(model, cfg)
+    assert isinstance(opts[0], SparseAdam) and isinstance(opts[1], torch.optim.Adam)
+    x = torch.stack([torch.randint(0, d, (64,)) for d in dims], 1).to(DEV)
+    y = (torch.rand(64) < 0.5).float().to(DEV)
+    losses = []
+    for _ in range(30):
+        for o in opts:
+            o.zero_grad()
+        loss = torch.nn.BCEWithLogitsLoss()(model(x), y)
+        loss.backward()
+        for o in opts:
+            o.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] * 0.7, losses[::5]
+    # SGD variant: one step equals a dense SGD step on the densified gradient
+    W = torch.nn.Parameter(torch.randn(40, 16, device=DEV))
+    W0 = W.detach().clone()
+    rows = torch.randint(0, 40, (200,), device=DEV)
+    vals = torch.randn(200, 16, device=DEV)
+    W.grad = torch.sparse_coo_tensor(rows.view(1, -1), vals, (40, 16), check_invariants=False)
+    SparseSGD([W], lr=0.1).step()
+    assert_close(W, W0 - 0.1 * W.grad.to_dense(), 1e-5, 1e-5)
+    cfg2 = {"sparse": True, "optimizer": "sgd", "learning_rate": 1e-2, "weight_decay": 0.0}
+    assert isinstance(get_optimizers(model, cfg2)[0], SparseSGD)
