@@ -71,26 +71,39 @@ __device__ __forceinline__ float4 guarded4(const float *p, long long off, int nv
   return r;
 }
 
-// TRANS is a compile-time layout; `interior` (uniform per workgroup and tile) selects the
-// branch-free path: whole tile in bounds and 16-B aligned -> two unguarded float4 loads.
+// Tile staging.  FAST (chosen ONCE per workgroup: 16-B aligned operands, the 64 rows of both
+// operands in bounds) loads full k-tiles with two unguarded float4 per thread — no branch may sit
+// between a load and its use inside the pipelined loop, or the compiler drains vmcnt(0) at the merge
+// and the prefetch is lost (seen in the ISA of the first version).  The guarded form handles edge
+// workgroups and the K tail.
+// Rows past the operand's end (edge workgroups) are CLAMPED to the last valid row / row group: the
+// duplicated data only feeds output rows or columns the epilogue never stores, and every address
+// stays inside the buffer — so edge workgroups run the same branch-free pipeline.
 template <int TRANS>
-__device__ __forceinline__ Staged stage_load(const float *P, int ld, int row0, int nrows, int k0, int K,
-                                             bool aligned) {
+__device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int row0, int nrows, int k0) {
   Staged s;
   const int t = threadIdx.x;
-  const bool interior = aligned && (row0 + BM <= nrows) && (k0 + BK <= K);
-  if (interior) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = t + i * 256;
-      if constexpr (!TRANS) {
-        s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(row0 + (f >> 3)) * ld + k0 + (f & 7) * 4);
-      } else {
-        s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(k0 + (f >> 4)) * ld + row0 + (f & 15) * 4);
-      }
+  for (int i = 0; i < 2; ++i) {
+    const int f = t + i * 256;
+    if constexpr (!TRANS) {
+      int r = row0 + (f >> 3);
+      r = r < nrows ? r : nrows - 1;
+      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)r * ld + k0 + (f & 7) * 4);
+    } else {
+      int r = row0 + (f & 15) * 4;          // nrows % 4 == 0 on this path: a group is all-in or all-out
+      r = r < nrows ? r : nrows - 4;
+      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(k0 + (f >> 4)) * ld + r);
     }
-    return s;
   }
+  return s;
+}
+
+template <int TRANS>
+__device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int row0, int nrows, int k0, int K,
+                                                     bool aligned) {
+  Staged s;
+  const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = t + i * 256;
@@ -128,6 +141,18 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
   }
 }
 
+__device__ __forceinline__ void mma_tile(floatx16 &acc, float (*As)[LDSS], float (*Bs)[LDSS], int ar, int br, int kh) {
+#pragma unroll
+  for (int c = 0; c < BK / 8; ++c) {
+    const float4 av = *reinterpret_cast<const float4 *>(&As[ar][c * 8 + kh * 4]);
+    const float4 bv = *reinterpret_cast<const float4 *>(&Bs[br][c * 8 + kh * 4]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+}
+
 // TA: A is [k][m] in memory; BT: B is staged transposed, i.e. B is [k][n] in memory (transB == 0)
 template <int TA, int BT>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
@@ -139,6 +164,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int i = lane & 31, kh = lane >> 5;
+  const int ar = wr * 32 + i, br = wc * 32 + i;
 
   const float *A = a.A + z * a.sA;
   const float *B = a.B + z * a.sB;
@@ -154,51 +180,61 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   const int first = slice * per;
   const int total = (first + per <= all) ? first + per : all;
   if (first >= total) return;   // uniform per workgroup: an empty slice adds nothing
-  // Two tiles of register prefetch: while tile `it` is multiplied out of LDS, tile it+1 sits in
-  // registers (issued one step ago, written to the other LDS buffer after this step's MFMAs) and
-  // the loads of tile it+2 are issued now — two MFMA phases (~0.9 us) cover the L2/HBM latency.
-  auto load_a = [&](int step) {
-    return stage_load<TA>(A + (step / ktiles) * a.gA, a.lda, m0, a.M, (step % ktiles) * BK, a.K, a.alignedA);
-  };
-  auto load_b = [&](int step) {
-    return stage_load<BT>(B + (step / ktiles) * a.gB, a.ldb, n0, a.N, (step % ktiles) * BK, a.K, a.alignedB);
-  };
-  Staged sa = load_a(first), sb = load_b(first);
-  stage_store<TA>(As[first & 1], sa);
-  stage_store<BT>(Bs[first & 1], sb);
-  Staged na, nb;                         // tile it+1
-  if (first + 1 < total) {
-    na = load_a(first + 1);
-    nb = load_b(first + 1);
-  }
-  __syncthreads();
 
-  for (int it = first; it < total; ++it) {
-    const int cur = it & 1;
-    const bool more = it + 1 < total;
-    Staged fa, fb;                       // tile it+2
-    const bool more2 = it + 2 < total;
-    if (more2) {
-      fa = load_a(it + 2);
-      fb = load_b(it + 2);
+  const bool fast = a.alignedA && a.alignedB && (!TA || (a.M % 4 == 0 && a.M >= 4)) && (!BT || (a.N % 4 == 0 && a.N >= 4));
+  if (fast) {
+    // Pipelined over FULL k-tiles only; a partial last tile of a group is a guarded step.
+    const int kfull = a.K / BK;                       // full tiles per group
+    auto is_full = [&](int step) { return (step % ktiles) < kfull; };
+    auto fa = [&](int step) { return stage_load_fast<TA>(A + (step / ktiles) * a.gA, a.lda, m0, a.M, (step % ktiles) * BK); };
+    auto fb = [&](int step) { return stage_load_fast<BT>(B + (step / ktiles) * a.gB, a.ldb, n0, a.N, (step % ktiles) * BK); };
+    int it = first;
+    while (it < total) {
+      if (!is_full(it)) {   // K tail of a group: one unpipelined guarded tile
+        const Staged ta = stage_load_guarded<TA>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, true);
+        const Staged tb = stage_load_guarded<BT>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, true);
+        __syncthreads();
+        stage_store<TA>(As[0], ta);
+        stage_store<BT>(Bs[0], tb);
+        __syncthreads();
+        mma_tile(acc, As[0], Bs[0], ar, br, kh);
+        ++it;
+        continue;
+      }
+      // run of consecutive full tiles [it, run_end)
+      int run_end = it;
+      while (run_end < total && is_full(run_end)) ++run_end;
+      __syncthreads();
+      Staged sa = fa(it), sb = fb(it);
+      stage_store<TA>(As[0], sa);
+      stage_store<BT>(Bs[0], sb);
+      Staged na = sa, nb = sb;
+      if (it + 1 < run_end) { na = fa(it + 1); nb = fb(it + 1); }
+      __syncthreads();
+      for (int s2 = it; s2 < run_end; ++s2) {
+        const int cur = (s2 - it) & 1;
+        Staged f2a = na, f2b = nb;
+        if (s2 + 2 < run_end) { f2a = fa(s2 + 2); f2b = fb(s2 + 2); }   // tile s2+2: in flight over two MFMA phases
+        mma_tile(acc, As[cur], Bs[cur], ar, br, kh);
+        if (s2 + 1 < run_end) {
+          stage_store<TA>(As[cur ^ 1], na);
+          stage_store<BT>(Bs[cur ^ 1], nb);
+        }
+        __syncthreads();
+        na = f2a;
+        nb = f2b;
+      }
+      it = run_end;
     }
-#pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      const float4 av = *reinterpret_cast<const float4 *>(&As[cur][wr * 32 + i][c * 8 + kh * 4]);
-      const float4 bv = *reinterpret_cast<const float4 *>(&Bs[cur][wc * 32 + i][c * 8 + kh * 4]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-    }
-    if (more) {
-      stage_store<TA>(As[cur ^ 1], na);
-      stage_store<BT>(Bs[cur ^ 1], nb);
-    }
-    __syncthreads();
-    if (more2) {
-      na = fa;
-      nb = fb;
+  } else {
+    for (int it = first; it < total; ++it) {
+      const Staged ta = stage_load_guarded<TA>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, a.alignedA);
+      const Staged tb = stage_load_guarded<BT>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, a.alignedB);
+      __syncthreads();
+      stage_store<TA>(As[0], ta);
+      stage_store<BT>(Bs[0], tb);
+      __syncthreads();
+      mma_tile(acc, As[0], Bs[0], ar, br, kh);
     }
   }
 
