@@ -299,6 +299,10 @@ class ShardedDeepFM(nn.Module):
         replay for FM+MLP forward, one for their backward, eager gradient all-to-all + all-reduce."""
         F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
         dev = self.embedding_shard.device
+        # no collective may be in flight while a capture is open (the RCCL watchdog polls events)
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=self.group)
+        torch.cuda.synchronize(dev)
         emb = torch.randn(batch_size, F, D, device=dev, requires_grad=True)
         lin = torch.randn(batch_size, F, device=dev, requires_grad=True)
 
@@ -316,6 +320,8 @@ class ShardedDeepFM(nn.Module):
         object.__setattr__(self, "_graphed_local",
                            torch.cuda.make_graphed_callables(_Local(self), (emb, lin), num_warmup_iters=3))
         object.__setattr__(self, "_graphed_batch", batch_size)
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=self.group)
 
     def forward(self, x):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
