@@ -140,6 +140,21 @@ MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const floa
                               int64_t n1, int64_t n2, int64_t mod1, int64_t div2,
                               int32_t op, int32_t xform, void *stream);
 
+/* ---- §8f rank 4 (first flavour): single-table gather with a per-element transform -------------
+ * PEP (src/models/embeddings/pep_embedding.py:82-92): out = sign(w) relu(|w| - sigmoid(s)), w = W[idx],
+ *   s = S[row*srs + d*scs] — strides (0,0) global, (0,1) dimension, (1,0) feature, (D,1) feature_dim.
+ * RetrainPep (:211-221): out = W[idx] * M (bool mask, 1 byte).  xform as in mi_dual_gather_fwd.
+ * Backward: dense gW (and gS, s_numel elements) caller-zeroed, float atomics; small S pre-summed in LDS.
+ */
+MI_API int mi_xform_gather_fwd(const int64_t *idx, const float *W, const float *S,
+                               const uint8_t *M, int64_t srs, int64_t scs, float *out,
+                               int64_t n, int32_t D, int64_t N, int32_t xform, int32_t *err,
+                               void *stream);
+MI_API int mi_xform_gather_bwd(const int64_t *idx, const float *g_out, const float *W,
+                               const float *S, const uint8_t *M, int64_t srs, int64_t scs,
+                               float *gW, float *gS, int64_t s_numel, int64_t n, int32_t D,
+                               int64_t N, int32_t xform, void *stream);
+
 /* ---- a11: CSR-pruned table rows (numba kernels K1/K2) ------------------------
  * src/models/embeddings/pruned_embedding.py:136-204: out[i,:] = dense row ids[i] of the
  * CSR matrix (values fp32, crow/col int64).  out fp32[n,D] need not be pre-zeroed.

@@ -125,6 +125,17 @@ def cerp_retrain_forward(idx, p_weight, q_weight, p_mask, q_mask, bucket_size: i
     return F.embedding(q_idx, q_weight * q_mask) + F.embedding(p_idx, p_weight * p_mask)
 
 
+def pep_forward(idx, weight, s) -> torch.Tensor:
+    """PepEmbeeding.forward (mode=None) — src/models/embeddings/pep_embedding.py:82-92: soft-threshold the
+    whole table (s broadcasts over it), then gather."""
+    return F.embedding(idx, soft_threshold(weight, s))
+
+
+def pep_retrain_forward(idx, weight, mask) -> torch.Tensor:
+    """RetrainPepEmbedding.forward — pep_embedding.py:215-221."""
+    return F.embedding(idx, weight * mask)
+
+
 # --------------------------------------------------------------------------- DHE
 def dhe_hash(ids: torch.Tensor, slopes, bias, primes, prefix: int, m: int = 1000000) -> torch.Tensor:
     """_get_universal_hash_batch — src/models/embeddings/dh_embedding.py:213-236.  torch's % on

@@ -618,3 +618,61 @@ class TTLookup(torch.autograd.Function):
 
 def tt_lookup(idx, cores, num_item, p_shapes, q_shapes, ranks):
     return TTLookup.apply(idx, num_item, tuple(p_shapes), tuple(q_shapes), tuple(ranks), *cores)
+
+
+# --------------------------------------------------------------------------------------
+# single-table gather with a per-element transform (PEP / RetrainPep)
+class XformGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, W, S, M, srs: int, scs: int, xform: int):
+        dev = _lib.require_gpu(idx, W)
+        idxc, Wc = _i64c(idx), _f32c(W)
+        Sc = None if S is None else _f32c(S)
+        Mc = None if M is None else M.to(torch.uint8).contiguous()
+        N, D = Wc.shape
+        out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=dev)
+        _lib.check(
+            _lib.load().mi_xform_gather_fwd(idxc.data_ptr(), Wc.data_ptr(), _lib.ptr(Sc), _lib.ptr(Mc), srs, scs,
+                                            out.data_ptr(), idxc.numel(), D, N, xform,
+                                            _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+            "mi_xform_gather_fwd",
+        )
+        ctx.save_for_backward(idxc, Wc, Sc, Mc)
+        ctx.meta = (srs, scs, xform, tuple(W.shape), None if S is None else tuple(S.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idxc, Wc, Sc, Mc = ctx.saved_tensors
+        srs, scs, xform, Wshape, Sshape = ctx.meta
+        g = _f32c(g)
+        N, D = Wc.shape
+        gW = torch.zeros_like(Wc)
+        gS = torch.zeros_like(Sc) if (Sc is not None and xform == XF_SOFT) else None
+        _lib.check(
+            _lib.load().mi_xform_gather_bwd(idxc.data_ptr(), g.data_ptr(), Wc.data_ptr(), _lib.ptr(Sc), _lib.ptr(Mc),
+                                            srs, scs, gW.data_ptr(), _lib.ptr(gS), gS.numel() if gS is not None else 0,
+                                            idxc.numel(), D, N, xform, _lib.stream_ptr(g.device)),
+            "mi_xform_gather_bwd",
+        )
+        return None, gW.view(Wshape), (gS.view(Sshape) if gS is not None else None), None, None, None, None
+
+
+def soft_threshold_gather(idx, W, s):
+    """F.embedding(idx, sign(W)*relu(|W| - sigmoid(s))) with s broadcastable to W ([1], [D], [N,1], [N,D])."""
+    N, D = W.shape
+    if s.numel() == 1:
+        srs, scs = 0, 0
+    elif s.dim() == 1 and s.shape[0] == D:
+        srs, scs = 0, 1
+    elif tuple(s.shape) == (N, 1):
+        srs, scs = 1, 0
+    elif tuple(s.shape) == (N, D):
+        srs, scs = D, 1
+    else:
+        raise ValueError(f"threshold of shape {tuple(s.shape)} does not broadcast over a [{N},{D}] table")
+    return XformGather.apply(idx, W, s, None, srs, scs, XF_SOFT)
+
+
+def masked_gather(idx, W, mask):
+    return XformGather.apply(idx, W, None, mask, 0, 0, XF_MASK)

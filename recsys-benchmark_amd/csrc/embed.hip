@@ -337,6 +337,81 @@ __global__ __launch_bounds__(kBlock) void k_fm_fwd_anyD(const float *__restrict_
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
 }
 
+// ------------------------------------------------------------- single-table transformed gather
+// PEP (src/models/embeddings/pep_embedding.py:82-92): out = soft(W[idx], s) with the threshold s
+// broadcast over rows and/or columns (global [1], dimension [D], feature [N,1], feature_dim [N,D]):
+// S element of (row, d) = S[row*srs + d*scs].  RetrainPep (:211-221): out = W[idx] * mask.
+// One thread per output element (coalesced for any D); the lookup never materialises soft(W).
+struct XformTable {
+  const float *W;
+  const float *S;
+  const uint8_t *M;
+  int64_t srs, scs;
+  int64_t N;
+};
+
+__global__ __launch_bounds__(kBlock) void k_xform_gather_fwd(const int64_t *__restrict__ idx, XformTable t,
+                                                             float *__restrict__ out, int64_t n, int D, int xf,
+                                                             int *err) {
+  const int64_t total = n * D;
+  int bad = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx[e / D];
+    const int d = (int)(e % D);
+    float v = 0.f;
+    if ((uint64_t)row < (uint64_t)t.N) {
+      const float w = t.W[row * D + d];
+      if (xf == XF_SOFT) v = soft_(w, t.S[row * t.srs + d * t.scs]);
+      else if (xf == XF_MASK) v = t.M[row * D + d] ? w : 0.f;
+      else v = w;
+    } else {
+      bad = 1;
+    }
+    out[e] = v;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
+// gW[row,d] += g * [|w| > sig(s)] ; gS[s_off] += -g sign(w) [..] sig (1 - sig).  A threshold tensor of
+// <= 8192 elements (global / dimension forms: every lookup adds into the same few words) is summed
+// per workgroup in LDS first.
+__global__ __launch_bounds__(kBlock) void k_xform_gather_bwd(const int64_t *__restrict__ idx, XformTable t,
+                                                             const float *__restrict__ g, float *__restrict__ gW,
+                                                             float *__restrict__ gS, int64_t n, int D, int xf,
+                                                             int s_numel, int lds_s) {
+  __shared__ float acc[kLdsAccFloats];
+  if (lds_s) {
+    for (int k = threadIdx.x; k < s_numel; k += blockDim.x) acc[k] = 0.f;
+    __syncthreads();
+  }
+  const int64_t total = n * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx[e / D];
+    const int d = (int)(e % D);
+    if ((uint64_t)row >= (uint64_t)t.N) continue;
+    const int64_t o = row * D + d;
+    float gv = g[e];
+    if (xf == XF_SOFT) {
+      const int64_t so = row * t.srs + d * t.scs;
+      const float w = t.W[o], th = sigmoidf_(t.S[so]);
+      const float k = (fabsf(w) - th > 0.f) ? 1.f : 0.f;
+      const float gs = -gv * signf_(w) * k * th * (1.f - th);
+      if (lds_s) atomicAdd(&acc[so], gs); else atomicAdd(gS + so, gs);
+      gv *= k;
+    } else if (xf == XF_MASK) {
+      gv = t.M[o] ? gv : 0.f;
+    }
+    atomicAdd(gW + o, gv);
+  }
+  if (lds_s) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < s_numel; k += blockDim.x)
+      if (acc[k] != 0.f) atomicAdd(gS + k, acc[k]);
+  }
+}
+
 inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0; }
 inline int grid_for_elems(int64_t total) {
   int64_t g = (total + kBlock - 1) / kBlock;
@@ -409,6 +484,35 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
   if ((lds1 || lds2) && grid > 512) grid = 512;
   MI_LAUNCH("dual_gather_bwd", k_dual_bwd, grid, kBlock, stream, idx, t, g_out, gr, n, F, De, op, xform, lds1,
             lds2);
+  return launch_status();
+}
+
+int mi_xform_gather_fwd(const int64_t *idx, const float *W, const float *S, const uint8_t *M, int64_t srs,
+                        int64_t scs, float *out, int64_t n, int32_t D, int64_t N, int32_t xform, int32_t *err,
+                        void *stream) {
+  if (n < 0 || D <= 0 || N < 0 || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !W || !out || (xform == XF_SOFT && !S) || (xform == XF_MASK && !M)) return MI_ERR_INVALID_ARG;
+  XformTable t{W, S, M, srs, scs, N};
+  MI_LAUNCH("xform_gather_fwd", k_xform_gather_fwd, grid_for_elems(n * D), kBlock, stream, idx, t, out, n, D, xform,
+            err);
+  return launch_status();
+}
+
+int mi_xform_gather_bwd(const int64_t *idx, const float *g_out, const float *W, const float *S, const uint8_t *M,
+                        int64_t srs, int64_t scs, float *gW, float *gS, int64_t s_numel, int64_t n, int32_t D,
+                        int64_t N, int32_t xform, void *stream) {
+  if (n < 0 || D <= 0 || N < 0 || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !g_out || !W || !gW) return MI_ERR_INVALID_ARG;
+  if (xform == XF_SOFT && (!S || !gS || s_numel <= 0)) return MI_ERR_INVALID_ARG;
+  if (xform == XF_MASK && !M) return MI_ERR_INVALID_ARG;
+  XformTable t{W, S, M, srs, scs, N};
+  const int lds_s = (xform == XF_SOFT && s_numel <= kLdsAccFloats) ? 1 : 0;
+  int grid = grid_for_elems(n * D);
+  if (lds_s && grid > 512) grid = 512;
+  MI_LAUNCH("xform_gather_bwd", k_xform_gather_bwd, grid, kBlock, stream, idx, t, g_out, gW, gS, n, D, xform,
+            (int)(lds_s ? s_numel : 0), lds_s);
   return launch_status();
 }
 

@@ -12,6 +12,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 from .base import IEmbedding, VanillaEmbedding
 from .cerp_embedding import CerpEmbedding, RetrainCerpEmbedding
 from .dh_embedding import DHEmbedding
+from .pep_embedding import PepEmbeeding, RetrainPepEmbedding
 from .pruned_embedding import PrunedEmbedding
 from .qr_embedding import QRHashingEmbedding
 from .tensortrain_embeddings import TTRecTorch
@@ -20,6 +21,8 @@ NAME_TO_CLS: Dict[str, type] = {
     "vanilla": VanillaEmbedding,
     "qr": QRHashingEmbedding,
     "dhe": DHEmbedding,
+    "pep": PepEmbeeding,
+    "pep_retrain": RetrainPepEmbedding,
     "cerp": CerpEmbedding,
     "cerp_retrain": RetrainCerpEmbedding,
     "tt_emb_torch": TTRecTorch,
@@ -27,8 +30,6 @@ NAME_TO_CLS: Dict[str, type] = {
 
 # registry keys of the reference that this build deliberately does not cover
 OUT_OF_SCOPE = {
-    "pep": "PEP soft-threshold pruning (SURVEY.md §2.1 #6, §8f rank 4)",
-    "pep_retrain": "PEP retrain (SURVEY.md §2.1 #6)",
     "optembed_d": "OptEmbed search (SURVEY.md §2.1 #7)",
     "optembed_d_retrain": "OptEmbed search (SURVEY.md §2.1 #7)",
     "optembed": "OptEmbed search (SURVEY.md §2.1 #7)",
@@ -84,4 +85,4 @@ def detect_special(config: Dict[str, Any]) -> Tuple[Optional[str], bool]:
 
 
 __all__ = ["IEmbedding", "VanillaEmbedding", "QRHashingEmbedding", "CerpEmbedding", "RetrainCerpEmbedding",
-           "DHEmbedding", "PrunedEmbedding", "TTRecTorch", "NAME_TO_CLS", "get_embedding", "detect_special"]
+           "DHEmbedding", "PrunedEmbedding", "TTRecTorch", "PepEmbeeding", "RetrainPepEmbedding", "NAME_TO_CLS", "get_embedding", "detect_special"]

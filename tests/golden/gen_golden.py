@@ -166,6 +166,48 @@ def gen_cerp():
              num_params=np.array(emb.get_num_params()), **params_of(emb), **out)
 
 
+# ------------------------------------------------------------------ G3b: PEP / PEP-retrain
+def gen_pep():
+    import tempfile
+
+    gen = torch.Generator().manual_seed(31)
+    dims = [13, 29, 7]
+    N, D = sum(dims), 8
+    x1 = torch.randint(0, N, (11,), generator=gen)
+    x2 = torch.randint(0, N, (6, 3), generator=gen)
+    for ttype in ["global", "dimension", "feature", "feature_dim"]:
+        with tempfile.TemporaryDirectory() as tmp:
+            set_seed(2023)
+            emb = get_embedding({"name": "pep", "threshold_type": ttype, "checkpoint_weight_dir": tmp}, dims, D,
+                                field_name="deepfm")
+            with torch.no_grad():
+                emb.s.copy_(torch.randn(emb.s.shape, generator=gen) * 0.7 - 1.8)
+            out = {}
+            for tag, x in (("1d", x1), ("2d", x2)):
+                emb.zero_grad()
+                o = emb(x)
+                G = torch.randn(o.shape, generator=gen)
+                (o * G).sum().backward()
+                out.update({f"x_{tag}": x, f"out_{tag}": o, f"G_{tag}": G})
+                out.update(grads_of(emb, f"grad_{tag}/"))
+            emb.zero_grad()
+            save(f"pep_{ttype}", field_dims=np.array(dims), hidden=np.array(D), weight=emb.get_weight(),
+                 num_params=np.array(emb.get_num_params()), **params_of(emb), **out)
+            if ttype == "feature_dim":
+                # retrain variant: mask from this checkpoint, fresh trainable weights
+                os.makedirs(os.path.join(tmp, "deepfm"), exist_ok=True)
+                torch.save(emb.state_dict(), os.path.join(tmp, "deepfm", "0.5.pth"))
+                set_seed(7)
+                re = get_embedding({"name": "pep_retrain", "checkpoint_weight_dir": tmp, "sparsity": 0.5}, dims, D,
+                                   field_name="deepfm")
+                o = re(x2)
+                G = torch.randn(o.shape, generator=gen)
+                (o * G).sum().backward()
+                save("pep_retrain", field_dims=np.array(dims), hidden=np.array(D), x=x2, out=o, G=G,
+                     ckpt_weight=emb.emb.weight, ckpt_s=emb.s, weight=re.get_weight(), nnz=np.array(int(re.get_num_params())),
+                     **params_of(re), **grads_of(re))
+
+
 # ------------------------------------------------------------------ G4: DHE
 def gen_dhe():
     gen = torch.Generator().manual_seed(13)
@@ -335,7 +377,7 @@ def gen_csr_pruned():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

@@ -318,3 +318,61 @@ def test_tt_reference_ranks_vs_oracle():
     emb(torch.tensor([20000, -1], device=DEV))
     with pytest.raises(IndexError):
         _lib.check_index_errors()
+
+
+# ------------------------------------------------------------------ PEP / PEP-retrain (§8f rank 4)
+@pytest.mark.parametrize("ttype", ["global", "dimension", "feature", "feature_dim"])
+def test_pep_matches_reference_golden(ttype, tmp_path):
+    g = load_golden(f"pep_{ttype}")
+    emb = get_embedding({"name": "pep", "threshold_type": ttype, "checkpoint_weight_dir": str(tmp_path)},
+                        g["field_dims"].tolist(), int(g["hidden"]), field_name="deepfm")
+    emb.load_state_dict(g.group("param/"), strict=True)
+    emb.to(DEV)
+    for tag in ("1d", "2d"):
+        emb.zero_grad()
+        out = emb(g.t(f"x_{tag}").to(DEV))
+        assert_close(out, g.t(f"out_{tag}"), 1e-6, 1e-7, f"out {tag}")
+        (out * g.t(f"G_{tag}").to(DEV)).sum().backward()
+        assert_close(emb.emb.weight.grad, g.t(f"grad_{tag}/emb.weight"), 1e-5, 1e-6, "g weight")
+        assert_close(emb.s.grad, g.t(f"grad_{tag}/s"), 1e-4, 1e-6, "g s")
+    assert_close(emb.get_weight(), g.t("weight"), 1e-6, 1e-7, "get_weight")
+    assert emb.get_num_params() == int(g["num_params"])
+
+
+def test_pep_retrain_matches_reference_golden(tmp_path):
+    g = load_golden("pep_retrain")
+    d = tmp_path / "deepfm"
+    os.makedirs(d)
+    torch.save({"emb.weight": g.t("ckpt_weight"), "s": g.t("ckpt_s")}, d / "0.5.pth")
+    emb = get_embedding({"name": "pep_retrain", "checkpoint_weight_dir": str(tmp_path), "sparsity": 0.5},
+                        g["field_dims"].tolist(), int(g["hidden"]), field_name="deepfm")
+    emb.load_state_dict(g.group("param/"), strict=True)
+    assert int(emb.get_num_params()) == int(g["nnz"])
+    emb.to(DEV)
+    out = emb(g.t("x").to(DEV))
+    assert_close(out, g.t("out"), 0, 0, "out")
+    (out * g.t("G").to(DEV)).sum().backward()
+    assert_close(emb.emb.weight.grad, g.t("grad/emb.weight"), 1e-5, 1e-6)
+    assert_close(emb.get_weight(), g.t("weight"), 0, 0)
+
+
+@pytest.mark.parametrize("ttype", ["global", "dimension", "feature", "feature_dim"])
+def test_pep_vs_oracle_large(ttype, tmp_path):
+    gen = torch.Generator().manual_seed(21)
+    N, D = 50000, 16
+    emb = get_embedding({"name": "pep", "threshold_type": ttype, "checkpoint_weight_dir": str(tmp_path)}, N, D).to(DEV)
+    with torch.no_grad():
+        emb.s.copy_((torch.randn(emb.s.shape, generator=gen) * 0.5 - 4.0).to(DEV))   # sigmoid ~ 0.018 vs xavier bound 0.011..
+        emb.emb.weight.mul_(5.0)
+    idx = torch.randint(0, N, (4096, 26), generator=gen)
+    out = emb(idx.to(DEV))
+    w = emb.emb.weight.detach().cpu().requires_grad_(True)
+    s = emb.s.detach().cpu().requires_grad_(True)
+    ref = ro.pep_forward(idx, w, s)
+    assert_close(out, ref, 1e-5, 1e-7, "forward")
+    G = torch.randn(ref.shape, generator=gen)
+    (ref * G).sum().backward()
+    (out * G.to(DEV)).sum().backward()
+    assert_close(emb.emb.weight.grad, w.grad, 1e-4, 1e-5, "g weight")
+    sc = max(1.0, float(s.grad.abs().max()))
+    assert_close(emb.s.grad, s.grad, 1e-3, 1e-4 * sc, "g s")

@@ -20,6 +20,7 @@ def test_registry_keys_cover_the_reference_registry():
     for k in OUT_OF_SCOPE:
         with pytest.raises(NotImplementedError):
             get_embedding({"name": k}, [3, 4], 8)
+    assert {"vanilla", "qr", "dhe", "cerp", "cerp_retrain", "tt_emb_torch", "pep", "pep_retrain"} <= set(NAME_TO_CLS)
     with pytest.raises(NotImplementedError):
         get_embedding({"name": "nope"}, [3, 4], 8)
 
