@@ -155,6 +155,14 @@ MI_API int mi_xform_gather_bwd(const int64_t *idx, const float *g_out, const flo
                                float *gW, float *gS, int64_t s_numel, int64_t n, int32_t D,
                                int64_t N, int32_t xform, void *stream);
 
+/* Quantised tables, inference only (src/models/embeddings/ptq_emb.py:24-25,85-91):
+ * qtype 1: W is fp16[N,D], out = fp32(W[idx]); 2 / 3: W is int8 / int16 codes, out = (code - bias[0]) * scale[0]
+ * with bias a device int8 / int16 word and scale a device fp32 word.
+ */
+MI_API int mi_gather_rows_quant(const int64_t *idx, const void *W, int32_t qtype,
+                                const float *scale, const void *bias, float *out, int64_t n,
+                                int32_t D, int64_t N, int32_t *err, void *stream);
+
 /* ---- a11: CSR-pruned table rows (numba kernels K1/K2) ------------------------
  * src/models/embeddings/pruned_embedding.py:136-204: out[i,:] = dense row ids[i] of the
  * CSR matrix (values fp32, crow/col int64).  out fp32[n,D] need not be pre-zeroed.

@@ -676,3 +676,21 @@ def soft_threshold_gather(idx, W, s):
 
 def masked_gather(idx, W, mask):
     return XformGather.apply(idx, W, None, mask, 0, 0, XF_MASK)
+
+
+def gather_rows_quant(idx, W, scale=None, bias=None):
+    """Dequantising row gather for fp16 / int8 / int16 tables (inference only)."""
+    dev = _lib.require_gpu(idx, W)
+    qtype = {torch.float16: 1, torch.int8: 2, torch.int16: 3}.get(W.dtype)
+    if qtype is None:
+        raise TypeError(f"unsupported quantised table dtype {W.dtype}")
+    idxc, Wc = _i64c(idx), W.contiguous()
+    N, D = Wc.shape
+    out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=dev)
+    _lib.check(
+        _lib.load().mi_gather_rows_quant(idxc.data_ptr(), Wc.data_ptr(), qtype, _lib.ptr(scale), _lib.ptr(bias),
+                                         out.data_ptr(), idxc.numel(), D, N, _lib.err_word(dev).data_ptr(),
+                                         _lib.stream_ptr(dev)),
+        "mi_gather_rows_quant",
+    )
+    return out

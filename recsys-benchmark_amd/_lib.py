@@ -35,6 +35,7 @@ SIGNATURES = {
                            _i64, _i64, _i32, _i32, _p],
     "mi_xform_gather_fwd": [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i32, _i64, _i32, _p, _p],
     "mi_xform_gather_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i32, _i64, _i32, _p],
+    "mi_gather_rows_quant": [_p, _p, _i32, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_csr_rows_fwd": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_dhe_hash": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _p],
     "mi_spmm_csr": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _i32, _p, _i32, _p, _i32, _p],

@@ -16,6 +16,8 @@
 //
 // Lane mapping as in gather_fm.hip: a row of De = 4*LPR floats is LPR adjacent lanes x
 // float4; a wave-instruction covers RS = 64/LPR lookups.
+#include <hip/hip_fp16.h>
+
 #include "common.hpp"
 
 namespace {
@@ -412,6 +414,42 @@ __global__ __launch_bounds__(kBlock) void k_xform_gather_bwd(const int64_t *__re
   }
 }
 
+// ------------------------------------------------------------- quantised tables (PTQ, inference)
+// src/models/embeddings/ptq_emb.py:24-25 (fp16 -> fp32) and :85-91 ((code - bias) * scale, int8/int16).
+// torch computes (res - bias) in the integer type promoted with the int bias tensor, then * scale
+// (fp32): code and bias are small integers, the subtraction is exact in int32.
+enum { Q_FP16 = 1, Q_INT8 = 2, Q_INT16 = 3 };
+
+__global__ __launch_bounds__(kBlock) void k_gather_rows_q(const int64_t *__restrict__ idx, const void *__restrict__ W,
+                                                          int qtype, const float *__restrict__ scale,
+                                                          const void *__restrict__ bias, float *__restrict__ out,
+                                                          int64_t n, int D, int64_t N, int *err) {
+  const int64_t total = n * D;
+  int bad = 0;
+  float sc = 1.f;
+  int bi = 0;
+  if (qtype != Q_FP16) {
+    sc = scale[0];
+    bi = (qtype == Q_INT8) ? (int)reinterpret_cast<const int8_t *>(bias)[0]
+                           : (int)reinterpret_cast<const int16_t *>(bias)[0];
+  }
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx[e / D];
+    float v = 0.f;
+    if ((uint64_t)row < (uint64_t)N) {
+      const int64_t o = row * D + e % D;
+      if (qtype == Q_FP16) v = __half2float(reinterpret_cast<const __half *>(W)[o]);
+      else if (qtype == Q_INT8) v = (float)((int)reinterpret_cast<const int8_t *>(W)[o] - bi) * sc;
+      else v = (float)((int)reinterpret_cast<const int16_t *>(W)[o] - bi) * sc;
+    } else {
+      bad = 1;
+    }
+    out[e] = v;
+  }
+  if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+
 inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0; }
 inline int grid_for_elems(int64_t total) {
   int64_t g = (total + kBlock - 1) / kBlock;
@@ -513,6 +551,16 @@ int mi_xform_gather_bwd(const int64_t *idx, const float *g_out, const float *W, 
   if (lds_s && grid > 512) grid = 512;
   MI_LAUNCH("xform_gather_bwd", k_xform_gather_bwd, grid, kBlock, stream, idx, t, g_out, gW, gS, n, D, xform,
             (int)(lds_s ? s_numel : 0), lds_s);
+  return launch_status();
+}
+
+int mi_gather_rows_quant(const int64_t *idx, const void *W, int32_t qtype, const float *scale, const void *bias,
+                         float *out, int64_t n, int32_t D, int64_t N, int32_t *err, void *stream) {
+  if (n < 0 || D <= 0 || N < 0 || qtype < Q_FP16 || qtype > Q_INT16) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !W || !out || (qtype != Q_FP16 && (!scale || !bias))) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("gather_rows_quant", k_gather_rows_q, grid_for_elems(n * D), kBlock, stream, idx, W, qtype, scale, bias,
+            out, n, D, N, err);
   return launch_status();
 }
 

@@ -208,6 +208,33 @@ def gen_pep():
                      **params_of(re), **grads_of(re))
 
 
+# ------------------------------------------------------------------ G3c: PTQ (fp16 / int8 / int16 tables)
+def gen_ptq():
+    import tempfile
+
+    from src.models.embeddings.ptq_emb import PTQEmb_Fp16, PTQEmb_Int
+
+    gen = torch.Generator().manual_seed(37)
+    N, D = 97, 16
+    W = (torch.rand(N, D, generator=gen) - 0.5) * 0.2
+    x = torch.randint(0, N, (9, 4), generator=gen)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "c.pth")
+        torch.save({"state_dict": {"embedding._emb_module.weight": W}}, path)
+        out = {"W": W, "x": x}
+        e = PTQEmb_Fp16(None, None, None, path)
+        out["fp16_weight"] = e.weight.view(torch.int16)      # raw half bits
+        out["fp16_out"] = e(x)
+        for bits in (8, 16):
+            e = PTQEmb_Int(None, None, None, path, n_bits=bits)
+            out[f"int{bits}_weight"] = e.weight
+            out[f"int{bits}_scale"] = e.scale
+            out[f"int{bits}_bias"] = e.bias
+            out[f"int{bits}_out"] = e(x)
+            out[f"int{bits}_full"] = e.get_weight()
+        save("ptq", **out)
+
+
 # ------------------------------------------------------------------ G4: DHE
 def gen_dhe():
     gen = torch.Generator().manual_seed(13)
@@ -377,7 +404,7 @@ def gen_csr_pruned():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

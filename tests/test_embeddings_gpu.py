@@ -376,3 +376,40 @@ def test_pep_vs_oracle_large(ttype, tmp_path):
     assert_close(emb.emb.weight.grad, w.grad, 1e-4, 1e-5, "g weight")
     sc = max(1.0, float(s.grad.abs().max()))
     assert_close(emb.s.grad, s.grad, 1e-3, 1e-4 * sc, "g s")
+
+
+# ------------------------------------------------------------------ PTQ tables (§8f rank 4)
+def test_ptq_matches_reference_golden(tmp_path):
+    from recsys_benchmark_amd.embeddings.ptq_emb import PTQEmb_Fp16, PTQEmb_Int
+
+    g = load_golden("ptq")
+    path = str(tmp_path / "c.pth")
+    torch.save({"state_dict": {"embedding._emb_module.weight": g.t("W")}}, path)
+    x = g.t("x").to(DEV)
+    e = PTQEmb_Fp16(None, None, None, path)
+    assert torch.equal(e.weight.view(torch.int16), g.t("fp16_weight"))
+    assert torch.equal(e.to(DEV)(x).cpu(), g.t("fp16_out")), "fp16 -> fp32 is exact"
+    for bits in (8, 16):
+        e = PTQEmb_Int(None, None, None, path, n_bits=bits)
+        assert torch.equal(e.weight, g.t(f"int{bits}_weight")), "integer codes must be bit-exact"
+        assert torch.equal(e.bias, g.t(f"int{bits}_bias")) and torch.equal(e.scale, g.t(f"int{bits}_scale"))
+        assert_close(e.get_weight(), g.t(f"int{bits}_full"), 0, 0)
+        assert_close(e.to(DEV)(x), g.t(f"int{bits}_out"), 0, 0, f"int{bits} dequantised rows")
+
+
+@pytest.mark.parametrize("n_bits", [16, 8])
+def test_ptq_known_codes(n_bits, tmp_path):      # tests/test_emb.py:529-561 of the reference
+    from recsys_benchmark_amd.embeddings.ptq_emb import PTQEmb_Int
+
+    bias, scale = 0, 0.1
+    q_min, q_max = (-1) * (1 << (n_bits - 1)), (1 << (n_bits - 1)) - 1
+    r_min = (q_min - bias) * scale
+    r_max = scale * (q_max - q_min) + r_min
+    w = torch.tensor([[r_min, 0.11, 0.22, 0.31, 0.66, 0.82, 1.31, r_max]], dtype=torch.float32)
+    codes = torch.tensor([[q_min, 1, 2, 3, 7, 8, 13, q_max]], dtype=torch.int16)
+    path = str(tmp_path / "t.pth")
+    torch.save({"state_dict": {"embedding._emb_module.weight": w}}, path)
+    emb = PTQEmb_Int([1], 8, None, path, n_bits)
+    assert (emb.weight == codes).all()
+    out = emb.to(DEV)(torch.zeros(3, dtype=torch.long, device=DEV))
+    assert out.cpu().isclose((codes * scale).expand(3, 8)).all()
