@@ -1,0 +1,131 @@
+"""GPU, BASELINE.json's full sizes: size-independent properties instead of an oracle run
+(the CPU oracle would take minutes at these sizes).
+
+C2: F=26 Criteo-Kaggle cardinalities, N=33,762,577 rows, D=16, B=4096.
+C5: Yelp2018-shaped graph, N=69,716 nodes, ~2.25 M stored entries, D=64, L=3.
+"""
+import pytest
+import torch
+
+from conftest import assert_close
+
+from recsys_benchmark_amd import _kernels, _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CRITEO = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
+          27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+@pytest.fixture(scope="module")
+def c2():
+    gen = torch.Generator().manual_seed(2023)
+    N, D, B = sum(CRITEO), 16, 4096
+    W = (torch.rand(N, D, device=DEV) - 0.5) * 0.1
+    w1 = torch.randn(N, 1, device=DEV)
+    bias = torch.tensor([0.3], device=DEV)
+    off = torch.tensor([0] + CRITEO[:-1]).cumsum(0).view(1, -1).to(DEV)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in CRITEO], 1).to(DEV)
+    return W, w1, bias, off, x
+
+
+def test_c2_fused_equals_its_parts(c2):
+    """fused gather+FM == plain row gather, then FM over that emb, then the bag over w1 (all library paths,
+    different kernels), and == a float64 evaluation of the FM formula on the gathered rows."""
+    W, w1, bias, off, x = c2
+    emb, yfm = _kernels.gather_fm(x, off, W, w1, bias)
+    rows = x + off
+    emb2 = _kernels.gather_rows(rows, W)
+    assert torch.equal(emb, emb2), "row copies must be bit-identical"
+    assert torch.equal(emb, W[rows]), "and equal to plain indexing of the table"
+    _, yfm2 = _kernels.fm_first_order(emb2, rows, w1, bias)
+    assert_close(yfm, yfm2, 1e-5, 1e-5, "fused vs two-kernel FM")
+    e64 = emb.double()
+    ref = 0.5 * (e64.sum(1).pow(2) - e64.pow(2).sum(1)).sum(1) + w1.double().view(-1)[rows].sum(1) + bias.double()
+    assert_close(yfm.double(), ref, 1e-5, 1e-5, "fp32 kernel vs float64 formula")
+    _lib.check_index_errors()
+
+
+def test_c2_first_order_and_bias_are_linear(c2):
+    W, w1, bias, off, x = c2
+    _, y0 = _kernels.gather_fm(x, off, W, w1, bias)
+    _, y1 = _kernels.gather_fm(x, off, W, 2.0 * w1, bias + 1.0)
+    rows = x + off
+    lin = w1.view(-1)[rows].sum(1)
+    assert_close(y1 - y0, lin + 1.0, 1e-4, 1e-4, "doubling w1 and shifting the bias")
+
+
+def test_c2_backward_forms_agree_and_sum_rule(c2):
+    """row-form (COO) gradient, densified, == dense (atomic) gradient; and sum_f of the FM part of the
+    gradient rows obeys  sum_f g_y (S - e_f) = g_y (F - 1) S."""
+    W, w1, bias, off, x = c2
+    B, F = x.shape
+    gen = torch.Generator().manual_seed(5)
+    g_emb = torch.randn(B, F, 16, generator=gen).to(DEV)
+    g_y = torch.randn(B, generator=gen).to(DEV)
+    grads = {}
+    for sparse in (True, False):
+        Wp = W.detach().requires_grad_(True)
+        w1p = w1.detach().requires_grad_(True)
+        emb, yfm = _kernels.gather_fm(x, off, Wp, w1p, bias, sparse_W=sparse, sparse_w1=sparse)
+        ((emb * g_emb).sum() + (yfm * g_y).sum()).backward()
+        grads[sparse] = (Wp.grad, w1p.grad, emb.detach())
+    gs, g1s, emb = grads[True]
+    gd, g1d, _ = grads[False]
+    assert gs.is_sparse and not gd.is_sparse
+    rows = gs._indices()[0]
+    assert torch.equal(rows, (x + off).view(-1)), "COO indices are idx + offsets, bit-exact"
+    touched = torch.unique(rows)
+    assert_close(gs.coalesce().to_dense()[touched], gd[touched], 1e-4, 1e-5, "rows form vs dense form")
+    assert not bool(gd.index_fill(0, touched, 0.0).any()), "dense form touches only looked-up rows"
+    assert_close(g1s.coalesce().to_dense()[touched], g1d[touched], 1e-4, 1e-5)
+    vals = gs._values().view(B, F, 16)
+    S = emb.sum(1)
+    assert_close((vals - g_emb).sum(1), g_y[:, None] * (F - 1) * S, 1e-3, 1e-4, "sum rule")
+
+
+@pytest.fixture(scope="module")
+def yelp():
+    gen = torch.Generator().manual_seed(2023)
+    U, I, nnz = 31668, 38048, 1128375
+    u = torch.randint(0, U, (nnz,), generator=gen)
+    i = (I * torch.rand(nnz, generator=gen).pow(2)).long().clamp_(max=I - 1)
+    n = U + I
+    idx = torch.stack([torch.cat([u, i + U]), torch.cat([i + U, u])])
+    adj = torch.sparse_coo_tensor(idx, torch.ones(2 * nnz), size=(n, n)).coalesce()
+    deg = torch.sparse.sum(adj, dim=1).to_dense()
+    dm = deg.clamp(min=1).pow(-0.5)
+    ii = adj.indices()
+    A = torch.sparse_coo_tensor(ii, adj.values() * dm[ii[0]] * dm[ii[1]], size=(n, n)).coalesce().to_sparse_csr()
+    return A.to(DEV), deg.to(DEV), U, I
+
+
+def test_c5_fixed_point_of_the_normalised_adjacency(yelp):
+    """A_hat = D^-1/2 A D^-1/2  =>  A_hat (D^1/2 1) = D^1/2 1 on every non-isolated node, so the L-layer
+    mean propagation of v = D^1/2 1 (broadcast over D columns) returns v."""
+    A, deg, U, I = yelp
+    v = deg.sqrt()[:, None].expand(-1, 64).contiguous()
+    out = _kernels.lightgcn_propagate(A, v[:U].contiguous(), v[U:].contiguous(), 3)
+    keep = deg > 0
+    assert_close(out[keep], v[keep], 2e-5, 1e-4, "fixed point")
+    iso = ~keep                                   # isolated nodes: A_hat row empty -> (v + 0 + 0 + 0) / 4
+    if iso.any():
+        assert_close(out[iso], v[iso] / 4, 1e-6, 1e-6)
+
+
+def test_c5_adjointness_and_transposed_backward(yelp):
+    """<A x, y> == <x, A^T y>: the backward kernel path (transposed plan) against the forward one."""
+    A, deg, U, I = yelp
+    gen = torch.Generator().manual_seed(3)
+    n = U + I
+    x = torch.randn(n, 64, generator=gen).to(DEV).requires_grad_(True)
+    y = torch.randn(n, 64, generator=gen).to(DEV)
+    Ax = _kernels.spmm(A, x)
+    (Ax * y).sum().backward()
+    ATy = x.grad
+    lhs = (Ax.detach().double() * y.double()).sum()
+    rhs = (x.detach().double() * ATy.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * max(1.0, abs(float(lhs)))
+    assert_close(ATy, _kernels.spmm(A, y), 1e-4, 1e-5, "symmetric A: A^T y == A y")
+    plan = _kernels.csr_plan(A)
+    assert plan.long_rows.numel() > 0 and plan.pattern_symmetric
