@@ -44,6 +44,10 @@ def main():
             else:
                 cols.append(torch.randint(0, d, (B,), generator=gen))
         x = torch.stack(cols, 1).to(dev)
+        # rotate 8 distinct id batches: re-using one batch keeps its rows Infinity-Cache resident and
+        # flatters the forward by ~35 % (tools/gather_probe.py)
+        xs = [x] + [torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1).to(dev) for _ in range(7)]
+        it = [0]
         emb = torch.empty(B, F, D, device=dev)
         yfm = torch.empty(B, device=dev)
         rows = torch.empty(B, F, dtype=torch.int64, device=dev)
@@ -54,6 +58,8 @@ def main():
         s = _lib.stream_ptr(dev)
 
         def fwd():
+            x = xs[it[0] % len(xs)] if not a.zipf else xs[0]
+            it[0] += 1
             _lib.check(lib.mi_gather_fm_fwd(x.data_ptr(), off.data_ptr(), W.data_ptr(), w1.data_ptr(), bias.data_ptr(),
                                             emb.data_ptr(), yfm.data_ptr(), rows.data_ptr(), B, F, D, N, err.data_ptr(), s))
 
