@@ -228,20 +228,18 @@ class FMFirstOrder(torch.autograd.Function):
 def fm_first_order(emb, rows, w1, bias, sparse_w1=False) -> Tuple[torch.Tensor, torch.Tensor]:
     """(emb, y_fm) for DeepFM when emb came from any IEmbedding (src/models/deepfm.py:91-98)."""
     if emb.dim() != 3 or tuple(rows.shape) != tuple(emb.shape[:2]):
-        # QR 'cat' yields [B,2F,D/2] (reference quirk); the FM terms are defined over that tensor
-        # while the first-order bag still runs over the B x F ids.
         return emb, _fm_first_order_mismatched(emb, rows, w1, bias, sparse_w1)
     return emb, FMFirstOrder.apply(emb, rows, w1, bias, sparse_w1)
 
 
 def _fm_first_order_mismatched(emb, rows, w1, bias, sparse_w1):
+    """QR with operation="cat": emb is [B, 2F, D/2] while the ids are [B, F].  The second-order term runs
+    over emb's own shape (mi_fm_fwd with an all-zero first-order table), the first-order bag over the
+    real ids (a D=1 row gather summed per sample)."""
     B = emb.shape[0]
     zero_rows = torch.zeros((B, emb.shape[1]), dtype=torch.int64, device=emb.device)
-    # second-order part over emb's own [B,F',D'] shape with a zero first-order table ...
     zero_w1 = torch.zeros((1,), dtype=torch.float32, device=emb.device)
     second = FMFirstOrder.apply(emb, zero_rows, zero_w1, None, False)
-    # ... plus the first-order bag over the real ids: a [B,F,1] "embedding" whose FM term is
-    # 0.5*((sum w)^2 - sum w^2); subtract it back out by computing only the linear part.
     lin = GatherRows.apply(rows, w1.view(-1, 1), sparse_w1).sum(dim=(1, 2))
     return second + lin + (bias if bias is not None else 0.0)
 

@@ -18,7 +18,7 @@ and has no distributed code; this is the MI355X-native extension of the same Dee
 Only the local lookup touches the HIP library; the routing (bucketing, splits, permutations,
 collectives) is plain torch so it is covered on CPU by gloo tests with the lookup injected.
 """
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist
