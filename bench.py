@@ -149,7 +149,9 @@ def main():
     # gathers see fresh rows like a real epoch instead of re-reading Infinity-Cache-resident ones.
     ring = [synth_batch(dims, B, 2023 + 7919 * rank + 104729 * i, dev) for i in range(max(1, args.ring))]
     x, y = ring[0][0].clone(), ring[0][1].clone()
-    lossf = torch.nn.BCEWithLogitsLoss()
+    from recsys_benchmark_amd.losses import BCEWithLogitsLoss
+
+    lossf = BCEWithLogitsLoss()      # same criterion as the reference trainer, one launch each way
     state = {"i": 0}
 
     def next_batch():

@@ -53,10 +53,10 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
   if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
-// out[m] = sum_n X[m,n] * v[n] (+ bias[0])
+// out[m] = sum_n X[m,n] * v[n] (+ bias[0]) (+ addend[m])
 __global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, int ldx, const float *__restrict__ v,
-                                                   const float *__restrict__ bias, float *__restrict__ out, int M,
-                                                   int N) {
+                                                   const float *__restrict__ bias, const float *__restrict__ addend,
+                                                   float *__restrict__ out, int M, int N) {
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * kWavesPerBlock;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, 
     float s = 0.f;
     for (int n = lane; n < N; n += kWave) s += X[(int64_t)m * ldx + n] * v[n];
     s = wave_sum(s);
-    if (lane == 0) out[m] = s + (bias ? bias[0] : 0.f);
+    if (lane == 0) out[m] = s + (bias ? bias[0] : 0.f) + (addend ? addend[m] : 0.f);
   }
 }
 
@@ -115,6 +115,35 @@ __global__ __launch_bounds__(kBlock) void k_mix_gate_bwd(const float *__restrict
   }
 }
 
+// mean_i [ max(x,0) - x*y + log1p(exp(-|x|)) ]  (torch's numerically stable binary_cross_entropy_with_logits,
+// reduction="mean"); ONE workgroup so the reduction needs no atomics and no zeroed target.
+__global__ __launch_bounds__(1024) void k_bce_logits_fwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                         float *__restrict__ loss, int64_t n) {
+  __shared__ float part[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float xv = x[i];
+    s += fmaxf(xv, 0.f) - xv * y[i] + log1pf(expf(-fabsf(xv)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    loss[0] = t / (float)n;
+  }
+}
+
+// dx = g[0] * (sigmoid(x) - y) / n
+__global__ __launch_bounds__(kBlock) void k_bce_logits_bwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ g, float *__restrict__ dx,
+                                                           int64_t n) {
+  const float sc = g[0] / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = sc * (1.f / (1.f + expf(-x[i])) - y[i]);
+}
+
 inline int grid_for_elems(int64_t total) {
   int64_t g = (total + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
@@ -149,12 +178,24 @@ int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, f
   return launch_status();
 }
 
-int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias, float *out, int32_t M, int32_t N,
-              void *stream) {
+int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias, const float *addend, float *out,
+              int32_t M, int32_t N, void *stream) {
   if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !v || !out) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, bias, out, M, N);
+  MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, bias, addend, out, M, N);
+  return launch_status();
+}
+
+int mi_bce_logits_fwd(const float *x, const float *y, float *loss, int64_t n, void *stream) {
+  if (n <= 0 || !x || !y || !loss) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("bce_logits_fwd", k_bce_logits_fwd, 1, 1024, stream, x, y, loss, n);
+  return launch_status();
+}
+
+int mi_bce_logits_bwd(const float *x, const float *y, const float *g, float *dx, int64_t n, void *stream) {
+  if (n <= 0 || !x || !y || !g || !dx) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("bce_logits_bwd", k_bce_logits_bwd, grid_for_elems(n), kBlock, stream, x, y, g, dx, n);
   return launch_status();
 }
 

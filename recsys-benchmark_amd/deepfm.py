@@ -91,7 +91,7 @@ class DeepFM(nn.Module):
         """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
         emb, y_fm = self._fm_and_embedding(x)
         b = emb.shape[0]
-        scores = y_fm.unsqueeze(1) + run_tail(self._deep_branch, emb.reshape(b, -1))
+        scores = run_tail(self._deep_branch, emb.reshape(b, -1), last_add=y_fm)   # y_fm + deep(emb)
         return scores.squeeze(-1)
 
     def get_ranks(self, x) -> torch.Tensor:

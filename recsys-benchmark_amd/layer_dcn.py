@@ -148,7 +148,7 @@ class _DCNMixFn(torch.autograd.Function):
             db = torch.zeros((1, d), dtype=torch.float32, device=dev)
             _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), M, d, s), "mi_colsum")
             dgsum = _new((M,), dev)
-            _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), None, dgsum.data_ptr(), M, d, s), "mi_rowdot")
+            _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), None, None, dgsum.data_ptr(), M, d, s), "mi_rowdot")
             dH2g = _new((M, Er), dev)
             gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)                             # dT U^T
             dU = _new((E, r, d), dev)

@@ -67,15 +67,18 @@ class _Linear1Fn(torch.autograd.Function):
     hipBLASLt spent ~40 us per step on it at [4096, 400] (rocprof r01)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, addend):
+        """addend (optional, [M]): added to the output row-wise inside the same kernel (DeepFM's y_fm)."""
         dev = _lib.require_gpu(x, W)
         x = _kernels._f32c(x)
         M, N = x.shape
         out = torch.empty((M, 1), dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().mi_rowdot(x.data_ptr(), N, W.data_ptr(), _lib.ptr(b), out.data_ptr(), M, N,
+        add = None if addend is None else _kernels._f32c(addend)
+        _lib.check(_lib.load().mi_rowdot(x.data_ptr(), N, W.data_ptr(), _lib.ptr(b), _lib.ptr(add), out.data_ptr(), M, N,
                                          _lib.stream_ptr(dev)), "mi_rowdot")
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.add_shape = None if addend is None else tuple(addend.shape)
         return out
 
     @staticmethod
@@ -96,7 +99,8 @@ class _Linear1Fn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             _lib.check(lib.mi_colsum(g.data_ptr(), 1, None, 0, red[N:].data_ptr(), M, 1, s), "mi_colsum")
             db = red[N:]
-        return dx, dW, db
+        dadd = g.view(ctx.add_shape) if (ctx.add_shape is not None and ctx.needs_input_grad[3]) else None
+        return dx, dW, db, dadd
 
 
 class _BNReLUDropFn(torch.autograd.Function):
@@ -172,7 +176,9 @@ def _groups(seq: nn.Sequential) -> List[List]:
     return out
 
 
-def run_tail(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """last_add ([B], optional): added to the tail's [B,1] output inside its last kernel when that layer is a
+    1-output Linear (DeepFM: scores = y_fm + deep(emb)); otherwise added with a plain op."""
     dev = x.device
     seed = _seed_word(dev)
     groups = _groups(seq)
@@ -200,7 +206,10 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
             m = grp[1]
             if isinstance(m, nn.Linear) and m.out_features == 1 and x.dim() == 2:
                 take(1)
-                x = _Linear1Fn.apply(x, m.weight, m.bias)
+                fuse = last_add is not None and k == len(groups) - 1
+                x = _Linear1Fn.apply(x, m.weight, m.bias, last_add if fuse else None)
+                if fuse:
+                    last_add = None
             elif isinstance(m, nn.Linear):
                 x = _LinearFn.apply(x, m.weight, m.bias, take(m.out_features), False)
             else:
@@ -226,4 +235,6 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
             bn is not None, bool(p > 0.0) if bn is None else bool(bn.training),
             bn.momentum if bn is not None else 0.0, bn.eps if bn is not None else 0.0, p, seed, 7919 * (k + 1),
             bump_in_kernel, stats, dgb)
+    if last_add is not None:
+        x = x + last_add.view(-1, *([1] * (x.dim() - 1)))
     return x

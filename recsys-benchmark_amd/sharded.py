@@ -289,8 +289,9 @@ class ShardedDeepFM(nn.Module):
         """emb [B,F,D], lin [B,F] (already exchanged) -> logits [B]: FM + first-order + MLP tail."""
         B = emb.shape[0]
         y_fm = self._fm(emb, lin, self._bias)
-        tail = run_tail if emb.is_cuda else (lambda seq, t: seq(t))   # CPU only in the injected gloo tests
-        return (y_fm.unsqueeze(1) + tail(self._deep_branch, emb.reshape(B, -1))).squeeze(-1)
+        if not emb.is_cuda:                                        # CPU only in the injected gloo tests
+            return (y_fm.unsqueeze(1) + self._deep_branch(emb.reshape(B, -1))).squeeze(-1)
+        return run_tail(self._deep_branch, emb.reshape(B, -1), last_add=y_fm).squeeze(-1)
 
     def enable_graphs(self, batch_size: int):
         """Capture the local compute (forward AND backward) for a fixed batch size as hipGraphs
