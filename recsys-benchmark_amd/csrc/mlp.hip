@@ -27,7 +27,57 @@ __device__ __forceinline__ uint32_t rng32(uint64_t seed, uint64_t idx) {
   return (uint32_t)((z ^ (z >> 31)) >> 16);
 }
 
-// grid (ceil(N/64), RB); block 256 = 64 columns x 4 row lanes
+// Column reductions, vectorised: a thread owns 4 adjacent columns (one float4 per row), a wave covers 256
+// columns = 1 KiB per row and instruction, the 4 waves of a workgroup take 4 different rows; rows are
+// strided over blockIdx.y with 4 rows in flight per thread.  Partial sums meet in LDS, one float atomic per
+// column per workgroup.  (N % 4 == 0 path; otherwise the scalar form below.)
+constexpr int kColTile = 256;
+
+__global__ __launch_bounds__(kBlock) void k_col_stats_v4(const float *__restrict__ Z, int ld, float *__restrict__ s1,
+                                                         float *__restrict__ s2, int M, int N, int64_t *bump) {
+  __shared__ float4 p1[4][64], p2[4][64];
+  if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bump[0] += 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * kColTile + lane * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (n0 < N) {
+    const float4 sh = ld4(Z + n0);
+    const int stride = gridDim.y * 4;
+    int m = blockIdx.y * 4 + w;
+    for (; m + 3 * stride < M; m += 4 * stride) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld4(Z + (int64_t)(m + u * stride) * ld + n0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = v[u].x - sh.x, dy = v[u].y - sh.y, dz = v[u].z - sh.z, dw = v[u].w - sh.w;
+        a.x += dx; a.y += dy; a.z += dz; a.w += dw;
+        b.x += dx * dx; b.y += dy * dy; b.z += dz * dz; b.w += dw * dw;
+      }
+    }
+    for (; m < M; m += stride) {
+      const float4 v = ld4(Z + (int64_t)m * ld + n0);
+      const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
+      a.x += dx; a.y += dy; a.z += dz; a.w += dw;
+      b.x += dx * dx; b.y += dy * dy; b.z += dz * dz; b.w += dw * dw;
+    }
+  }
+  p1[w][lane] = a;
+  p2[w][lane] = b;
+  __syncthreads();
+  // flush: thread t owns column t of the tile, so every atomic wave-instruction is 64 CONTIGUOUS floats
+  {
+    const int t = threadIdx.x, n = blockIdx.x * kColTile + t;
+    if (n < N) {
+      const float *q1 = reinterpret_cast<const float *>(&p1[0][0]);
+      const float *q2 = reinterpret_cast<const float *>(&p2[0][0]);
+      atomicAdd(s1 + n, q1[t] + q1[256 + t] + q1[512 + t] + q1[768 + t]);
+      atomicAdd(s2 + n, q2[t] + q2[256 + t] + q2[512 + t] + q2[768 + t]);
+    }
+  }
+}
+
+// grid (ceil(N/64), RB); block 256 = 64 columns x 4 row lanes   (any N)
 __global__ __launch_bounds__(kBlock) void k_col_stats(const float *__restrict__ Z, int ld, float *__restrict__ s1,
                                                       float *__restrict__ s2, int M, int N, int64_t *bump) {
   __shared__ float p1[4][64], p2[4][64];
@@ -216,6 +266,68 @@ __device__ __forceinline__ float bwd_dyh(const BnBwdArgs &a, int64_t e, int n, f
   return pre > 0.f ? d : 0.f;
 }
 
+__global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
+  __shared__ float4 p1[4][64], p2[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * kColTile + lane * 4;
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+  if (n0 < a.N) {
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f}, g[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.has_bn) {
+      const float4 m4 = ld4(a.save_mean + n0), r4 = ld4(a.save_rstd + n0);
+      mean[0] = m4.x; mean[1] = m4.y; mean[2] = m4.z; mean[3] = m4.w;
+      rstd[0] = r4.x; rstd[1] = r4.y; rstd[2] = r4.z; rstd[3] = r4.w;
+      if (a.gamma) { const float4 t = ld4(a.gamma + n0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
+      if (a.beta) { const float4 t = ld4(a.beta + n0); bt[0] = t.x; bt[1] = t.y; bt[2] = t.z; bt[3] = t.w; }
+    }
+    const float ks = a.keep ? 1.f / (1.f - a.p) : 1.f;
+    const int stride = gridDim.y * 4;
+    float accb[4] = {0.f, 0.f, 0.f, 0.f}, accg[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = blockIdx.y * 4 + w; m < a.M; m += 2 * stride) {
+      float4 z[2], dy[2];
+      uchar4 k4[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int mm = m + u * stride;
+        ok[u] = mm < a.M;
+        const int mr = ok[u] ? mm : m;
+        z[u] = ld4(a.Z + (int64_t)mr * a.ld + n0);
+        dy[u] = ld4(a.dY + (int64_t)mr * a.N + n0);
+        k4[u] = a.keep ? *reinterpret_cast<const uchar4 *>(a.keep + (int64_t)mr * a.N + n0) : make_uchar4(1, 1, 1, 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!ok[u]) continue;
+        const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, dd[4] = {dy[u].x, dy[u].y, dy[u].z, dy[u].w};
+        const unsigned char kk[4] = {k4[u].x, k4[u].y, k4[u].z, k4[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float zh = (zz[j] - mean[j]) * rstd[j];
+          float d = kk[j] ? dd[j] * ks : 0.f;
+          d = (g[j] * zh + bt[j]) > 0.f ? d : 0.f;
+          accb[j] += d;
+          accg[j] += d * zh;
+        }
+      }
+    }
+    sb = make_float4(accb[0], accb[1], accb[2], accb[3]);
+    sg = make_float4(accg[0], accg[1], accg[2], accg[3]);
+  }
+  p1[w][lane] = sb;
+  p2[w][lane] = sg;
+  __syncthreads();
+  {
+    const int t = threadIdx.x, n = blockIdx.x * kColTile + t;
+    if (n < a.N) {
+      const float *q1 = reinterpret_cast<const float *>(&p1[0][0]);
+      const float *q2 = reinterpret_cast<const float *>(&p2[0][0]);
+      atomicAdd(a.dbeta + n, q1[t] + q1[256 + t] + q1[512 + t] + q1[768 + t]);
+      atomicAdd(a.dgamma + n, q2[t] + q2[256 + t] + q2[512 + t] + q2[768 + t]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce(BnBwdArgs a) {
   __shared__ float p1[4][64], p2[4][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -309,6 +421,14 @@ inline int grid_for_elems(int64_t total) {
   if (g > kMaxGrid) g = kMaxGrid;
   return (int)g;
 }
+inline dim3 col_grid_v4(int M, int N) {
+  const int cb = (N + kColTile - 1) / kColTile;
+  int rb = (M + 31) / 32;                  // >= 8 rows per wave
+  const int want = (384 + cb - 1) / cb;    // ~1.5 workgroups per CU: few adders per column
+  if (rb > want) rb = want;
+  if (rb < 1) rb = 1;
+  return dim3(cb, rb);
+}
 inline dim3 col_grid(int M, int N) {
   // enough row-blocks that (column blocks x row blocks) is a few workgroups per CU
   const int cb = (N + 63) / 64;
@@ -340,13 +460,10 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   if (bump_seed && !(has_bn && training)) return MI_ERR_INVALID_ARG;  // only the statistics launch can bump
   if (has_bn && training) {
     int64_t *bump = bump_seed ? seed : nullptr;
-    hipEvent_t ea, eb;
-    if (mi::prof_acquire("bn_col_stats", &ea, &eb))
-      hipExtLaunchKernelGGL(k_col_stats, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, ea, eb, 0, Z, ldz, stats,
-                            stats + N, M, N, bump);
+    if (N % 4 == 0 && ldz % 4 == 0 && aligned16(Z) && aligned16(stats))
+      MI_LAUNCH("bn_col_stats", k_col_stats_v4, col_grid_v4(M, N), kBlock, stream, Z, ldz, stats, stats + N, M, N, bump);
     else
-      hipLaunchKernelGGL(k_col_stats, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, Z, ldz, stats, stats + N,
-                         M, N, bump);
+      MI_LAUNCH("bn_col_stats", k_col_stats, col_grid(M, N), kBlock, stream, Z, ldz, stats, stats + N, M, N, bump);
   }
   BnArgs a;
   a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = has_bn; a.training = training;
@@ -378,11 +495,11 @@ int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t
   a.dgamma = dgamma_dbeta; a.dbeta = dgamma_dbeta ? dgamma_dbeta + N : nullptr;
   a.dZ = dZ;
   if (has_bn) {
-    hipEvent_t ea, eb;
-    if (mi::prof_acquire("bn_bwd_reduce", &ea, &eb))
-      hipExtLaunchKernelGGL(k_bn_bwd_reduce, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, ea, eb, 0, a);
-    else
-      hipLaunchKernelGGL(k_bn_bwd_reduce, col_grid(M, N), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const bool v4r = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dY) && (!keep || ((uintptr_t)keep & 3) == 0) &&
+                     aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta) && (!gamma || aligned16(gamma)) &&
+                     (!beta || aligned16(beta));
+    if (v4r) MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce_v4, col_grid_v4(M, N), kBlock, stream, a);
+    else MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce, col_grid(M, N), kBlock, stream, a);
   }
   const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dZ) && aligned16(dY) &&
                   (!keep || ((uintptr_t)keep & 3) == 0) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
