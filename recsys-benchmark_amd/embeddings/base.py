@@ -45,18 +45,12 @@ class VanillaEmbedding(IEmbedding):
         **kwargs,
     ):
         super().__init__()
-        if isinstance(field_dims, int):
-            field_dims = [field_dims]
-        field_dims = list(field_dims)
-
         assert mode in [None, "sum", "mean", "max"]
+        rows = field_dims if isinstance(field_dims, int) else sum(field_dims)
         self._mode = mode
-
-        if mode is None:
-            self._emb_module = nn.Embedding(sum(field_dims), hidden_size, **kwargs)
-        else:
-            self._emb_module = nn.EmbeddingBag(sum(field_dims), hidden_size, mode=mode, **kwargs)
-
+        # the holder module only owns the parameter (and its `sparse` flag): lookups never call it
+        self._emb_module = (nn.Embedding(rows, hidden_size, **kwargs) if mode is None
+                            else nn.EmbeddingBag(rows, hidden_size, mode=mode, **kwargs))
         if initializer == "xavier":
             nn.init.xavier_uniform_(self._emb_module.weight)
         else:

@@ -30,34 +30,23 @@ class CerpEmbedding(IEmbedding):
         field_name: str = "",
     ):
         super().__init__()
-        if isinstance(field_dims, int):
-            field_dims = [field_dims]
+        dims = [field_dims] if isinstance(field_dims, int) else list(field_dims)
         assert mode in [None, "sum", "mean", "max"]
+        self._field_dims = torch.tensor(dims)
+        self._mode, self.field_name = mode, field_name
+        self._num_item, self._hidden_size, self._bucket_size = sum(dims), hidden_size, bucket_size
+        # a Q row is shared by ceil(N / bucket) consecutive ids; a P row by every bucket-th id
+        self.q_entity_per_row = int(np.ceil(self._num_item / bucket_size))
 
-        num_item = sum(field_dims)
-        self._field_dims = torch.tensor(field_dims)
-        self._mode = mode
-        self.field_name: str = field_name
+        def table():
+            return nn.Parameter(nn.init.xavier_uniform_(torch.zeros(bucket_size, hidden_size)))
 
-        self.p_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
-        self.q_weight = nn.Parameter(torch.zeros(bucket_size, hidden_size))
-        nn.init.xavier_uniform_(self.p_weight)
-        nn.init.xavier_uniform_(self.q_weight)
+        def threshold():
+            return self.init_threshold("element-wise", threshold_init, row_size=bucket_size, col_size=hidden_size,
+                                       threshold_init_method=threshold_init_method)
 
-        self.q_threshold = self.init_threshold(
-            "element-wise", threshold_init, row_size=bucket_size, col_size=hidden_size,
-            threshold_init_method=threshold_init_method,
-        )
-        self.p_threshold = self.init_threshold(
-            "element-wise", threshold_init, row_size=bucket_size, col_size=hidden_size,
-            threshold_init_method=threshold_init_method,
-        )
-
-        self._num_item = num_item
-        self._hidden_size = hidden_size
-        self._bucket_size = bucket_size
-        # Q's avg entities per row = ceil(#entities / bucket size)
-        self.q_entity_per_row = int(np.ceil(self._num_item / self._bucket_size))
+        self.p_weight, self.q_weight = table(), table()
+        self.q_threshold, self.p_threshold = threshold(), threshold()
 
     @staticmethod
     def init_threshold(
@@ -67,39 +56,37 @@ class CerpEmbedding(IEmbedding):
         col_size: int,
         threshold_init_method: str = "all_ones",
     ) -> nn.Parameter:
-        """Same distributions and scaling as the reference (cerp_embedding.py:74-140)."""
-        requires_scaling = True
+        """`init` times a [0,1] pattern: all ones by default (any unknown method name, like the
+        reference's own default string "all-ones"); "uniform" / "normal" / "xavier_uniform" draw a
+        pattern that is squeezed into [0,1] (sigmoid for the global form, per-row min-max for the
+        element-wise form; a plain U(0,1) draw is already in range)."""
+        if threshold_type not in ("global", "element-wise"):
+            raise ValueError("Invalid threshold_type: {}".format(threshold_type))
         if threshold_type == "global":
-            mat = torch.ones(1)
-            if threshold_init_method == "uniform":
-                mat = mat * torch.rand(1)
-                requires_scaling = False
-            elif threshold_init_method == "normal":
-                mat = mat * torch.normal(mean=0.0, std=1.0, size=(1,))
-            elif threshold_init_method == "xavier_uniform":
+            if threshold_init_method == "xavier_uniform":
                 raise NotImplementedError
-            else:
-                requires_scaling = False
-            if requires_scaling:
-                mat = torch.sigmoid(mat)
-            return nn.Parameter(mat * init)
-        elif threshold_type == "element-wise":
-            mat = torch.ones([row_size, col_size])
-            if threshold_init_method == "uniform":
-                mat = mat * torch.nn.init.uniform_(torch.zeros((row_size, col_size)))
-            elif threshold_init_method == "normal":
-                mat = mat * torch.normal(mean=0.0, std=1.0, size=mat.shape)
-            elif threshold_init_method == "xavier_uniform":
-                mat = mat * nn.init.xavier_uniform_(torch.zeros(size=mat.shape))
-            else:
-                requires_scaling = False
-            if requires_scaling:
-                mat_min, _ = mat.min(dim=1, keepdim=True)
-                mat_max, _ = mat.max(dim=1, keepdim=True)
-                mat = (mat - mat_min) / (mat_max - mat_min)
-            assert (0 <= mat).all() and (1 >= mat).all()
-            return nn.Parameter(init * mat)
-        raise ValueError("Invalid threshold_type: {}".format(threshold_type))
+            draws = {"uniform": lambda: torch.rand(1), "normal": lambda: torch.normal(0.0, 1.0, size=(1,))}
+            pattern = torch.ones(1)
+            if threshold_init_method in draws:
+                pattern = pattern * draws[threshold_init_method]()
+                if threshold_init_method == "normal":
+                    pattern = torch.sigmoid(pattern)
+            return nn.Parameter(pattern * init)
+
+        shape = (row_size, col_size)
+        draws = {
+            "uniform": lambda: torch.nn.init.uniform_(torch.zeros(shape)),
+            "normal": lambda: torch.normal(0.0, 1.0, size=shape),
+            "xavier_uniform": lambda: nn.init.xavier_uniform_(torch.zeros(shape)),
+        }
+        pattern = torch.ones(shape)
+        if threshold_init_method in draws:
+            pattern = pattern * draws[threshold_init_method]()
+            lo = pattern.min(dim=1, keepdim=True)[0]
+            hi = pattern.max(dim=1, keepdim=True)[0]
+            pattern = (pattern - lo) / (hi - lo)
+        assert bool(((pattern >= 0) & (pattern <= 1)).all())
+        return nn.Parameter(init * pattern)
 
     def apply_pruning(self):
         """Materialised pruned tables, for the bookkeeping helpers only (the lookup fuses this)."""

@@ -66,17 +66,14 @@ class PepEmbeeding(IEmbedding):   # (sic: the reference's class name)
         return _kernels.bag_reduce(rows, self._mode)
 
     def init_threshold(self, init, num_item, hidden_size) -> nn.Parameter:
-        if self.threshold_type == "global":
-            return nn.Parameter(init * torch.ones(1))
-        elif self.threshold_type == "dimension":
-            return nn.Parameter(init * torch.ones([hidden_size]))
-        elif self.threshold_type == "feature":
-            return nn.Parameter(init * torch.ones([num_item, 1]))
-        elif self.threshold_type in ("field", "field_dim"):
+        """One threshold logit per (global | dimension | feature | feature x dimension)."""
+        shapes = {"global": (1,), "dimension": (hidden_size,), "feature": (num_item, 1),
+                  "feature_dim": (num_item, hidden_size)}
+        if self.threshold_type in ("field", "field_dim"):
             raise NotImplementedError()
-        elif self.threshold_type == "feature_dim":
-            return nn.Parameter(init * torch.ones([num_item, hidden_size]))
-        raise ValueError("Invalid threshold_type: {}".format(self.threshold_type))
+        if self.threshold_type not in shapes:
+            raise ValueError("Invalid threshold_type: {}".format(self.threshold_type))
+        return nn.Parameter(torch.full(shapes[self.threshold_type], float(init)))
 
     def get_sparsity(self, get_n_params=False):
         total_params = self.emb.weight.numel()

@@ -1,14 +1,14 @@
 """QR (quotient-remainder) hashed embedding — reference: src/models/embeddings/qr_embedding.py:10-113.
 
-Same constructor, `emb1` / `emb2` parameter holders (state_dict keys `emb1.weight`,
-`emb2.weight`), initialisers and quirks:
-  * `emb1` has `divider` rows and is indexed by the REMAINDER, `emb2` has
-    (N-1)//divider+1 rows and is indexed by the QUOTIENT (the naming is inverted
-    relative to the paper; `divider: 2` means a 2-row emb1);
-  * `operation="cat"` concatenates along dim=1, so a [B,F] input gives [B,2F,D/2].
-The lookup, the `%` / `//` index math and the combine run in one HIP kernel
-(mi_dual_gather_fwd); get_weight() is that kernel over arange(N), differentiable.
+Drop-in: same constructor arguments, parameter holders `emb1` / `emb2` (state_dict keys
+`emb1.weight`, `emb2.weight`), initial distributions and quirks —
+  * `emb1` has `divider` rows and is addressed by the REMAINDER, `emb2` has (N-1)//divider+1 rows
+    and is addressed by the QUOTIENT (names inverted w.r.t. the paper: `divider: 2` = a 2-row emb1);
+  * operation "cat" concatenates along dim=1, so [B,F] ids give [B,2F,D/2].
+Index math, both row gathers and the combine are one HIP kernel (mi_dual_gather_fwd);
+get_weight() is that kernel over arange(N) and stays differentiable.
 """
+import functools
 import math
 from typing import List, Literal, Optional, Union
 
@@ -17,6 +17,14 @@ from torch import nn
 
 from .. import _kernels
 from .base import IEmbedding
+
+_COMBINE = ("cat", "add", "mult")
+
+
+def table_rows(num_item: int, divider: Optional[int]):
+    """(divider, rows of emb1, rows of emb2); divider defaults to floor(sqrt(N))."""
+    d = int(math.sqrt(num_item)) if divider is None else divider
+    return d, d, (num_item - 1) // d + 1
 
 
 class QRHashingEmbedding(IEmbedding):
@@ -30,71 +38,45 @@ class QRHashingEmbedding(IEmbedding):
         initializer="uniform",
     ):
         super().__init__()
-        assert operation in ["cat", "add", "mult"]
-        if operation == "cat":
-            assert hidden_size % 2 == 0
+        assert operation in _COMBINE
+        assert operation != "cat" or hidden_size % 2 == 0
+        self._operation, self._mode, self._hidden_size = operation, mode, hidden_size
+        self._num_item = field_dims if isinstance(field_dims, int) else sum(field_dims)
+        self._divider, rows1, rows2 = table_rows(self._num_item, divider)
 
-        if isinstance(field_dims, int):
-            field_dims = [field_dims]
+        width = hidden_size // 2 if operation == "cat" else hidden_size
+        make = nn.Embedding if mode is None else functools.partial(nn.EmbeddingBag, mode=mode)
+        self.emb1, self.emb2 = make(rows1, width), make(rows2, width)
 
-        num_item = sum(field_dims)
-        if divider is None:
-            divider = int(math.sqrt(num_item))
+        init = {"normal": self._init_normal_weight, "uniform": self._init_uniform_weight}.get(initializer)
+        if init is not None:
+            init()
 
-        emb_size = hidden_size
-        if operation == "cat":
-            emb_size = hidden_size // 2
-
-        self._operation = operation
-        size = (num_item - 1) // divider + 1
-
-        if mode is None:
-            self.emb1 = nn.Embedding(divider, emb_size)
-            self.emb2 = nn.Embedding(size, emb_size)
-        else:
-            self.emb1 = nn.EmbeddingBag(divider, emb_size, mode=mode)
-            self.emb2 = nn.EmbeddingBag(size, emb_size, mode=mode)
-        self._mode = mode
-
-        self._hidden_size = hidden_size
-        self._divider = divider
-        self._num_item = num_item
-
-        if initializer == "normal":
-            self._init_normal_weight()
-        elif initializer == "uniform":
-            self._init_uniform_weight()
+    def _tables(self):
+        return self.emb1.weight, self.emb2.weight
 
     def _init_uniform_weight(self):
-        alpha = math.sqrt(1 / self._num_item)
-        nn.init.uniform_(self.emb1.weight, alpha, 1)
-        nn.init.uniform_(self.emb2.weight, alpha, 1)
+        # U(sqrt(1/N), 1) on both tables (the DLRM QR trick's range: a product is never ~0*0)
+        low = math.sqrt(1 / self._num_item)
+        for w in self._tables():
+            nn.init.uniform_(w, low, 1)
 
     def _init_normal_weight(self):
-        std = 0.1
-        if self._operation == "add":
-            std = std / 2
-        elif self._operation == "mult":
-            std = math.sqrt(std)
-        nn.init.normal_(self.emb1.weight, std=std)
-        nn.init.normal_(self.emb2.weight, std=std)
+        std = {"add": 0.1 / 2, "mult": math.sqrt(0.1)}.get(self._operation, 0.1)
+        for w in self._tables():
+            nn.init.normal_(w, std=std)
 
     def forward(self, tensor: torch.Tensor):
+        w1, w2 = self._tables()
+        d = self._divider
         if self._mode is None:
-            return _kernels.dual_gather(tensor, self.emb1.weight, self.emb2.weight,
-                                        mod1=self._divider, div2=self._divider, op=self._operation)
-        # bag modes reduce each table's rows BEFORE the combine (two EmbeddingBags in the
-        # reference, qr_embedding.py:60-63,98-99): two row gathers, then the small combine.
-        inp1 = tensor % self._divider
-        inp2 = tensor // self._divider
-        emb1 = _kernels.bag_reduce(_kernels.gather_rows(inp1, self.emb1.weight), self._mode)
-        emb2 = _kernels.bag_reduce(_kernels.gather_rows(inp2, self.emb2.weight), self._mode)
-        if self._operation == "cat":
-            return torch.cat([emb1, emb2], dim=1)
-        elif self._operation == "add":
-            return emb1 + emb2
-        return emb1 * emb2
+            return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation)
+        # EmbeddingBag modes reduce each table's rows BEFORE the combine (two bags in the reference)
+        bag1 = _kernels.bag_reduce(_kernels.gather_rows(tensor % d, w1), self._mode)
+        bag2 = _kernels.bag_reduce(_kernels.gather_rows(tensor // d, w2), self._mode)
+        if self._operation == "mult":
+            return bag1 * bag2
+        return bag1 + bag2 if self._operation == "add" else torch.cat([bag1, bag2], dim=1)
 
     def get_weight(self):
-        arr = torch.arange(self._num_item, device=self.emb1.weight.device)
-        return self(arr)
+        return self(torch.arange(self._num_item, device=self.emb1.weight.device))
