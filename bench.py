@@ -236,8 +236,8 @@ def main():
         ks = kt.summary()
         fb, bb = alg_bytes_per_sample(F, D)
         alg = {"gather_fm_fwd": fb * B, "gather_fm_bwd_rows": bb * B, "gather_fm_bwd_dense": bb * B}
-        if sharded:  # emb arrives by all-to-all: FM runs over it, its backward has no MLP-grad input
-            alg = {"fm_fwd": (4 * F * D + 12 * F + 4) * B, "gather_fm_bwd_rows": (8 * F * D + 4 * F + 4) * B}
+        if sharded:  # same kernels over the exchanged packed rows, addressed by slot: same bytes per sample
+            alg = {"slot_fm_fwd": fb * B, "slot_fm_bwd": bb * B}
         kernels = {}
         for k, s in ks.items():
             e = {"avg_us": round(s["avg_us"], 3), "min_us": round(s["min_us"], 3), "launches": s["count"]}

@@ -304,6 +304,37 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 
+/* ---- §8e: device-side routing of the row-sharded DeepFM lookup -------------------------------
+ * No reference counterpart (the reference keeps one table on one device,
+ * src/models/embeddings/base.py:52-57); the arithmetic either side of the exchange is the
+ * reference's (src/models/deepfm.py:88-98).  Tables are sharded owner = row % world,
+ * local = row / world; every shard ends in one extra SINK row that padding slots point at.
+ *
+ * mi_route_buckets: rows = idx + offsets[i % F] (offsets may be NULL) for n = B*F lookups; STABLE
+ *   bucketing by owner into send_rows[world, cap] (owner-local row ids; unused slots = the owner's
+ *   sink row ceil((N - owner) / world)), slot[n] = owner*cap + position of every lookup.  Lookups
+ *   that overflow a bucket or are outside [0, N) get slot = world*cap (the dump slot) and OR 1 into
+ *   *overflow / MI_IDX_OUT_OF_RANGE into *err.  workspace: mi_route_workspace_elems(n, world) int32.
+ * mi_gather_pack_rows: out[i, 0:D] = W[rows[i], :], out[i, D] = w1[rows[i]], out[i, D+1:D+4] = 0;
+ *   out rows are D + 4 floats (one all-to-all carries both tables).  D = 4 * 2^k only.
+ * mi_slot_fm_fwd: mi_gather_fm_fwd over the received packed rows buf[nrows, D+4] addressed by slot
+ *   (row nrows-1 = the zeroed dump row): emb[B,F,D], yfm[B].
+ * mi_slot_fm_bwd: zero gbuf[nslot, D+4], then the row gradients of mi_gather_fm_bwd_rows written to
+ *   gbuf[slot[b,f]] (first-order gradient in column D); slots >= nslot are skipped.               */
+MI_API int64_t mi_route_workspace_elems(int64_t n, int32_t world);
+MI_API int mi_route_buckets(const int64_t *idx, const int64_t *offsets, int64_t n, int32_t F,
+                            int32_t world, int64_t N, int64_t cap, int32_t *workspace,
+                            int64_t *send_rows, int64_t *slot, int32_t *overflow, int32_t *err,
+                            void *stream);
+MI_API int mi_gather_pack_rows(const int64_t *rows, const float *W, const float *w1, float *out,
+                               int64_t m, int32_t D, int64_t Nl, int32_t *err, void *stream);
+MI_API int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const float *bias,
+                          float *emb_out, float *yfm_out, int64_t B, int32_t F, int32_t D,
+                          int32_t *err, void *stream);
+MI_API int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y,
+                          const float *g_emb, float *gbuf, int64_t nslot, int64_t B, int32_t F,
+                          int32_t D, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

@@ -692,3 +692,104 @@ def gather_rows_quant(idx, W, scale=None, bias=None):
         "mi_gather_rows_quant",
     )
     return out
+
+
+# ---- row-sharded lookup: device-side routing (csrc/route.hip) -----------------
+def route_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], world: int, num_rows: int, cap: int,
+                  overflow: torch.Tensor, slot_out: Optional[torch.Tensor] = None):
+    """Stable bucketing of rows = idx + offsets by owner = row % world.
+
+    Returns (send_rows int64[world*cap] of owner-local rows, slot int64[idx.shape]); `overflow`
+    is an int32[1] device word that gets 1 OR-ed in when a bucket exceeds `cap`."""
+    dev = _lib.require_gpu(idx, offsets, overflow)
+    lib = _lib.load()
+    idxc = _i64c(idx)
+    if overflow.dtype != torch.int32:
+        raise TypeError("overflow must be an int32 device word")
+    F = idxc.shape[-1] if idxc.dim() > 1 else 1
+    off = None if offsets is None else _i64c(offsets.reshape(-1))
+    if off is not None and off.numel() != F:
+        raise ValueError(f"offsets must have {F} entries")
+    n = idxc.numel()
+    ws = torch.empty(int(lib.mi_route_workspace_elems(n, world)), dtype=torch.int32, device=dev)
+    send_rows = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    slot = slot_out if slot_out is not None else torch.empty(idxc.shape, dtype=torch.int64, device=dev)
+    if slot.numel() != n or slot.dtype != torch.int64 or not slot.is_contiguous():
+        raise ValueError("slot_out must be a contiguous int64 tensor with one entry per lookup")
+    _lib.check(
+        lib.mi_route_buckets(idxc.data_ptr(), _lib.ptr(off), n, F, world, num_rows, cap, ws.data_ptr(),
+                             send_rows.data_ptr(), slot.data_ptr(), overflow.data_ptr(),
+                             _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+        "mi_route_buckets",
+    )
+    return send_rows, slot
+
+
+def gather_pack_rows(local_rows: torch.Tensor, W: torch.Tensor, w1: torch.Tensor) -> torch.Tensor:
+    """[m, D+4] packed rows (W[r,:], w1[r], 0, 0, 0) for the owner-local rows r."""
+    dev = _lib.require_gpu(local_rows, W, w1)
+    lib = _lib.load()
+    rows = _i64c(local_rows.reshape(-1))
+    Wc, w1c = _f32c(W), _f32c(w1)
+    Nl, D = Wc.shape
+    if w1c.numel() != Nl:
+        raise ValueError("first-order shard must have one weight per embedding row")
+    out = torch.empty((rows.numel(), D + 4), dtype=torch.float32, device=dev)
+    _lib.check(
+        lib.mi_gather_pack_rows(rows.data_ptr(), Wc.data_ptr(), w1c.data_ptr(), out.data_ptr(), rows.numel(), D,
+                                Nl, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+        "mi_gather_pack_rows",
+    )
+    return out
+
+
+class SlotFM(torch.autograd.Function):
+    """(emb[B,F,D], y_fm[B]) from the packed rows a sharded lookup received, addressed by slot
+    (src/models/deepfm.py:88-98 on exchanged rows).  buf is [S+1, D+4] with row S all zeros (the
+    dump slot); the gradient w.r.t. buf comes back in the same layout, ready for the all-to-all."""
+
+    @staticmethod
+    def forward(ctx, buf, slot, bias):
+        dev = _lib.require_gpu(buf, slot, bias)
+        lib = _lib.load()
+        buf = _f32c(buf)
+        slot = _i64c(slot)
+        B, F = slot.shape
+        D = buf.shape[1] - 4
+        emb = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        yfm = torch.empty((B,), dtype=torch.float32, device=dev)
+        _lib.check(
+            lib.mi_slot_fm_fwd(slot.data_ptr(), buf.data_ptr(), buf.shape[0], _lib.ptr(bias), emb.data_ptr(),
+                               yfm.data_ptr(), B, F, D, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+            "mi_slot_fm_fwd",
+        )
+        ctx.save_for_backward(emb, slot)
+        ctx.meta = (B, F, D, buf.shape[0], bias is not None)
+        ctx.set_materialize_grads(False)
+        return emb, yfm
+
+    @staticmethod
+    def backward(ctx, g_emb, g_y):
+        emb, slot = ctx.saved_tensors
+        B, F, D, rows, has_bias = ctx.meta
+        dev = emb.device
+        lib = _lib.load()
+        if g_y is None:
+            g_y = torch.zeros((B,), dtype=torch.float32, device=dev)
+        g_y = _f32c(g_y)
+        g_emb = None if g_emb is None else _f32c(g_emb)
+        gbuf = None
+        if ctx.needs_input_grad[0]:
+            gbuf = torch.empty((rows, D + 4), dtype=torch.float32, device=dev)
+            # the kernel zeroes rows [0, S) itself; the dump row's gradient is never read
+            _lib.check(
+                lib.mi_slot_fm_bwd(slot.data_ptr(), emb.data_ptr(), g_y.data_ptr(), _lib.ptr(g_emb),
+                                   gbuf.data_ptr(), rows - 1, B, F, D, _lib.stream_ptr(dev)),
+                "mi_slot_fm_bwd",
+            )
+        gb = g_y.sum().view(1) if (has_bias and ctx.needs_input_grad[2]) else None
+        return gbuf, None, gb
+
+
+def slot_fm(buf, slot, bias):
+    return SlotFM.apply(buf, slot, bias)

@@ -56,11 +56,16 @@ SIGNATURES = {
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, _p],
     "mi_scatter_axpy_rows": [_p, _p, ctypes.c_float, _p, _i64, _i32, _i64, _p],
+    "mi_route_workspace_elems": [_i64, _i32],
+    "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
+    "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
+    "mi_slot_fm_fwd": [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p],
+    "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
     "mi_prof_enable": [_i32],
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
-_RESTYPES = {"mi_strerror": ctypes.c_char_p}
+_RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
     const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
-    int64_t B, int F, int64_t N, int *err) {
+    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err) {
+  // ldw / ldw1: floats between consecutive rows of W / w1 (D and 1 for the reference's tables;
+  // D + 4 for both when they are the packed rows a sharded lookup received, see route.hip)
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63;
@@ -51,14 +53,14 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
       for (int k = 0; k < NIT; ++k) {
         const int f = r + k * RS;
         act[k] = f < F;
-        row[k] = act[k] ? idx[base + f] + offsets[f] : 0;
+        row[k] = act[k] ? idx[base + f] + (offsets ? offsets[f] : 0) : 0;
       }
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         ok[k] = act[k] && (uint64_t)row[k] < (uint64_t)N;
         bad |= (act[k] && !ok[k]);
-        v[k] = ok[k] ? ld4(W + row[k] * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        l[k] = (ok[k] && q == 0) ? w1[row[k]] : 0.f;
+        v[k] = ok[k] ? ld4(W + row[k] * ldw + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        l[k] = (ok[k] && q == 0) ? w1[row[k] * ldw1] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
@@ -73,11 +75,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
       }
     } else {
       for (int f = r; f < F; f += RS) {
-        const int64_t row = idx[base + f] + offsets[f];
+        const int64_t row = idx[base + f] + (offsets ? offsets[f] : 0);
         const bool ok = (uint64_t)row < (uint64_t)N;
         bad |= !ok;
-        const float4 v = ok ? ld4(W + row * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && q == 0) lin += w1[row];
+        const float4 v = ok ? ld4(W + row * ldw + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && q == 0) lin += w1[row * ldw1];
         st4(emb + (base + f) * D + q * 4, v);
         if (rows_out && q == 0) rows_out[base + f] = row;
         S.x += v.x; S.y += v.y; S.z += v.z; S.w += v.w;
@@ -133,11 +135,14 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
 }
 
 // ----------------------------------------------------- backward, row form ----
-template <int LPR, int NIT>
+// SLOT = false: gvals[b,f,:] / g1vals[b,f] in lookup order (the reference's COO values).
+// SLOT = true : the row goes to gvals + slot[b,f]*(D+4), its first-order gradient into column D of
+//               the same packed row; slots >= nslot (the dump slot of route.hip) are skipped.
+template <int LPR, int NIT, bool SLOT>
 __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
     const float *__restrict__ emb, const float *__restrict__ g_y,
     const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
-    int64_t B, int F) {
+    int64_t B, int F, const int64_t *__restrict__ slot, int64_t nslot) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63;
@@ -174,8 +179,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
           o4.y = ge[k].y + gy * (S.y - e[k].y);
           o4.z = ge[k].z + gy * (S.z - e[k].z);
           o4.w = ge[k].w + gy * (S.w - e[k].w);
-          st4(gvals + (base + f) * D + q * 4, o4);
-          if (q == 0) g1vals[base + f] = gy;
+          if constexpr (SLOT) {
+            const int64_t s = slot[base + f];
+            if ((uint64_t)s < (uint64_t)nslot) {
+              st4(gvals + s * (D + 4) + q * 4, o4);
+              if (q == 0) st4(gvals + s * (D + 4) + D, make_float4(gy, 0.f, 0.f, 0.f));
+            }
+          } else {
+            st4(gvals + (base + f) * D + q * 4, o4);
+            if (q == 0) g1vals[base + f] = gy;
+          }
         }
       }
     } else {
@@ -193,8 +206,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
         o4.y = ge.y + gy * (S.y - e.y);
         o4.z = ge.z + gy * (S.z - e.z);
         o4.w = ge.w + gy * (S.w - e.w);
-        st4(gvals + o, o4);
-        if (q == 0) g1vals[base + f] = gy;
+        if constexpr (SLOT) {
+          const int64_t s = slot[base + f];
+          if ((uint64_t)s < (uint64_t)nslot) {
+            st4(gvals + s * (D + 4) + q * 4, o4);
+            if (q == 0) st4(gvals + s * (D + 4) + D, make_float4(gy, 0.f, 0.f, 0.f));
+          }
+        } else {
+          st4(gvals + o, o4);
+          if (q == 0) g1vals[base + f] = gy;
+        }
       }
     }
   }
@@ -479,7 +500,7 @@ int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W,
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                       \
   MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT>), grid, kBlock, stream, idx, offsets, \
-            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, err)
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, (int64_t)D, (int64_t)1, err)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   } else {
@@ -498,8 +519,8 @@ int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb
   if (vec_ok(D) && aligned16(emb) && aligned16(gvals) && (!g_emb || aligned16(g_emb))) {
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                      \
-  MI_LAUNCH("gather_fm_bwd_rows", (k_gather_fm_bwd_rows<LPR, NIT>), grid, kBlock, stream, emb, \
-            g_y, g_emb, gvals, g1vals, B, F)
+  MI_LAUNCH("gather_fm_bwd_rows", (k_gather_fm_bwd_rows<LPR, NIT, false>), grid, kBlock, stream, \
+            emb, g_y, g_emb, gvals, g1vals, B, F, (const int64_t *)nullptr, (int64_t)0)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   } else {
@@ -567,6 +588,48 @@ int mi_scatter_add_rows(const int64_t *idx, const float *g, float *gW, int64_t n
     MI_LAUNCH("scatter_add_rows", k_scatter_add_rows_anyD,
               grid_for_waves(((int64_t)n * D + kWave - 1) / kWave), kBlock, stream, idx, g, gW, n, D, N);
   }
+  return launch_status();
+}
+
+// ---- the same two kernels over the packed rows a sharded lookup received (route.hip) ----
+int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const float *bias,
+                   float *emb_out, float *yfm_out, int64_t B, int32_t F, int32_t D, int32_t *err,
+                   void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || nrows < 0) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!slot || !buf || !emb_out || !yfm_out) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(D) || !aligned16(buf) || !aligned16(emb_out)) return MI_ERR_UNSUPPORTED;
+  const int grid = grid_for_waves(B);
+  const int lpr = D / 4, nit = nit_for(F, lpr);
+  const int64_t ld = D + 4;
+#define CALL(LPR, NIT)                                                                        \
+  MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT>), grid, kBlock, stream, slot,           \
+            (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr, \
+            B, F, nrows, ld, ld, err)
+  MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+  return launch_status();
+}
+
+int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y, const float *g_emb,
+                   float *gbuf, int64_t nslot, int64_t B, int32_t F, int32_t D, void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || nslot < 0) return MI_ERR_INVALID_ARG;
+  if (nslot > 0 && !gbuf) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(D) || !aligned16(gbuf) || (emb && !aligned16(emb)) || (g_emb && !aligned16(g_emb)))
+    return MI_ERR_UNSUPPORTED;
+  // padding slots must read as zero gradients at the owner
+  if (nslot > 0 &&
+      hipMemsetAsync(gbuf, 0, (size_t)nslot * (D + 4) * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return MI_ERR_LAUNCH;
+  if (B == 0) return MI_OK;
+  if (!slot || !emb || !g_y) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  const int lpr = D / 4, nit = nit_for(F, lpr);
+#define CALL(LPR, NIT)                                                                         \
+  MI_LAUNCH("slot_fm_bwd", (k_gather_fm_bwd_rows<LPR, NIT, true>), grid, kBlock, stream, emb,  \
+            g_y, g_emb, gbuf, (float *)nullptr, B, F, slot, nslot)
+  MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
   return launch_status();
 }
 

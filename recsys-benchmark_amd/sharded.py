@@ -1,24 +1,37 @@
 """Row-sharded embedding tables across the GPUs of one node (BASELINE config 4).
 
 The reference keeps ONE concatenated table on one device (src/models/embeddings/base.py:52-57)
-and has no distributed code; this is the MI355X-native extension of the same DeepFM path:
+and has no distributed code; this is the MI355X-native extension of the same DeepFM path
+(src/models/deepfm.py:88-102):
 
   * one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI);
   * the concatenated [N, D] table and the [N] first-order table are sharded by
     `owner = row % world`, `local_row = row // world`: every field's ids — hot Zipf heads
-    included — spread evenly, so lookups per rank balance without knowing the field sizes;
-  * data-parallel batch: each rank owns B samples.  Forward = all-to-all #1 (row ids to their
-    owners) -> local HIP row gather -> all-to-all #2 (rows + first-order weights back) -> the
-    fused FM / first-order kernel and the MLP on the sample's owner.  Backward mirrors it:
-    one all-to-all of gradient rows, which land as row-form (COO) gradients of the local shards.
-    xGMI is a point-to-point mesh: all-to-all is one direct hop per peer pair, no ring.
-  * the dense tail (MLP, bias) is replicated; its gradients are averaged with ONE flat
-    all-reduce (~2 MB, latency-bound).
+    included — spread evenly, so lookups per rank balance without knowing the field sizes.
+    Every shard ends in one extra SINK row (zero, zero gradients) that padding slots address;
+  * data-parallel batch: each rank owns B samples.  A step is
 
-Only the local lookup touches the HIP library; the routing (bucketing, splits, permutations,
-collectives) is plain torch so it is covered on CPU by gloo tests with the lookup injected.
+        route (HIP)        rows = x + offsets, stable bucketing by owner into [world, cap] slots
+        all-to-all #1      owner-local row ids                       (8 B per slot)
+        pack  (HIP)        W[row] and w1[row] into rows of D+4 floats
+        all-to-all #2      packed rows back to the requesters        (4(D+4) B per slot)
+        slot gather + FM + first-order (one HIP kernel) + the MLP tail, data-parallel
+        -- backward --
+        FM/gather backward writes gradient rows straight into the outgoing [world*cap, D+4] buffer
+        all-to-all #3      gradient rows to the owners -> row-form (COO) gradients of the shards
+        ONE flat all-reduce of the replicated tail's gradients (~2 MB)
+
+    xGMI is a point-to-point mesh: an all-to-all is one direct hop per peer pair, no ring.
+  * static shapes: every rank sends exactly `cap` slots to every peer, so there is no host sync
+    and the compute between the collectives replays as hipGraphs (`enable_graphs`).  A bucket that
+    overflows (pathological skew) drops the excess lookups to zeros and raises the sticky flag
+    `check_overflow()` reports; `bucket_slack=world` makes overflow impossible (cap = n).
+
+The three device steps come from `ops` (default: the HIP library).  The world-size-2 gloo tests
+run on CPU, where the library cannot, and inject torch restatements of the same three steps so
+that the choreography — splits, buffer layouts, gradient averaging — is what they exercise.
 """
-from typing import Callable, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -28,160 +41,71 @@ from . import _kernels
 from .mlp import run_tail
 
 
-def _hip_gather(W: torch.Tensor, local_rows: torch.Tensor) -> torch.Tensor:
-    return _kernels.gather_rows(local_rows, W)
+class HipOps:
+    """The product's device steps (csrc/route.hip, csrc/gather_fm.hip, csrc/mlp.hip)."""
 
-
-class _Route:
-    """Bucket n global row ids by owner and remember how to undo it."""
-
-    def __init__(self, rows: torch.Tensor, world: int, group):
-        flat = rows.reshape(-1)
-        owner = flat % world
-        # stable sort by owner keeps the (sample, field) order inside each bucket
-        self.perm = torch.argsort(owner, stable=True)
-        self.send_rows = (flat // world)[self.perm].contiguous()      # owner-local row ids
-        send_counts = torch.bincount(owner, minlength=world)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=group)
-        # split sizes must be host ints for all_to_all_single: one small sync per step
-        both = torch.stack([send_counts, recv_counts]).tolist()
-        self.send_splits: List[int] = both[0]
-        self.recv_splits: List[int] = both[1]
-        self.n_send = flat.numel()
-        self.n_recv = sum(self.recv_splits)
-        self.group = group
-
-    def to_owner(self, t: torch.Tensor) -> torch.Tensor:
-        """t is [n_send, ...] in bucket order -> [n_recv, ...] on the owners."""
-        out = t.new_empty((self.n_recv,) + tuple(t.shape[1:]))
-        dist.all_to_all_single(out, t.contiguous(), self.recv_splits, self.send_splits, group=self.group)
-        return out
-
-    def to_requester(self, t: torch.Tensor) -> torch.Tensor:
-        """t is [n_recv, ...] on the owners -> [n_send, ...] in bucket order at the requesters."""
-        out = t.new_empty((self.n_send,) + tuple(t.shape[1:]))
-        dist.all_to_all_single(out, t.contiguous(), self.send_splits, self.recv_splits, group=self.group)
-        return out
-
-    def unpermute(self, t: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(t)
-        out[self.perm] = t
-        return out
-
-
-class _FixedRoute:
-    """Static-shape routing: every rank sends exactly `cap` slots to every peer (padding slots carry
-    local row 0 forward and zero gradients backward), so there is no host sync, no data-dependent
-    shape, and the whole step can be captured in a hipGraph.  `cap` = ceil(n/world) * slack + 6 sigma;
-    a bucket that still overflows (pathological skew) drops the excess lookups to zeros and raises
-    the sticky `overflow` flag that `ShardedDeepFM.check_overflow()` turns into an error."""
-
-    def __init__(self, rows: torch.Tensor, world: int, group, slack: float, overflow: torch.Tensor):
-        flat = rows.reshape(-1)
-        n = flat.numel()
-        mean = -(-n // world)
-        cap = n if world == 1 else min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
-        self.cap, self.world, self.group, self.n = cap, world, group, n
-        owner = flat % world
-        order = torch.argsort(owner, stable=True)
-        owner_sorted = owner[order]
-        # (torch.bincount reads its max back to the host: not capturable)
-        counts = (owner.unsqueeze(1) == torch.arange(world, device=flat.device).unsqueeze(0)).sum(0)
-        starts = torch.cumsum(counts, 0) - counts
-        pos = torch.arange(n, device=flat.device) - starts[owner_sorted]
-        fits = pos < cap
-        overflow.logical_or_((~fits).any().view(1))
-        dump = world * cap                               # one extra slot swallows the overflow
-        slot_sorted = torch.where(fits, owner_sorted * cap + pos, torch.full_like(pos, dump))
-        # slot of every ORIGINAL lookup position (dump for dropped ones)
-        self.slot = torch.empty_like(slot_sorted)
-        self.slot[order] = slot_sorted
-        send = torch.zeros(world * cap + 1, dtype=flat.dtype, device=flat.device)
-        send[self.slot] = flat // world
-        self.send_rows = send[:-1]
-
-    def exchange(self, t: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(t)
-        dist.all_to_all_single(out, t.contiguous(), group=self.group)
-        return out
-
-    def scatter_to_slots(self, t: torch.Tensor) -> torch.Tensor:
-        """[n, ...] in lookup order -> [world*cap, ...] send buffer (zeros in padding slots)."""
-        buf = t.new_zeros((self.world * self.cap + 1,) + tuple(t.shape[1:]))
-        buf[self.slot] = t
-        return buf[:-1]
-
-    def gather_from_slots(self, buf: torch.Tensor) -> torch.Tensor:
-        """[world*cap, ...] returned buffer -> [n, ...] in lookup order (zeros for dropped lookups)."""
-        ext = torch.cat([buf, buf.new_zeros((1,) + tuple(buf.shape[1:]))])
-        return ext[self.slot]
-
-
-class ShardedLookupFixed(torch.autograd.Function):
-    """Same contract as ShardedLookup with the static-shape routing (the default on GPUs)."""
+    route_buckets = staticmethod(_kernels.route_buckets)
+    gather_pack_rows = staticmethod(_kernels.gather_pack_rows)
+    slot_fm = staticmethod(_kernels.slot_fm)
 
     @staticmethod
-    def forward(ctx, rows, W_local, w1_local, world: int, group, gather: Callable, slack: float, overflow):
-        route = _FixedRoute(rows, world, group, slack, overflow)
-        local_rows = route.exchange(route.send_rows)                          # [world*cap]
-        emb = route.gather_from_slots(route.exchange(gather(W_local, local_rows)))
-        lin = route.gather_from_slots(route.exchange(gather(w1_local.view(-1, 1), local_rows))).view(-1)
-        ctx.route, ctx.local_rows = route, local_rows
-        ctx.shapes = (tuple(W_local.shape), tuple(w1_local.shape))
-        return emb, lin
+    def tail(deep_branch: nn.Sequential, x: torch.Tensor, y_fm: torch.Tensor) -> torch.Tensor:
+        return run_tail(deep_branch, x, last_add=y_fm).squeeze(-1)
+
+
+def bucket_capacity(n: int, world: int, slack: float) -> int:
+    """Slots per peer bucket: the mean load with `slack` headroom plus six standard deviations."""
+    if world == 1:
+        return n
+    mean = -(-n // world)
+    return min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
+
+
+class _Exchange(torch.autograd.Function):
+    """x[B,F] raw ids -> (packed rows received [world*cap + 1, D+4], slot[B,F]).
+
+    Backward ships the gradient of the received buffer to the owners and returns it as
+    uncoalesced COO gradients of the LOCAL shards (what nn.Embedding(sparse=True) gives a local
+    table), averaged over ranks like the dense tail's all-reduce (every rank's loss is a mean over
+    ITS samples; the sum over ranks / world is the gradient of the global-batch mean)."""
 
     @staticmethod
-    def backward(ctx, g_emb, g_lin):
-        route, local_rows = ctx.route, ctx.local_rows
-        Wshape, w1shape = ctx.shapes
-        inv = 1.0 / route.world
+    def forward(ctx, x, W_local, w1_local, model):
+        ops, world, group = model.ops, model.world, model.group
+        D = W_local.shape[1]
+        cap = bucket_capacity(x.numel(), world, model.bucket_slack)
+        S = world * cap
+        static = model.__dict__.get("_static_io")
+        use_static = static is not None and static[0].shape[0] == S + 1 and tuple(static[1].shape) == tuple(x.shape)
+        send_rows, slot = ops.route_buckets(x, model.offsets, world, model.num_rows, cap, model.bucket_overflow,
+                                            slot_out=static[1] if use_static else None)
+        local_rows = torch.empty_like(send_rows)
+        dist.all_to_all_single(local_rows, send_rows, group=group)
+        packed = ops.gather_pack_rows(local_rows, W_local, w1_local)              # [S, D+4]
+        if use_static:
+            recv = static[0].detach()        # same storage (no copy into the graph), fresh autograd identity
+        else:
+            recv = packed.new_empty((S + 1, D + 4))
+            recv[S].zero_()                  # the dump slot reads as a zero row
+        dist.all_to_all_single(recv[:S], packed, group=group)
+        ctx.local_rows, ctx.meta = local_rows, (S, D, world, group, tuple(W_local.shape), tuple(w1_local.shape))
+        ctx.mark_non_differentiable(slot)
+        return recv, slot
+
+    @staticmethod
+    def backward(ctx, g_recv, _g_slot):
+        S, D, world, group, Wshape, w1shape = ctx.meta
+        g_owner = g_recv.new_empty((S, D + 4))
+        dist.all_to_all_single(g_owner, g_recv[:S].contiguous(), group=group)
+        inv = 1.0 / world
+        idx = ctx.local_rows.view(1, -1)
         gW = gw1 = None
         if ctx.needs_input_grad[1]:
-            g_rows = route.exchange(route.scatter_to_slots(g_emb.contiguous())).mul_(inv)
-            gW = torch.sparse_coo_tensor(local_rows.view(1, -1), g_rows, Wshape, check_invariants=False)
+            gW = torch.sparse_coo_tensor(idx, g_owner[:, :D] * inv, Wshape, check_invariants=False)
         if ctx.needs_input_grad[2]:
-            g1 = route.exchange(route.scatter_to_slots(g_lin.contiguous().view(-1, 1))).mul_(inv)
-            gw1 = torch.sparse_coo_tensor(local_rows.view(1, -1), g1.view((-1,) + (1,) * (len(w1shape) - 1)),
-                                          w1shape, check_invariants=False)
-        return None, gW, gw1, None, None, None, None, None
-
-
-class ShardedLookup(torch.autograd.Function):
-    """(emb[n,D], lin[n]) for n global rows from the row-sharded tables.
-
-    Backward ships the gradient rows to the owners and returns them as uncoalesced COO
-    gradients of the LOCAL shards (what nn.Embedding(sparse=True) would give a local table).
-    """
-
-    @staticmethod
-    def forward(ctx, rows, W_local, w1_local, world: int, group, gather: Callable):
-        route = _Route(rows, world, group)
-        local_rows = route.to_owner(route.send_rows)
-        emb_owner = gather(W_local, local_rows)                     # [n_recv, D]
-        lin_owner = gather(w1_local.view(-1, 1), local_rows)        # [n_recv, 1]
-        emb = route.unpermute(route.to_requester(emb_owner))
-        lin = route.unpermute(route.to_requester(lin_owner)).view(-1)
-        ctx.route, ctx.local_rows = route, local_rows
-        ctx.shapes = (tuple(W_local.shape), tuple(w1_local.shape))
-        return emb, lin
-
-    @staticmethod
-    def backward(ctx, g_emb, g_lin):
-        route, local_rows = ctx.route, ctx.local_rows
-        Wshape, w1shape = ctx.shapes
-        gW = gw1 = None
-        # every rank's loss is a mean over ITS samples; like the all-reduce of the dense tail the
-        # table gradients are averaged over ranks (gradient of the global-batch mean loss)
-        inv = 1.0 / dist.get_world_size(route.group)
-        if ctx.needs_input_grad[1]:
-            g_rows = route.to_owner(g_emb.contiguous()[route.perm]).mul_(inv)
-            gW = torch.sparse_coo_tensor(local_rows.view(1, -1), g_rows, Wshape, check_invariants=False)
-        if ctx.needs_input_grad[2]:
-            g1 = route.to_owner(g_lin.contiguous()[route.perm]).mul_(inv)
-            gw1 = torch.sparse_coo_tensor(local_rows.view(1, -1), g1.view((-1,) + (1,) * (len(w1shape) - 1)),
-                                          w1shape, check_invariants=False)
-        return None, gW, gw1, None, None, None
+            g1 = (g_owner[:, D] * inv).view((-1,) + (1,) * (len(w1shape) - 1))
+            gw1 = torch.sparse_coo_tensor(idx, g1, w1shape, check_invariants=False)
+        return None, gW, gw1, None
 
 
 def shard_rows(full: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -197,31 +121,30 @@ class ShardedDeepFM(nn.Module):
     """DeepFM (src/models/deepfm.py:11-105) with row-sharded tables and a replicated MLP tail.
 
     Constructor arguments as the reference's DeepFM where they apply.  `embedding_shard`
-    ([N_local, D]) and `fc_shard` ([N_local, 1]) hold only this rank's rows; use
+    ([N_local + 1, D]) and `fc_shard` ([N_local + 1, 1]) hold this rank's rows plus the sink row; use
     `load_full_tables` to shard a reference checkpoint's `embedding._emb_module.weight` /
     `fc.weight`.  Table gradients are row-form (sparse COO) on the local shards.
     """
 
     def __init__(self, field_dims: List[int], num_factor: int, hidden_sizes: List[int], p_dropout: float = 0.1,
-                 use_batchnorm=False, device=None, process_group=None, gather: Optional[Callable] = None,
-                 fm: Optional[Callable] = None, exact_routing: bool = False, bucket_slack: float = 1.25):
-        """exact_routing=True sizes the all-to-all splits exactly (one host sync per step);
-        the default pads every peer bucket to a fixed capacity (no sync, graph-capturable)."""
+                 use_batchnorm=False, device=None, process_group=None, ops=None, bucket_slack: float = 1.25):
         super().__init__()
-        self.exact_routing = exact_routing
+        self.ops = ops or HipOps
         self.bucket_slack = bucket_slack
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        self._gather = gather or _hip_gather
-        self._fm = fm or self._hip_fm
         N = sum(field_dims)
         self.num_rows = N
-        n_local = local_num_rows(N, self.rank, self.world)
-        # xavier-uniform over the GLOBAL [N, D] matrix (src/models/embeddings/base.py:66-67)
+        self.num_local_rows = local_num_rows(N, self.rank, self.world)
+        # xavier-uniform over the GLOBAL [N, D] matrix (src/models/embeddings/base.py:66-67); sink row zero
         bound = (6.0 / (N + num_factor)) ** 0.5
-        self.embedding_shard = nn.Parameter((torch.rand(n_local, num_factor, device=device) * 2 - 1) * bound)
-        self.fc_shard = nn.Parameter(torch.randn(n_local, 1, device=device))   # N(0,1) like nn.EmbeddingBag
+        W = (torch.rand(self.num_local_rows + 1, num_factor, device=device) * 2 - 1) * bound
+        w1 = torch.randn(self.num_local_rows + 1, 1, device=device)                # N(0,1) like nn.EmbeddingBag
+        W[-1].zero_()
+        w1[-1].zero_()
+        self.embedding_shard = nn.Parameter(W)
+        self.fc_shard = nn.Parameter(w1)
         self._bias = nn.Parameter(torch.zeros(1, device=device))
         deep_in = num_factor * len(field_dims)
         layers: List[nn.Module] = []
@@ -236,7 +159,7 @@ class ShardedDeepFM(nn.Module):
         self._deep_branch = nn.Sequential(*layers).to(device)
         fd = torch.cat([torch.tensor([0], dtype=torch.long), torch.tensor(field_dims)])
         self.register_buffer("offsets", torch.cumsum(fd[:-1], 0).unsqueeze(0).to(device))
-        self.register_buffer("bucket_overflow", torch.zeros(1, dtype=torch.bool, device=device), persistent=False)
+        self.register_buffer("bucket_overflow", torch.zeros(1, dtype=torch.int32, device=device), persistent=False)
         self.sync_dense_parameters()
 
     # ---- parameter plumbing ------------------------------------------------------------
@@ -250,62 +173,53 @@ class ShardedDeepFM(nn.Module):
 
     def allreduce_dense_grads(self):
         """Average the replicated tail's gradients with one flat collective."""
-        ps = [p for p in self.dense_parameters() if p.grad is not None]
-        if not ps:
+        grads = [p.grad for p in self.dense_parameters() if p.grad is not None]
+        if not grads:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        dist.all_reduce(flat, group=self.group)
-        flat /= self.world
-        o = 0
-        for p in ps:
-            n = p.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p.grad))
-            o += n
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, group=self.group)
+            flat /= self.world
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
     def check_overflow(self):
         """Synchronise; raise if any fixed-capacity bucket overflowed since the last check."""
         if bool(self.bucket_overflow.item()):
             self.bucket_overflow.zero_()
             raise RuntimeError("sharded lookup: a peer bucket overflowed its fixed capacity (extreme id skew); "
-                               "raise bucket_slack or use exact_routing=True")
+                               "raise bucket_slack (bucket_slack=world can never overflow)")
 
     @torch.no_grad()
     def load_full_tables(self, embedding_weight: torch.Tensor, fc_weight: torch.Tensor):
-        self.embedding_shard.copy_(shard_rows(embedding_weight, self.rank, self.world))
-        self.fc_shard.copy_(shard_rows(fc_weight, self.rank, self.world))
-
-    # ---- forward -----------------------------------------------------------------------
-    @staticmethod
-    def _hip_fm(emb, lin, bias):
-        # the first-order weights arrive already gathered: feed them to the fused FM kernel as
-        # a B*F-row table addressed by the identity
-        B, F, _ = emb.shape
-        ident = torch.arange(B * F, device=emb.device).view(B, F)
-        _, y = _kernels.fm_first_order(emb, ident, lin.reshape(-1, 1), bias)
-        return y
+        n = self.num_local_rows
+        self.embedding_shard[:n].copy_(shard_rows(embedding_weight, self.rank, self.world))
+        self.fc_shard[:n].copy_(shard_rows(fc_weight, self.rank, self.world))
+        self.embedding_shard[n].zero_()
+        self.fc_shard[n].zero_()
 
     # ---- the compute between the collectives ------------------------------------------------
-    def _local_compute(self, emb, lin):
-        """emb [B,F,D], lin [B,F] (already exchanged) -> logits [B]: FM + first-order + MLP tail."""
-        B = emb.shape[0]
-        y_fm = self._fm(emb, lin, self._bias)
-        if not emb.is_cuda:                                        # CPU only in the injected gloo tests
-            return (y_fm.unsqueeze(1) + self._deep_branch(emb.reshape(B, -1))).squeeze(-1)
-        return run_tail(self._deep_branch, emb.reshape(B, -1), last_add=y_fm).squeeze(-1)
+    def _local_compute(self, recv, slot):
+        """received packed rows + slots -> logits [B]: slot gather, FM, first-order term, MLP tail."""
+        emb, y_fm = self.ops.slot_fm(recv, slot, self._bias)
+        return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm)
 
     def enable_graphs(self, batch_size: int):
         """Capture the local compute (forward AND backward) for a fixed batch size as hipGraphs
         (torch.cuda.make_graphed_callables).  The RCCL collectives stay outside the graphs —
-        recording them hung on this stack — so a step is: eager routing + all-to-alls, ONE graph
-        replay for FM+MLP forward, one for their backward, eager gradient all-to-all + all-reduce."""
+        recording them hung on this stack — so a step is: routing + two all-to-alls, ONE graph replay
+        for gather+FM+MLP forward, one for their backward, the gradient all-to-all + all-reduce.
+        The exchange writes straight into the graphs' static inputs (no staging copy)."""
         F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
         dev = self.embedding_shard.device
+        S = self.world * bucket_capacity(batch_size * F, self.world, self.bucket_slack)
         # no collective may be in flight while a capture is open (the RCCL watchdog polls events)
         torch.cuda.synchronize(dev)
         dist.barrier(group=self.group)
         torch.cuda.synchronize(dev)
-        emb = torch.randn(batch_size, F, D, device=dev, requires_grad=True)
-        lin = torch.randn(batch_size, F, device=dev, requires_grad=True)
+        recv = torch.zeros(S + 1, D + 4, device=dev).requires_grad_(True)
+        slot = torch.arange(batch_size * F, device=dev).view(batch_size, F) % max(S, 1)
 
         class _Local(nn.Module):
             def __init__(inner, outer):
@@ -314,28 +228,23 @@ class ShardedDeepFM(nn.Module):
                 inner._bias = outer._bias
                 inner._deep_branch = outer._deep_branch
 
-            def forward(inner, e, l):
-                return inner.outer[0]._local_compute(e, l)
+            def forward(inner, r, s):
+                return inner.outer[0]._local_compute(r, s)
 
         # kept out of the module registry (it shares this module's parameters; state_dict must not change)
         object.__setattr__(self, "_graphed_local",
-                           torch.cuda.make_graphed_callables(_Local(self), (emb, lin), num_warmup_iters=3))
+                           torch.cuda.make_graphed_callables(_Local(self), (recv, slot), num_warmup_iters=3))
         object.__setattr__(self, "_graphed_batch", batch_size)
+        with torch.no_grad():
+            recv.zero_()
+        object.__setattr__(self, "_static_io", (recv, slot))
         torch.cuda.synchronize(dev)
         dist.barrier(group=self.group)
 
     def forward(self, x):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
-        B, F = x.shape
-        rows = x + self.offsets
-        if self.exact_routing:
-            emb, lin = ShardedLookup.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
-                                           self._gather)
-        else:
-            emb, lin = ShardedLookupFixed.apply(rows, self.embedding_shard, self.fc_shard, self.world, self.group,
-                                                self._gather, self.bucket_slack, self.bucket_overflow)
-        emb, lin = emb.view(B, F, -1), lin.view(B, F)
+        recv, slot = _Exchange.apply(x, self.embedding_shard, self.fc_shard, self)
         graphed = self.__dict__.get("_graphed_local")
-        if graphed is not None and B == self._graphed_batch and self.training:
-            return graphed(emb, lin)
-        return self._local_compute(emb, lin)
+        if graphed is not None and x.shape[0] == self._graphed_batch and self.training:
+            return graphed(recv, slot)
+        return self._local_compute(recv, slot)

@@ -1,0 +1,186 @@
+"""GPU: the device-side routing of the row-sharded lookup (csrc/route.hip + the slot variants of
+the gather+FM kernels) against its torch restatement (oracle/sharded_ops.py, pinned by the gloo
+world-2 test) — integer outputs bit-exact, fp32 within the stated tolerances — and an emulated
+multi-rank exchange on one GPU against the unsharded kernel."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+import recsys_benchmark_amd as pkg
+from oracle.sharded_ops import TorchOps
+from recsys_benchmark_amd import _kernels, _lib
+from recsys_benchmark_amd.sharded import bucket_capacity, local_num_rows, shard_rows
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _flag():
+    return torch.zeros(1, dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("B,F", [(1, 1), (5, 3), (39, 26), (40, 26), (4096, 26), (1000, 39)])
+def test_route_matches_restatement_bit_exact(world, B, F):
+    g = torch.Generator().manual_seed(B * 131 + F + world)
+    dims = torch.randint(1, 5000, (F,), generator=g)
+    N = int(dims.sum())
+    offsets = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.long), dims[:-1]]), 0)
+    x = torch.stack([torch.randint(0, int(d), (B,), generator=g) for d in dims], 1)
+    cap = bucket_capacity(B * F, world, 1.25)
+    of_ref = torch.zeros(1, dtype=torch.int32)
+    send_ref, slot_ref = TorchOps.route_buckets(x, offsets, world, N, cap, of_ref)
+    of = _flag()
+    send, slot = _kernels.route_buckets(x.to(DEV), offsets.to(DEV), world, N, cap, of)
+    assert torch.equal(slot.cpu(), slot_ref)
+    assert torch.equal(send.cpu(), send_ref)
+    assert int(of.item()) == int(of_ref.item())
+    pkg.check_index_errors()
+
+
+def test_route_int32_ids_no_offsets_and_noncontiguous():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 977, (64, 7), generator=g, dtype=torch.int32)
+    xt = x.t()                                         # non-contiguous view
+    for inp in (x, xt):
+        ref = TorchOps.route_buckets(inp, None, 4, 977, 200, torch.zeros(1, dtype=torch.int32))
+        got = _kernels.route_buckets(inp.to(DEV), None, 4, 977, 200, _flag())
+        assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+
+
+def test_route_overflow_goes_to_dump_slot_and_raises_flag():
+    x = torch.zeros(300, 1, dtype=torch.int64)          # every lookup hits owner 0
+    x[::3] = 5
+    cap, world = 64, 4
+    of_ref = torch.zeros(1, dtype=torch.int32)
+    send_ref, slot_ref = TorchOps.route_buckets(x, None, world, 1000, cap, of_ref)
+    of = _flag()
+    send, slot = _kernels.route_buckets(x.to(DEV), None, world, 1000, cap, of)
+    assert int(of_ref.item()) == 1 and int(of.item()) == 1
+    assert torch.equal(slot.cpu(), slot_ref) and torch.equal(send.cpu(), send_ref)
+    assert int((slot.cpu() == world * cap).sum()) == int((slot_ref == world * cap).sum()) > 0
+
+
+def test_route_out_of_range_ids_hit_the_dump_slot_and_the_error_word():
+    x = torch.tensor([[3, 10], [-1, 2], [7, 0]], dtype=torch.int64)
+    offsets = torch.tensor([0, 8])
+    N = 12                                             # 8 + 10 >= N, -1 < 0
+    ref = TorchOps.route_buckets(x, offsets, 2, N, 6, torch.zeros(1, dtype=torch.int32))
+    got = _kernels.route_buckets(x.to(DEV), offsets.to(DEV), 2, N, 6, _flag())
+    assert torch.equal(got[1].cpu(), ref[1]) and torch.equal(got[0].cpu(), ref[0])
+    assert int(got[1][0, 1]) == 12 and int(got[1][1, 0]) == 12
+    with pytest.raises(IndexError):
+        pkg.check_index_errors()
+
+
+def test_route_empty_batch():
+    send, slot = _kernels.route_buckets(torch.zeros(0, 5, dtype=torch.int64, device=DEV), None, 2, 100, 0, _flag())
+    assert send.numel() == 0 and slot.numel() == 0
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 64, 256])
+def test_gather_pack_rows(D):
+    g = torch.Generator().manual_seed(D)
+    W, w1 = torch.randn(500, D, generator=g), torch.randn(500, 1, generator=g)
+    rows = torch.randint(0, 500, (777,), generator=g)
+    ref = TorchOps.gather_pack_rows(rows, W, w1)
+    got = _kernels.gather_pack_rows(rows.to(DEV), W.to(DEV), w1.to(DEV))
+    assert torch.equal(got.cpu(), ref)                 # copies: bit-exact
+    pkg.check_index_errors()
+
+
+def test_gather_pack_rejects_unsupported_width_loudly():
+    with pytest.raises(_lib.MI355XLibraryError):
+        _kernels.gather_pack_rows(torch.zeros(3, dtype=torch.int64, device=DEV), torch.zeros(5, 6, device=DEV),
+                                  torch.zeros(5, 1, device=DEV))
+
+
+@pytest.mark.parametrize("B,F,D", [(1, 1, 16), (33, 26, 16), (64, 39, 16), (17, 100, 8), (9, 5, 64)])
+def test_slot_fm_forward_backward(B, F, D):
+    g = torch.Generator().manual_seed(B + F + D)
+    S = B * F + 11                                     # some slots stay unused (padding)
+    buf = torch.randn(S + 1, D + 4, generator=g) * 0.1        # embedding-like magnitudes
+    buf[:, D + 1:] = 0
+    buf[S] = 0
+    slot = torch.randperm(S, generator=g)[:B * F].view(B, F)
+    slot[0, 0] = S                                     # one dropped lookup -> the dump row
+    bias = torch.tensor([0.3])
+    g_emb, g_y = torch.randn(B, F, D, generator=g), torch.randn(B, generator=g)
+
+    rb, rbias = buf.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    e_ref, y_ref = TorchOps.slot_fm(rb, slot, rbias)
+    ((e_ref * g_emb).sum() + (y_ref * g_y).sum()).backward()
+
+    hb, hbias = buf.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    e, y = _kernels.slot_fm(hb, slot.to(DEV), hbias)
+    ((e * g_emb.to(DEV)).sum() + (y * g_y.to(DEV)).sum()).backward()
+    assert torch.equal(e.detach().cpu(), e_ref.detach())                      # gathered rows: exact
+    assert_close(y, y_ref, 1e-5, 1e-5, "y_fm")                                # fp32 sum order
+    # gradient rows [0, S): exact layout, padding rows zero; the dump row is never shipped
+    # g_emb + g_y * (S_b - e): S_b is a sum of F unit-normal terms taken in a different order -> absolute
+    # error ~ F * eps * |S_b| ~ 1e-6 on entries that cancel to ~0; hence the absolute floor of 1e-5
+    assert_close(hb.grad[:S, :D + 1], rb.grad[:S, :D + 1], 1e-5, 1e-5, "grad rows")
+    assert not hb.grad[:S, D + 1:].any()
+    unused = torch.ones(S, dtype=torch.bool)
+    unused[slot.view(-1)[slot.view(-1) < S]] = False
+    assert not hb.grad[:S][unused.to(DEV)].any()
+    assert_close(hbias.grad, rbias.grad, 1e-5, 1e-6, "bias grad")
+    pkg.check_index_errors()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_emulated_ranks_reproduce_the_unsharded_lookup(world):
+    """All `world` ranks emulated on one GPU (the all-to-alls done by slicing): logits' FM part and
+    the gradient rows arriving at every owner must equal the unsharded fused kernel's."""
+    g = torch.Generator().manual_seed(world)
+    dims, D, B = [50, 7, 1000, 3, 211], 16, 48
+    F, N = len(dims), sum(dims)
+    offsets = torch.cumsum(torch.tensor([0] + dims[:-1]), 0).to(DEV)
+    W, w1 = torch.randn(N, D, generator=g).to(DEV), torch.randn(N, 1, generator=g).to(DEV)
+    bias = torch.tensor([0.1], device=DEV)
+    xs = [torch.stack([torch.randint(0, d, (B,), generator=g) for d in dims], 1).to(DEV) for _ in range(world)]
+    cap = bucket_capacity(B * F, world, 1.25)
+    S = world * cap
+    shards = []
+    for r in range(world):
+        n = local_num_rows(N, r, world)
+        Wl, wl = torch.zeros(n + 1, D, device=DEV), torch.zeros(n + 1, 1, device=DEV)
+        Wl[:n], wl[:n] = shard_rows(W, r, world), shard_rows(w1, r, world)
+        shards.append((Wl, wl))
+    routed = [_kernels.route_buckets(x, offsets, world, N, cap, _flag()) for x in xs]
+    # all-to-all #1: owner o receives bucket o of every requester r, in requester order
+    local_rows = [torch.cat([routed[r][0][o * cap:(o + 1) * cap] for r in range(world)]) for o in range(world)]
+    packed = [_kernels.gather_pack_rows(local_rows[o], *shards[o]) for o in range(world)]
+    # all-to-all #2: requester r receives chunk r of every owner o, in owner order
+    g_total = torch.zeros(N, D, device=DEV)
+    g1_total = torch.zeros(N, device=DEV)
+    ref_total = torch.zeros(N, D, device=DEV)
+    ref1_total = torch.zeros(N, device=DEV)
+    g_send = []
+    for r in range(world):
+        recv = torch.zeros(S + 1, D + 4, device=DEV)
+        recv[:S] = torch.cat([packed[o][r * cap:(r + 1) * cap] for o in range(world)])
+        recv.requires_grad_(True)
+        emb, y = _kernels.slot_fm(recv, routed[r][1], bias)
+        Wf, w1f = W.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+        emb_ref, y_ref = _kernels.gather_fm(xs[r], offsets, Wf, w1f, bias, True, True)
+        assert torch.equal(emb, emb_ref)
+        assert_close(y, y_ref, 1e-6, 1e-6, "y_fm")
+        ge, gy = torch.randn(B, F, D, generator=g).to(DEV), torch.randn(B, generator=g).to(DEV)
+        ((emb * ge).sum() + (y * gy).sum()).backward()
+        ((emb_ref * ge).sum() + (y_ref * gy).sum()).backward()
+        ref_total += Wf.grad.to_dense()
+        ref1_total += w1f.grad.to_dense().view(-1)
+        g_send.append(recv.grad[:S])
+    # all-to-all #3 + scatter at the owners
+    for o in range(world):
+        g_owner = torch.cat([g_send[r][o * cap:(o + 1) * cap] for r in range(world)])
+        n = local_num_rows(N, o, world)
+        acc = torch.zeros(n + 1, D + 4, device=DEV).index_add_(0, local_rows[o], g_owner)
+        assert not acc[n].any()                                               # the sink only sees zeros
+        g_total[o::world] += acc[:n, :D]
+        g1_total[o::world] += acc[:n, D]
+    assert_close(g_total, ref_total, 1e-5, 1e-5, "table grad")
+    assert_close(g1_total, ref1_total, 1e-5, 1e-6, "first-order grad")
+    pkg.check_index_errors()

@@ -46,8 +46,11 @@ def test_sharded_world1_equals_unsharded(one_rank_group):
     lossf(a, y).backward()
     lossf(b, y).backward()
     sh.allreduce_dense_grads()
-    assert_close(sh.embedding_shard.grad, ref.embedding.get_weight().grad.to_dense(), 1e-5, 1e-7, "table grad")
-    assert_close(sh.fc_shard.grad, ref.fc.weight.grad.to_dense(), 1e-5, 1e-7, "first-order grad")
+    N = sum(dims)
+    gW, g1 = sh.embedding_shard.grad.to_dense(), sh.fc_shard.grad.to_dense()
+    assert_close(gW[:N], ref.embedding.get_weight().grad.to_dense(), 1e-5, 1e-7, "table grad")
+    assert_close(g1[:N], ref.fc.weight.grad.to_dense(), 1e-5, 1e-7, "first-order grad")
+    assert not gW[N].any() and not g1[N].any()                 # the sink row
     assert_close(sh._bias.grad, ref._bias.grad, 1e-5, 1e-7)
     for (k, p), (_, q) in zip(sh._deep_branch.named_parameters(), ref._deep_branch.named_parameters()):
         assert_close(p.grad, q.grad, 1e-4, 1e-6, k)
