@@ -241,6 +241,82 @@ class ShardedDeepFM(nn.Module):
         torch.cuda.synchronize(dev)
         dist.barrier(group=self.group)
 
+    def make_graphed_step(self, criterion, batch_size: int):
+        """A whole training step `step(x, y) -> loss` for a fixed batch size with everything between the
+        collectives — slot gather + FM + MLP forward, the criterion, and the complete backward down to the
+        outgoing gradient rows and one FLAT buffer of the replicated tail's gradients — replayed as ONE
+        hipGraph.  Outside the graph a step is four library launches (routing, packing), three all-to-alls,
+        two strided scales that form the shards' COO gradients, and the flat all-reduce: no autograd
+        bookkeeping, no host sync.  After a step `p.grad` of every parameter is set exactly as by
+        `criterion(model(x), y).backward(); model.allreduce_dense_grads()` (dense gradients are views of
+        the flat buffer); the returned loss is a device scalar that the next step overwrites."""
+        F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
+        dev = self.embedding_shard.device
+        world, group = self.world, self.group
+        cap = bucket_capacity(batch_size * F, world, self.bucket_slack)
+        S = world * cap
+        dense = self.dense_parameters()
+        recv = torch.zeros(S + 1, D + 4, device=dev).requires_grad_(True)
+        slot = (torch.arange(batch_size * F, device=dev) % max(S, 1)).view(batch_size, F)
+        ys = torch.zeros(batch_size, device=dev)
+
+        def local():
+            loss = criterion(self._local_compute(recv, slot), ys)
+            grads = torch.autograd.grad(loss, [recv] + dense)
+            return loss, grads[0], torch.cat([g.reshape(-1) for g in grads[1:]])
+
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=group)              # no collective in flight while a capture is open
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                local()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss, g_recv, flat = local()
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=group)
+
+        sizes = [p.numel() for p in dense]
+        views = [v.view_as(p) for v, p in zip(flat.split(sizes), dense)]
+        avg = dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else None
+        inv = 1.0 / world
+        Wshape, w1shape = tuple(self.embedding_shard.shape), tuple(self.fc_shard.shape)
+
+        def step(x, y):
+            if tuple(x.shape) != (batch_size, F):
+                raise ValueError(f"this step was captured for x of shape {(batch_size, F)}, got {tuple(x.shape)}")
+            ys.copy_(y)
+            send_rows, _ = self.ops.route_buckets(x, self.offsets, world, self.num_rows, cap, self.bucket_overflow,
+                                                  slot_out=slot)
+            local_rows = torch.empty_like(send_rows)
+            dist.all_to_all_single(local_rows, send_rows, group=group)
+            packed = self.ops.gather_pack_rows(local_rows, self.embedding_shard, self.fc_shard)
+            with torch.no_grad():
+                dist.all_to_all_single(recv[:S], packed, group=group)
+                graph.replay()
+                g_owner = torch.empty_like(packed)
+                dist.all_to_all_single(g_owner, g_recv[:S], group=group)
+                idx = local_rows.view(1, -1)
+                self.embedding_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, :D] * inv, Wshape,
+                                                                    check_invariants=False)
+                self.fc_shard.grad = torch.sparse_coo_tensor(idx, (g_owner[:, D] * inv).view(-1, 1), w1shape,
+                                                             check_invariants=False)
+                if avg is not None:
+                    dist.all_reduce(flat, op=avg, group=group)
+                else:
+                    dist.all_reduce(flat, group=group)
+                    flat.mul_(inv)
+            for p, v in zip(dense, views):
+                p.grad = v
+            return loss
+
+        return step
+
     def forward(self, x):
         """x: int [B_local, F] raw per-field ids -> logits [B_local]."""
         recv, slot = _Exchange.apply(x, self.embedding_shard, self.fc_shard, self)

@@ -40,6 +40,30 @@ def main():
     for (k, p), (_, q) in zip(graphed.named_buffers(), eager.named_buffers()):
         torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6, msg=lambda m: f"buffer {k}: {m}")
     graphed.check_overflow()
+
+    # the one-graph training step: same loss, same p.grad on every parameter, same buffers, twice in a row
+    from recsys_benchmark_amd.losses import BCEWithLogitsLoss
+
+    stepper = ShardedDeepFM(dims, D, [32, 16], p_dropout=0.0, use_batchnorm=True, device=dev)
+    stepper.load_state_dict(eager.state_dict())
+    step = stepper.make_graphed_step(BCEWithLogitsLoss(), B)
+    for it in range(2):
+        eager.load_state_dict(stepper.state_dict())        # warm-ups / earlier steps moved the BN running stats
+        x = torch.stack([torch.randint(0, d, (B,)) for d in dims], 1).to(dev)
+        y = (torch.rand(B) < 0.3).float().to(dev)
+        eager.zero_grad(set_to_none=True)
+        ref_loss = lossf(eager(x), y)
+        ref_loss.backward()
+        eager.allreduce_dense_grads()
+        loss = step(x, y)
+        torch.testing.assert_close(loss.reshape(()), ref_loss.detach().reshape(()), rtol=1e-5, atol=1e-6)
+        for (k, p), (_, q) in zip(stepper.named_parameters(), eager.named_parameters()):
+            g = p.grad.to_dense() if p.grad.is_sparse else p.grad
+            r = q.grad.to_dense() if q.grad.is_sparse else q.grad
+            torch.testing.assert_close(g, r, rtol=1e-4, atol=1e-6, msg=lambda m: f"step {it} {k}: {m}")
+        for (k, p), (_, q) in zip(stepper.named_buffers(), eager.named_buffers()):
+            torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6, msg=lambda m: f"step {it} buffer {k}: {m}")
+    stepper.check_overflow()
     torch.cuda.synchronize()
     print("GRAPHED_SHARDED_OK", flush=True)
     dist.destroy_process_group()
