@@ -184,12 +184,16 @@ def main():
     graphed_local = False
     if sharded and not args.no_graph:
         # everything between the collectives (gather+FM+MLP forward, criterion, whole backward) as ONE hipGraph
-        graphed_step = model.make_graphed_step(lossf, B)
-        graphed_local = True
+        try:
+            graphed_step = model.make_graphed_step(lossf, B)
+            graphed_local = True
 
-        def step():
-            next_batch()
-            graphed_step(x, y)
+            def step():
+                next_batch()
+                graphed_step(x, y)
+        except Exception as e:  # noqa: BLE001 - keep the run alive: the eager step is always valid
+            print(f"[bench] rank {rank}: capturing the local compute failed ({type(e).__name__}: {e}); eager",
+                  file=sys.stderr, flush=True)
     if use_graph:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -268,18 +268,21 @@ class ShardedDeepFM(nn.Module):
         torch.cuda.synchronize(dev)
         dist.barrier(group=group)              # no collective in flight while a capture is open
         torch.cuda.synchronize(dev)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                local()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss, g_recv, flat = local()
-        torch.cuda.synchronize(dev)
-        dist.barrier(group=group)
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    local()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread may poll its events while this thread records
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                loss, g_recv, flat = local()
+        finally:                               # every rank reaches the closing barrier, failed capture or not
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=group)
 
         sizes = [p.numel() for p in dense]
         views = [v.view_as(p) for v, p in zip(flat.split(sizes), dense)]
