@@ -215,6 +215,37 @@ MI_API int mi_tt_bwd(const int64_t *idx, const float *g_out, const float *const 
                      const int32_t *q_shapes, const int32_t *ranks, int64_t n, int32_t D,
                      int64_t N, void *stream);
 
+/* ---- a10, grouped form: the TT-Rec lookup as one GEMM per core slice ---------------------------
+ * Same arithmetic as mi_tt_fwd/bwd (tensortrain_embeddings.py:100-150).  The lookups of level c are
+ * ordered by their digit i_c, so that all lookups sharing the slice core_c[i_c] are consecutive rows:
+ *   res_c[(l,h), :] = res_{c-1}[(l,h), :] . core_c[i_c(l)]   viewed [r_c, q_c*r_{c+1}]
+ * runs on the MFMA units through mi_gemm_f32_row_groups (forward and input gradient) and
+ * mi_gemm_f32_k_groups (slice gradients); the host side (recsys-benchmark_amd/_kernels.py) builds the
+ * orderings with device-side sorts, no host sync.
+ *   mi_tt_digits: digits[c*n + i] = c-th mixed-radix digit of idx[i] over p_shapes (int32); ids outside
+ *     [0, N) give digits 0, valid[i] = 0 and MI_IDX_OUT_OF_RANGE in *err.
+ *   mi_move_chunks: dst[dst_row[i]*dst_stride + e] (= or +=, float atomics) src[src_row[i]*src_stride + e]
+ *     for e < width (multiple of 4), zeroed / skipped where mask[i] == 0; NULL row arrays = identity.
+ *   mi_gemm_f32_row_groups: C[M,N] = A[M,K] . opB(B + mtile_b[m/64]*sB); 64-row tiles with mtile_b < 0
+ *     are skipped (the rows of a group are padded to whole tiles).
+ *   mi_gemm_f32_k_groups: for each segment s: C[kseg[s][2]*sC ...][M,N] += A[k0:k0+K, :M]^T . B[k0:k0+K, :N]
+ *     with (k0, K) = kseg[s][0:2], float atomics, C zeroed by the caller.
+ *   mi_segment_sum: out[kseg[s][2]*ldo + j] += sum_{r<K} X[(k0+r)*ldx + j], j < width (core 0's gradient:
+ *     the lookups sharing a first digit are consecutive rows).                                          */
+MI_API int mi_tt_digits(const int64_t *idx, int64_t n, int64_t N, const int32_t *p_shapes,
+                        int32_t ncores, int32_t *digits, uint8_t *valid, int32_t *err, void *stream);
+MI_API int mi_move_chunks(const float *src, const int64_t *src_row, int64_t src_stride, float *dst,
+                          const int64_t *dst_row, int64_t dst_stride, int32_t width, int64_t n,
+                          const uint8_t *mask, int32_t accumulate, void *stream);
+MI_API int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, int32_t N,
+                                  int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transB,
+                                  int64_t sB, const int32_t *mtile_b, void *stream);
+MI_API int mi_segment_sum(const float *X, int64_t ldx, int32_t width, const int64_t *kseg,
+                          int32_t nseg, float *out, int64_t ldo, void *stream);
+MI_API int mi_gemm_f32_k_groups(const float *A, const float *B, float *C, int32_t M, int32_t N,
+                                int32_t lda, int32_t ldb, int32_t ldc, int64_t sC, const int64_t *kseg,
+                                int32_t nseg, void *stream);
+
 /* ---- a12/a13: fp32 MFMA GEMM with fused CrossNet epilogues ------------------
  * C[M,N] = epi( sum_{g<kgroups} opA(A + g*gA)[M,K] . opB(B + g*gB)[K,N] ), batched over `batch`
  * with element strides sA/sB/sC (and sR1/sR2/sC2).  transA=0: A[m*lda+k], 1: A[k*lda+m];

@@ -614,8 +614,178 @@ class TTLookup(torch.autograd.Function):
         return (None, None, None, None, None, *gcs)
 
 
+# ---- grouped form: one MFMA GEMM per core slice (csrc/tt_grouped.hip, gemm.hip) ------------------
+_TT_TILE = 64            # rows per GEMM tile: the rows of a digit group are padded to whole tiles
+_TT_SEG = 2048           # reduction rows per slice-gradient segment (long groups are cut, float atomics join)
+_TT_SEG0 = 256           # rows per segment of core 0's gradient sum
+_TT_GROUPED_MIN = 4096   # below this many lookups the sort / planning launches cost more than they save
+_TT_MAX_TILES = 65535    # gridDim.y
+
+
+class _TTLevelPlan:
+    """Layout of one level: the lookups ordered by `digit`, each owning `H` consecutive rows, every digit
+    group padded to whole 64-row tiles.  Built with device-side torch ops only (sort, searchsorted,
+    cumsum): no host sync, static shapes."""
+
+    def __init__(self, digit: torch.Tensor, H: int, p: int, seg: int):
+        dev, n = digit.device, digit.numel()
+        sorted_d, perm = torch.sort(digit, stable=True)
+        bounds = torch.searchsorted(sorted_d, torch.arange(p + 1, device=dev, dtype=digit.dtype))   # [p+1]
+        starts, cnt = bounds[:-1], bounds[1:] - bounds[:-1]
+        rows = cnt * H
+        rpad = (rows + (_TT_TILE - 1)) // _TT_TILE * _TT_TILE
+        pend = torch.cumsum(rpad, 0)
+        pbeg = pend - rpad
+        self.ntiles = (n * H + _TT_TILE - 1) // _TT_TILE + p          # static upper bound
+        self.mpad = self.ntiles * _TT_TILE
+        t0 = torch.arange(self.ntiles, device=dev) * _TT_TILE
+        g_t = torch.searchsorted(pend, t0, right=True)
+        self.mtile_b = torch.where(g_t < p, g_t, torch.full_like(g_t, -1)).to(torch.int32)
+        g_s = sorted_d.to(torch.int64)
+        pos_sorted = pbeg[g_s] + (torch.arange(n, device=dev) - starts[g_s]) * H
+        self.pos = torch.empty(n, dtype=torch.int64, device=dev)      # first row of every ORIGINAL lookup
+        self.pos[perm] = pos_sorted
+        # reduction segments of at most `seg` rows, none straddling a group
+        chunks = (rows + (seg - 1)) // seg
+        cend = torch.cumsum(chunks, 0)
+        self.nseg = (n * H + seg - 1) // seg + p
+        j = torch.arange(self.nseg, device=dev)
+        g_j = torch.searchsorted(cend, j, right=True)
+        live = g_j < p
+        g_c = torch.where(live, g_j, torch.zeros_like(g_j))
+        local = j - (cend[g_c] - chunks[g_c])
+        k0 = pbeg[g_c] + local * seg
+        K = torch.where(live, torch.minimum(rows[g_c] - local * seg, torch.full_like(local, seg)), torch.zeros_like(local))
+        self.kseg = torch.stack([k0, K, g_c], 1).contiguous()          # int64 [nseg, 3]
+
+
+def _move(src, src_row, src_stride, dst, dst_row, dst_stride, width, n, mask=None, accumulate=False):
+    _lib.check(
+        _lib.load().mi_move_chunks(src.data_ptr(), _lib.ptr(src_row), src_stride, dst.data_ptr(), _lib.ptr(dst_row),
+                                   dst_stride, width, n, _lib.ptr(mask), 1 if accumulate else 0,
+                                   _lib.stream_ptr(dst.device)),
+        "mi_move_chunks",
+    )
+
+
+def tt_grouped_supported(n: int, q_shapes, ranks) -> bool:
+    """The grouped form needs 16-byte chunk widths / strides, at least two cores, enough lookups to
+    amortise the planning, and tile counts within one grid dimension."""
+    ncores = len(q_shapes)
+    if ncores < 2 or n < _TT_GROUPED_MIN:
+        return False
+    H = 1
+    for c in range(ncores):
+        H *= q_shapes[c]
+        if (q_shapes[c] * ranks[c + 1]) % 4 or (c > 0 and ranks[c] % 4):
+            return False
+    return H % 4 == 0
+
+
+class TTLookupGrouped(torch.autograd.Function):
+    """out[n, D] = TT-Rec rows, every level as GEMMs grouped by that level's digit."""
+
+    @staticmethod
+    def forward(ctx, idx, num_item: int, p_shapes, q_shapes, ranks, *cores):
+        dev = _lib.require_gpu(idx, *cores)
+        lib = _lib.load()
+        stream = _lib.stream_ptr(dev)
+        idxc = _i64c(idx).view(-1)
+        cs = [_f32c(c) for c in cores]
+        n, nc = idxc.numel(), len(cs)
+        digits = torch.empty((nc, n), dtype=torch.int32, device=dev)
+        valid = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mi_tt_digits(idxc.data_ptr(), n, num_item, (_ct.c_int32 * nc)(*p_shapes), nc, digits.data_ptr(),
+                                    valid.data_ptr(), _lib.err_word(dev).data_ptr(), stream), "mi_tt_digits")
+        Hs = [1]
+        for q in q_shapes:
+            Hs.append(Hs[-1] * q)                                   # Hs[c] = rows per lookup entering level c
+        D = Hs[-1]
+        plans = {c: _TTLevelPlan(digits[c], Hs[c], p_shapes[c], _TT_SEG) for c in range(1, nc)}
+        d0 = digits[0].to(torch.int64)
+        # level 1 operand: core 0's slices [q_0, r_1] dropped into level 1's layout
+        w0 = q_shapes[0] * ranks[1]
+        A = torch.empty((plans[1].mpad, ranks[1]), dtype=torch.float32, device=dev)
+        _move(cs[0], d0, w0, A, plans[1].pos, ranks[1], w0, n, mask=valid)
+        saved_A = []
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        for c in range(1, nc):
+            K, Nn = ranks[c], q_shapes[c] * ranks[c + 1]
+            C = torch.empty((plans[c].mpad, Nn), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_gemm_f32_row_groups(A.data_ptr(), cs[c].data_ptr(), C.data_ptr(), plans[c].mpad, Nn, K,
+                                                  K, Nn, Nn, 0, K * Nn, plans[c].mtile_b.data_ptr(), stream),
+                       "mi_gemm_f32_row_groups")
+            saved_A.append(A)
+            width = Hs[c] * Nn                                      # a lookup's rows, contiguous
+            if c + 1 < nc:
+                A = torch.empty((plans[c + 1].mpad, ranks[c + 1]), dtype=torch.float32, device=dev)
+                _move(C, plans[c].pos, Nn, A, plans[c + 1].pos, ranks[c + 1], width, n)
+            else:
+                _move(C, plans[c].pos, Nn, out, None, D, width, n)
+        ctx.save_for_backward(d0, valid, *cs, *saved_A)
+        ctx.plans = plans
+        ctx.meta = (num_item, list(p_shapes), list(q_shapes), list(ranks), Hs, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        num_item, p_shapes, q_shapes, ranks, Hs, n = ctx.meta
+        nc = len(p_shapes)
+        d0, valid, *rest = ctx.saved_tensors
+        cs, As = rest[:nc], rest[nc:]
+        plans = ctx.plans
+        dev = g.device
+        lib = _lib.load()
+        stream = _lib.stream_ptr(dev)
+        g = _f32c(g)
+        D = Hs[-1]
+        gcs = [torch.zeros_like(c) for c in cs]
+        last = nc - 1
+        N_last = q_shapes[last] * ranks[last + 1]
+        dC = torch.empty((plans[last].mpad, N_last), dtype=torch.float32, device=dev)
+        _move(g, None, D, dC, plans[last].pos, N_last, D, n, mask=valid)
+        for c in range(last, 0, -1):
+            K, Nn = ranks[c], q_shapes[c] * ranks[c + 1]
+            A = As[c - 1]
+            # slice gradients: gcore_c[i] += A_rows(i)^T . dC_rows(i)
+            _lib.check(lib.mi_gemm_f32_k_groups(A.data_ptr(), dC.data_ptr(), gcs[c].data_ptr(), K, Nn, K, Nn, Nn, K * Nn,
+                                                plans[c].kseg.data_ptr(), plans[c].nseg, stream), "mi_gemm_f32_k_groups")
+            # input gradient: dA = dC . core_c[i]^T
+            dA = torch.empty((plans[c].mpad, K), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_gemm_f32_row_groups(dC.data_ptr(), cs[c].data_ptr(), dA.data_ptr(), plans[c].mpad, K, Nn,
+                                                  Nn, Nn, K, 1, K * Nn, plans[c].mtile_b.data_ptr(), stream),
+                       "mi_gemm_f32_row_groups")
+            width = Hs[c] * K
+            if c > 1:
+                Np = q_shapes[c - 1] * ranks[c]
+                dC = torch.empty((plans[c - 1].mpad, Np), dtype=torch.float32, device=dev)
+                _move(dA, plans[c].pos, K, dC, plans[c - 1].pos, Np, width, n)
+            else:
+                # core 0: order the lookups by their first digit and sum each group's rows
+                w0 = q_shapes[0] * ranks[1]
+                plan0 = _TTLevelPlan(d0.to(torch.int32), 1, p_shapes[0], _TT_SEG0)
+                X = torch.empty((plan0.mpad, w0), dtype=torch.float32, device=dev)
+                _move(dA, plans[1].pos, K, X, plan0.pos, w0, w0, n, mask=valid)
+                _lib.check(lib.mi_segment_sum(X.data_ptr(), w0, w0, plan0.kseg.data_ptr(), plan0.nseg,
+                                              gcs[0].data_ptr(), w0, stream), "mi_segment_sum")
+        return (None, None, None, None, None, *gcs)
+
+
 def tt_lookup(idx, cores, num_item, p_shapes, q_shapes, ranks):
-    return TTLookup.apply(idx, num_item, tuple(p_shapes), tuple(q_shapes), tuple(ranks), *cores)
+    args = (num_item, tuple(p_shapes), tuple(q_shapes), tuple(ranks), *cores)
+    n = idx.numel()
+    if not tt_grouped_supported(min(n, _TT_GROUPED_MIN), q_shapes, ranks) or n < _TT_GROUPED_MIN:
+        return TTLookup.apply(idx, *args)
+    # a level's row tiles must fit one grid dimension: very large batches (get_weight over the whole
+    # vocabulary) go through in pieces
+    H = 1
+    for q in q_shapes[:-1]:
+        H *= q
+    piece = (_TT_MAX_TILES - max(p_shapes) - 1) * _TT_TILE // H
+    flat = idx.reshape(-1)
+    if n <= piece:
+        return TTLookupGrouped.apply(flat, *args)
+    return torch.cat([TTLookupGrouped.apply(flat[i:i + piece], *args) for i in range(0, n, piece)])
 
 
 # --------------------------------------------------------------------------------------

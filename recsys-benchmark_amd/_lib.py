@@ -56,6 +56,11 @@ SIGNATURES = {
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, _p],
     "mi_scatter_axpy_rows": [_p, _p, ctypes.c_float, _p, _i64, _i32, _i64, _p],
+    "mi_tt_digits": [_p, _i64, _i64, _p, _i32, _p, _p, _p, _p],
+    "mi_move_chunks": [_p, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _i32, _p],
+    "mi_gemm_f32_row_groups": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p, _p],
+    "mi_gemm_f32_k_groups": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i64, _p, _i32, _p],
+    "mi_segment_sum": [_p, _i64, _i32, _p, _i32, _p, _i64, _p],
     "mi_route_workspace_elems": [_i64, _i32],
     "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],

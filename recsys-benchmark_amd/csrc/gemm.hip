@@ -51,6 +51,9 @@ struct GemmArgs {
   long long sC2;
   int alignedA, alignedB;
   int splitk;             // >1: blockIdx.z = batch*splitk + slice; slices add into C atomically (EPI_NONE/ACCUM only)
+  // grouped forms (TT-Rec levels, tt_grouped.hip): both null for a plain GEMM
+  const int *mtile_b;     // [gridDim.y] B slice of each 64-row tile of A/C (B + idx*sB), -1: tile unused
+  const long long *kseg;  // [batch][3] = (first reduction row, rows, C slice): per-z K range, C + slice*sC, atomic adds
 };
 
 constexpr int BM = 64, BN = 64, BK = 32, LDSS = BK + 4;
@@ -168,6 +171,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 
   const float *A = a.A + z * a.sA;
   const float *B = a.B + z * a.sB;
+  long long cslice = z;
+  if (a.mtile_b) {                       // row-grouped: this tile's rows all multiply the same B slice
+    const int g = a.mtile_b[blockIdx.y];
+    if (g < 0) return;
+    B = a.B + (long long)g * a.sB;
+  }
+  if (a.kseg) {                          // reduction-grouped: z owns rows [k0, k0+K) of both operands
+    const long long k0 = a.kseg[z * 3];
+    a.K = (int)a.kseg[z * 3 + 1];
+    cslice = a.kseg[z * 3 + 2];
+    A = a.A + k0 * (TA ? a.lda : 1);
+    B = a.B + k0 * (BT ? a.ldb : 1);
+  }
 
   floatx16 acc;
 #pragma unroll
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   // ---- epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of its 32x32 tile
   const int n = n0 + wc * 32 + i;
   if (n >= a.N) return;
-  float *C = a.C + z * a.sC;
+  float *C = a.C + cslice * a.sC;
   const float *R1 = a.R1 ? a.R1 + z * a.sR1 : nullptr;
   const float *R2 = a.R2 ? a.R2 + z * a.sR2 : nullptr;
   float *C2 = a.C2 ? a.C2 + z * a.sC2 : nullptr;
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     if (m >= a.M) continue;
     const float v = acc[r];
     const long long co = (long long)m * a.ldc + n;
-    if (a.splitk > 1) {
+    if (a.splitk > 1 || a.kseg) {
       atomicAdd(C + co, v);
       continue;
     }
@@ -322,6 +338,8 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   a.R1 = R1; a.R2 = R2; a.ldr1 = ldr1; a.ldr2 = ldr2; a.sR1 = sR1; a.sR2 = sR2;
   a.rowscale = rowscale; a.nrs = nrs;
   a.C2 = C2; a.ldc2 = ldc2; a.sC2 = sC2;
+  a.mtile_b = nullptr;
+  a.kseg = nullptr;
   a.alignedA = aligned16(A) && (lda % 4 == 0) && (sA % 4 == 0) && (gA % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0) && (gB % 4 == 0);
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splitk);
@@ -337,6 +355,72 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   else { if (a.transB) GO(0, 0); else GO(0, 1); }
 #undef GO
   return launch_status();
+}
+
+// ---- grouped forms used by the TT-Rec levels (tt_grouped.hip) ------------------------------------
+static int launch_grouped(GemmArgs &a, dim3 grid, const char *name, void *stream) {
+  hipEvent_t ea, eb;
+  const bool prof = mi::prof_acquire(name, &ea, &eb);
+#define GO(TA, BT)                                                                                      \
+  do {                                                                                                  \
+    if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
+    else hipLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, a);          \
+  } while (0)
+  if (a.transA) { if (a.transB) GO(1, 0); else GO(1, 1); }
+  else { if (a.transB) GO(0, 0); else GO(0, 1); }
+#undef GO
+  return launch_status();
+}
+
+static void plain_args(GemmArgs &a, const float *A, const float *B, float *C, int M, int N, int K, int lda,
+                       int ldb, int ldc, int transA, int transB) {
+  a.splitk = 1;
+  a.A = A; a.B = B; a.C = C;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.transA = transA ? 1 : 0; a.transB = transB ? 1 : 0;
+  a.sA = 0; a.sB = 0; a.sC = 0;
+  a.kgroups = 1; a.gA = 0; a.gB = 0;
+  a.epi = EPI_NONE; a.bias = nullptr;
+  a.R1 = a.R2 = nullptr; a.ldr1 = a.ldr2 = 0; a.sR1 = a.sR2 = 0;
+  a.rowscale = nullptr; a.nrs = 0;
+  a.C2 = nullptr; a.ldc2 = 0; a.sC2 = 0;
+  a.mtile_b = nullptr; a.kseg = nullptr;
+}
+
+int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K,
+                           int32_t lda, int32_t ldb, int32_t ldc, int32_t transB, int64_t sB,
+                           const int32_t *mtile_b, void *stream) {
+  if (M < 0 || N < 0 || K < 0) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MI_OK;
+  if (!A || !B || !C || !mtile_b) return MI_ERR_INVALID_ARG;
+  GemmArgs a;
+  plain_args(a, A, B, C, M, N, K, lda, ldb, ldc, 0, transB);
+  a.sB = sB;
+  a.mtile_b = mtile_b;
+  a.alignedA = aligned16(A) && (lda % 4 == 0);
+  a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
+  if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
+  return launch_grouped(a, grid, "gemm_row_groups", stream);
+}
+
+int mi_gemm_f32_k_groups(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t lda,
+                         int32_t ldb, int32_t ldc, int64_t sC, const int64_t *kseg, int32_t nseg,
+                         void *stream) {
+  if (M < 0 || N < 0 || nseg < 0) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0 || nseg == 0) return MI_OK;
+  if (!A || !B || !C || !kseg) return MI_ERR_INVALID_ARG;
+  if (nseg > 65535) return MI_ERR_UNSUPPORTED;
+  GemmArgs a;
+  plain_args(a, A, B, C, M, N, 0, lda, ldb, ldc, 1, 0);   // C[slice] += A[rows,:M]^T . B[rows,:N]
+  a.sC = sC;
+  a.kseg = reinterpret_cast<const long long *>(kseg);
+  a.alignedA = aligned16(A) && (lda % 4 == 0);
+  a.alignedB = aligned16(B) && (ldb % 4 == 0);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nseg);
+  if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
+  return launch_grouped(a, grid, "gemm_k_groups", stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,106 @@
+"""GPU: the grouped (one MFMA GEMM per core slice) TT-Rec lookup against the oracle's restatement of
+tt_rec_torch_forward (src/models/embeddings/tensortrain_embeddings.py:100-150, pinned to the tt_*
+goldens) and against the per-lookup kernels, forward and all core gradients.
+Tolerances: fp32 contractions of length r_c <= 128 in a different order (MFMA k-order, float-atomic
+joins of reduction segments): rtol 1e-4 forward, 1e-3 on gradients that sum thousands of lookups."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+from oracle import reference_ops as ro
+from recsys_benchmark_amd import _kernels, _lib
+from recsys_benchmark_amd.embeddings import TTRecTorch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _emb(N, ranks, ps, qs, seed):
+    gen = torch.Generator().manual_seed(seed)
+    emb = TTRecTorch(N, 16, ranks, tt_p_shapes=ps, tt_q_shapes=qs, weight_dist="normal")
+    with torch.no_grad():
+        for c in emb.tt_cores:
+            c.copy_(torch.randn(c.shape, generator=gen) * 0.1)
+    return emb, gen
+
+
+def _check(emb, idx, gen, rtol_g=1e-3, atol_g=1e-4):
+    cores = [c.detach().clone().requires_grad_(True) for c in emb.tt_cores]
+    ref = ro.tt_forward(idx.flatten(), emb.tt_p_shapes, emb.tt_q_shapes, emb.tt_ranks, cores)
+    G = torch.randn(ref.shape, generator=gen)
+    (ref * G).sum().backward()
+    emb.to(DEV)
+    emb.zero_grad()
+    out = emb(idx.to(DEV)).reshape(-1, ref.shape[-1])
+    assert_close(out, ref, 1e-4, 1e-5, "forward")
+    (out * G.to(DEV)).sum().backward()
+    for i, c in enumerate(cores):
+        assert_close(emb.tt_cores[i].grad, c.grad, rtol_g, atol_g, f"grad core {i}")
+    _lib.check_index_errors()
+
+
+@pytest.mark.parametrize("ranks,ps,qs", [([128, 96], [25, 25, 32], [2, 2, 4]),      # configs/deepfm/tt_rec.yaml:10
+                                         ([16, 8], [10, 50, 40], [2, 2, 4]),
+                                         ([32], [200, 100], [4, 4]),                 # two cores
+                                         ([8, 12, 4], [10, 10, 20, 10], [2, 2, 1, 4])])  # four cores
+def test_grouped_matches_oracle(ranks, ps, qs):
+    N = 20000
+    emb, gen = _emb(N, ranks, ps, qs, 11)
+    n = 6000
+    assert _kernels.tt_grouped_supported(n, emb.tt_q_shapes, emb.tt_ranks)
+    idx = torch.randint(0, N, (n,), generator=gen)
+    _check(emb, idx, gen)
+
+
+def test_grouped_skewed_ids_and_2d_input():
+    """Zipf-like ids: a few digit groups hold most lookups (long reduction segments, many duplicates)."""
+    N = 20000
+    emb, gen = _emb(N, [128, 96], [25, 25, 32], [2, 2, 4], 5)
+    u = torch.rand(300, 26, generator=gen)
+    idx = (N * u ** 6).long().clamp_(0, N - 1)
+    assert idx.numel() >= _kernels._TT_GROUPED_MIN
+    _check(emb, idx, gen, rtol_g=2e-3, atol_g=2e-4)
+
+
+def test_grouped_equals_per_lookup_kernels_and_flags_bad_ids():
+    N = 20000
+    emb, gen = _emb(N, [16, 8], [10, 50, 40], [2, 2, 4], 9)
+    emb.to(DEV)
+    idx = torch.randint(0, N, (5000,), generator=gen).to(DEV)
+    args = (N, tuple(emb.tt_p_shapes), tuple(emb.tt_q_shapes), tuple(emb.tt_ranks), *emb.tt_cores)
+    a = _kernels.TTLookup.apply(idx, *args)
+    b = _kernels.TTLookupGrouped.apply(idx, *args)
+    assert_close(b, a, 1e-5, 1e-6, "grouped vs per-lookup")
+    _lib.check_index_errors()
+    bad = idx.clone()
+    bad[7], bad[4000] = N, -3
+    c = _kernels.TTLookupGrouped.apply(bad, *args)
+    assert not c[7].any() and not c[4000].any()                     # out-of-range ids give zero rows
+    keep = torch.ones(5000, dtype=torch.bool, device=DEV)
+    keep[7] = keep[4000] = False
+    assert torch.equal(c[keep], b[keep])
+    with pytest.raises(IndexError):
+        _lib.check_index_errors()
+
+
+def test_small_batches_and_odd_shapes_take_the_per_lookup_path():
+    assert not _kernels.tt_grouped_supported(100, [2, 2, 4], [1, 128, 96, 1])         # too few lookups
+    assert not _kernels.tt_grouped_supported(10 ** 5, [2, 2, 2, 2], [1, 8, 8, 8, 1])  # last level 2 floats wide
+    assert not _kernels.tt_grouped_supported(10 ** 5, [4, 4], [1, 3, 1])              # rank not a multiple of 4
+    assert _kernels.tt_grouped_supported(10 ** 5, [2, 2, 4], [1, 128, 96, 1])
+
+
+def test_get_weight_goes_through_in_pieces(monkeypatch):
+    """TTRecTorch.get_weight (tensortrain_embeddings.py:253-270) = lookup of arange(N); with the tile budget
+    lowered the batch is cut into pieces, the result must not change."""
+    N = 9000
+    emb, gen = _emb(N, [16, 8], [10, 30, 30], [2, 2, 4], 3)
+    emb.to(DEV)
+    full = emb.get_weight()
+    monkeypatch.setattr(_kernels, "_TT_MAX_TILES", 200)
+    pieces = emb.get_weight()
+    assert torch.equal(pieces, full)
+    ref = ro.tt_forward(torch.arange(N), emb.tt_p_shapes, emb.tt_q_shapes, emb.tt_ranks,
+                        [c.detach().cpu() for c in emb.tt_cores])
+    assert_close(full, ref, 1e-4, 1e-5, "get_weight")
