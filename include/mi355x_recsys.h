@@ -335,6 +335,29 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 
+/* ---- §8f rank 3: the LightGCN step either side of the propagation -------------------------------
+ * mi_bpr_fwd/bwd: src/losses.py:6-22 on rows picked from the propagated tables
+ *   (torch.index_select x3, src/trainer/lightgcn.py:395-399): x_b = u_b.(p_b - n_b) with
+ *   u_b = U[ui[b]], p_b = P[pi[b]], n_b = Nn[ni[b]] (NULL index arrays = row b);
+ *   loss = mean_b -logsigmoid(x_b) (partials joined in index order: deterministic), sig[b] = sigmoid(-x_b).
+ *   bwd: dU[ui[b]] += c_b (p_b - n_b), dP[pi[b]] += c_b u_b, dN[ni[b]] -= c_b u_b, c_b = -g sig[b] / B
+ *   (float atomics into caller-zeroed dense gradients when the index array is given, stores otherwise;
+ *   any of dU/dP/dN may be NULL).  workspace: mi_bpr_workspace_elems(B) floats.
+ * mi_mask_topk_rows: src/trainer/lightgcn.py:122-138: for row b (user users[b], or b if NULL)
+ *   scores[b, col[crow[u] .. crow[u+1])] = -inf (in place; crow may be NULL = no mask), then the
+ *   indices (and optionally values) of the k largest entries, score descending, ties by ascending
+ *   index.  k <= 256.                                                                               */
+MI_API int64_t mi_bpr_workspace_elems(int64_t B);
+MI_API int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, float *sig,
+                      float *workspace, float *loss, void *stream);
+MI_API int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, const float *sig,
+                      const float *g, float *dU, float *dP, float *dN, void *stream);
+MI_API int mi_mask_topk_rows(float *scores, int64_t ld, int64_t nrows, int64_t ncol,
+                             const int64_t *users, const int64_t *crow, const int64_t *col, int32_t k,
+                             int64_t *out_idx, float *out_val, void *stream);
+
 /* ---- §8e: device-side routing of the row-sharded DeepFM lookup -------------------------------
  * No reference counterpart (the reference keeps one table on one device,
  * src/models/embeddings/base.py:52-57); the arithmetic either side of the exchange is the

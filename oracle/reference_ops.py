@@ -311,3 +311,18 @@ def tt_forward(indices: torch.Tensor, tt_p_shapes, tt_q_shapes, tt_ranks, cores)
             res = torch.einsum("abhj,jbkr->abhkr", res, sl)
             res = res.reshape(res.shape[0], res.shape[1], res.shape[2] * res.shape[3], res.shape[4])
     return res.squeeze(0).squeeze(-1)
+
+
+def masked_topk(user_embs: torch.Tensor, item_embs: torch.Tensor, users: torch.Tensor, graph, k: int,
+                filter_item_on_train: bool = True) -> torch.Tensor:
+    """Scoring tail of validate_epoch — src/trainer/lightgcn.py:122-138: scores, -inf on the user's train
+    items (the reference's Python double loop), torch.topk indices."""
+    scores = user_embs[users] @ item_embs.T
+    if filter_item_on_train:
+        ind0: List[int] = []
+        ind1: List[int] = []
+        for i, user in enumerate(users.tolist()):
+            ind0.extend([i] * len(graph[user]))
+            ind1.extend(graph[user])
+        scores[ind0, ind1] = float("-inf")
+    return torch.topk(scores, k)[1]

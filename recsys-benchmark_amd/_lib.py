@@ -61,6 +61,10 @@ SIGNATURES = {
     "mi_gemm_f32_row_groups": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p, _p],
     "mi_gemm_f32_k_groups": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i64, _p, _i32, _p],
     "mi_segment_sum": [_p, _i64, _i32, _p, _i32, _p, _i64, _p],
+    "mi_bpr_workspace_elems": [_i64],
+    "mi_bpr_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p],
+    "mi_bpr_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p],
+    "mi_mask_topk_rows": [_p, _i64, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p],
     "mi_route_workspace_elems": [_i64, _i32],
     "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
@@ -70,7 +74,8 @@ SIGNATURES = {
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
-_RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64}
+_RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
+             "mi_bpr_workspace_elems": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()

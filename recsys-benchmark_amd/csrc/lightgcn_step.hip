@@ -1,0 +1,293 @@
+// lightgcn_step.hip — the LightGCN step either side of the propagation.
+//
+//  * BPR loss over rows picked from the propagated tables — src/losses.py:6-22 applied to
+//    torch.index_select(all_user_emb, 0, users) etc. (src/trainer/lightgcn.py:395-399): gathers,
+//    two row dots, -logsigmoid, mean in ONE launch; the backward scatters the three gradient rows
+//    straight into the dense table gradients (what index_select's backward builds with index_add).
+//  * validation scoring tail — src/trainer/lightgcn.py:122-138: scores[ind0, ind1] = -inf for the
+//    items a user already has in train (a Python double loop in the reference; here a CSR row per
+//    user on the device) and torch.topk(scores, k) indices, one workgroup per user row.
+//
+// Ordering of the top-k: score descending, ties by ascending item index (a strict total order, so
+// the result does not depend on scheduling).
+#include "common.hpp"
+
+namespace {
+using namespace mi;
+
+__device__ __forceinline__ float softplus(float x) {   // log(1 + e^x), stable
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+// 16 lanes (one float4 each) per sample when D == 64; generic D: lanes stride over d.
+// part[blockIdx.x] = sum over the block's samples of softplus(-(u.p - u.n)); the last block to finish
+// adds the partials in index order (deterministic) and writes the mean.
+__global__ __launch_bounds__(kBlock) void k_bpr_fwd(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, float *__restrict__ sig, float *__restrict__ part, unsigned *ticket,
+    float *__restrict__ loss) {
+  __shared__ float red[kWavesPerBlock];
+  __shared__ bool last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc = 0.f;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const float *u = U + (ui ? ui[b] : b) * D;
+    const float *p = P + (pi ? pi[b] : b) * D;
+    const float *q = Nn + (ni ? ni[b] : b) * D;
+    float d = 0.f;
+    for (int j = lane; j < D; j += kWave) d += u[j] * (p[j] - q[j]);
+    d = wave_sum(d);                       // y_pos - y_neg
+    if (lane == 0) {
+      sig[b] = 1.f / (1.f + expf(d));      // sigmoid(-d) = -dL_b/dd
+      acc += softplus(-d);                 // -logsigmoid(d)
+    }
+  }
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < kWavesPerBlock; ++j) s += red[j];
+    part[blockIdx.x] = s;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {                              // fixed summation tree over the partials: deterministic
+    __threadfence();
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < gridDim.x; j += kBlock) s += ((volatile float *)part)[j];
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int j = 0; j < kWavesPerBlock; ++j) t += red[j];
+      loss[0] = t / (float)B;
+      *ticket = 0;                         // re-armed for the next launch
+    }
+  }
+}
+
+// dU[ui[b]] += c (p - n), dP[pi[b]] += c u, dN[ni[b]] -= c u with c = -g * sig[b] / B
+// (float atomics when an index array is given — rows repeat —, plain stores otherwise)
+__global__ __launch_bounds__(kBlock) void k_bpr_bwd(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, const float *__restrict__ sig, const float *__restrict__ g,
+    float *__restrict__ dU, float *__restrict__ dP, float *__restrict__ dN) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float scale = -g[0] / (float)B;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t ur = ui ? ui[b] : b, pr = pi ? pi[b] : b, nr = ni ? ni[b] : b;
+    const float c = scale * sig[b];
+    for (int j = lane; j < D; j += kWave) {
+      const float u = U[ur * D + j], p = P[pr * D + j], q = Nn[nr * D + j];
+      if (dU) { if (ui) atomicAdd(dU + ur * D + j, c * (p - q)); else dU[ur * D + j] = c * (p - q); }
+      if (dP) { if (pi) atomicAdd(dP + pr * D + j, c * u); else dP[pr * D + j] = c * u; }
+      if (dN) { if (ni) atomicAdd(dN + nr * D + j, -c * u); else dN[nr * D + j] = -c * u; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ mask + top-k per row ----
+constexpr int kCand = 2048;   // candidate slots in LDS
+constexpr int kSample = 4096; // row prefix that sets the candidate bound
+
+struct Cand {
+  float v;
+  int i;
+};
+
+// f(value, column) over one row, 256 threads; float4 loads (4 independent elements in flight per
+// iteration, two iterations unrolled) when the row is 16-byte aligned
+template <class Fn>
+__device__ __forceinline__ void scan_row(const float *__restrict__ row, int64_t ncol, bool vec, Fn f) {
+  const int tid = threadIdx.x;
+  int64_t done = 0;
+  if (vec) {
+    const int64_t n4 = ncol >> 2;
+#pragma unroll 2
+    for (int64_t c = tid; c < n4; c += kBlock) {
+      const float4 x = ld4(row + c * 4);
+      const int j = (int)(c * 4);
+      f(x.x, j);
+      f(x.y, j + 1);
+      f(x.z, j + 2);
+      f(x.w, j + 3);
+    }
+    done = n4 << 2;
+  }
+  for (int64_t j = done + tid; j < ncol; j += kBlock) f(row[j], (int)j);
+}
+__device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool before(float av, int ai, float bv, int bi) {
+  return av > bv || (av == bv && ai < bi);
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_topk(
+    float *__restrict__ scores, int64_t ld, int64_t ncol, const int64_t *__restrict__ users,
+    const int64_t *__restrict__ crow, const int64_t *__restrict__ col, int k,
+    int64_t *__restrict__ out_idx, float *__restrict__ out_val) {
+  __shared__ Cand cand[kCand];
+  __shared__ float lmax[kBlock];
+  __shared__ int lidx[kBlock];
+  __shared__ float thr_v;
+  __shared__ int thr_i;
+  __shared__ int count;
+  const int tid = threadIdx.x;
+  float *row = scores + (int64_t)blockIdx.x * ld;
+  const float ninf = -__builtin_huge_valf();
+
+  if (crow) {   // items the user already interacted with in train never rank
+    const int64_t u = users ? users[blockIdx.x] : blockIdx.x;
+    for (int64_t e = crow[u] + tid; e < crow[u + 1]; e += kBlock) {
+      const int64_t c = col[e];
+      if ((uint64_t)c < (uint64_t)ncol) row[c] = ninf;
+    }
+    __syncthreads();
+  }
+
+  // pass 1 over a PREFIX of the row (a full second read of a 150 KB row would come from HBM again: 2048
+  // rows are in flight): every thread's best element of the sample; the k-th best of those 256 bounds the
+  // k-th best of the whole row from below
+  const bool vec = ((ld & 3) == 0) && aligned16_dev(scores);
+  float bv = ninf;
+  int bi = 0x7fffffff;
+  scan_row(row, ncol < kSample ? ncol : (int64_t)kSample, vec, [&](float v, int j) {
+    if (before(v, j, bv, bi)) { bv = v; bi = j; }
+  });
+  lmax[tid] = bv;
+  lidx[tid] = bi;
+  if (tid == 0) {
+    count = 0;
+    thr_v = ninf;          // default bound admits everything (fewer than k threads own an element)
+    thr_i = 0x7fffffff;
+  }
+  __syncthreads();
+  if (bi != 0x7fffffff) {
+    int rank = 0;
+    for (int t = 0; t < kBlock; ++t) rank += before(lmax[t], lidx[t], bv, bi);
+    if (rank == k - 1) { thr_v = bv; thr_i = bi; }
+  }
+  __syncthreads();
+  const float tv = thr_v;
+  const int ti = thr_i;
+  // pass 2, the one full read: everything not after the bound is a candidate (~k * ncol / kSample of them)
+  scan_row(row, ncol, vec, [&](float v, int j) {
+    if (!before(tv, ti, v, j)) {
+      const int s = atomicAdd(&count, 1);
+      if (s < kCand) { cand[s].v = v; cand[s].i = j; }
+    }
+  });
+  __syncthreads();
+  const int n = count;
+  if (n <= kCand) {
+    // bitonic sort of the candidates in LDS under the strict total order (padded to a power of two with
+    // entries that sort last); the first k are the answer
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int a = n + tid; a < P; a += kBlock) { cand[a].v = ninf; cand[a].i = 0x7fffffff; }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (P >> 1); t += kBlock) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const Cand a = cand[lo], b = cand[hi];
+          const bool desc = (lo & size) == 0;
+          const bool swap = desc ? before(b.v, b.i, a.v, a.i) : before(a.v, a.i, b.v, b.i);
+          if (swap) { cand[lo] = b; cand[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < k) {
+      out_idx[(int64_t)blockIdx.x * k + tid] = cand[tid].i;
+      if (out_val) out_val[(int64_t)blockIdx.x * k + tid] = cand[tid].v;
+    }
+    return;
+  }
+  // too many candidates (massive ties): k rounds of "best element after the previous pick"
+  float pv = __builtin_huge_valf();
+  int pi = -1;
+  for (int r = 0; r < k; ++r) {
+    float cv = ninf;
+    int ci = 0x7fffffff;
+    scan_row(row, ncol, vec, [&](float v, int j) {
+      const bool after_prev = (pi < 0) || before(pv, pi, v, j);
+      if (after_prev && before(v, j, cv, ci)) { cv = v; ci = j; }
+    });
+    __syncthreads();
+    lmax[tid] = cv;
+    lidx[tid] = ci;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+      if (tid < s && before(lmax[tid + s], lidx[tid + s], lmax[tid], lidx[tid])) {
+        lmax[tid] = lmax[tid + s];
+        lidx[tid] = lidx[tid + s];
+      }
+      __syncthreads();
+    }
+    pv = lmax[0];
+    pi = lidx[0];
+    if (tid == 0) {
+      out_idx[(int64_t)blockIdx.x * k + r] = pi;
+      if (out_val) out_val[(int64_t)blockIdx.x * k + r] = pv;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mi_bpr_workspace_elems(int64_t B) {
+  if (B < 0) return 0;
+  return grid_for_waves(B) + 1;   // per-block partial sums + the ticket word
+}
+
+int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+               const int64_t *ni, int64_t B, int32_t D, float *sig, float *workspace, float *loss,
+               void *stream) {
+  if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (!U || !P || !Nn || !sig || !workspace || !loss) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  // workspace[grid] is the ticket: zeroed here once per call (captured as a memset node in a graph)
+  if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+    return MI_ERR_LAUNCH;
+  MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, sig, workspace,
+            reinterpret_cast<unsigned *>(workspace + grid), loss);
+  return launch_status();
+}
+
+int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+               const int64_t *ni, int64_t B, int32_t D, const float *sig, const float *g, float *dU,
+               float *dP, float *dN, void *stream) {
+  if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (!U || !P || !Nn || !sig || !g) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("bpr_bwd", k_bpr_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, sig, g,
+            dU, dP, dN);
+  return launch_status();
+}
+
+int mi_mask_topk_rows(float *scores, int64_t ld, int64_t nrows, int64_t ncol, const int64_t *users,
+                      const int64_t *crow, const int64_t *col, int32_t k, int64_t *out_idx,
+                      float *out_val, void *stream) {
+  if (nrows < 0 || ncol < 0 || ld < ncol || k < 1) return MI_ERR_INVALID_ARG;
+  if (k > ncol || ncol >= (1ll << 31)) return MI_ERR_INVALID_ARG;   // torch.topk raises for k > size
+  if (k > kBlock) return MI_ERR_UNSUPPORTED;
+  if (nrows == 0) return MI_OK;
+  if (!scores || !out_idx || (crow && !col)) return MI_ERR_INVALID_ARG;
+  if (nrows > 0x7fffffff) return MI_ERR_UNSUPPORTED;
+  MI_LAUNCH("mask_topk", k_mask_topk, (int)nrows, kBlock, stream, scores, ld, ncol, users, crow, col, k,
+            out_idx, out_val);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -132,3 +132,37 @@ def get_sparsity_and_param(model: Union[LightGCN, SingleLightGCN]):
     max_params = (model._num_user + model._num_item) * model._hidden_size
     num_params = sum(emb.get_num_params() for emb in embs)
     return 1 - num_params / max_params, num_params
+
+
+def train_items_csr(graph, num_users: int, device=None):
+    """CSR (crow, col) of the train interactions, from the reference dataset's `graph`
+    (user -> iterable of item ids, CFGraphDataset.get_graph()).  Built once per dataset on the host."""
+    lens = [len(graph[u]) if u in graph else 0 for u in range(num_users)] if isinstance(graph, dict) else \
+        [len(graph[u]) for u in range(num_users)]
+    crow = torch.zeros(num_users + 1, dtype=torch.int64)
+    crow[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
+    flat = [i for u in range(num_users) for i in (graph[u] if (not isinstance(graph, dict) or u in graph) else ())]
+    col = torch.tensor(flat, dtype=torch.int64)
+    return crow.to(device), col.to(device)
+
+
+def score_topk(user_embs: torch.Tensor, item_embs: torch.Tensor, users: torch.Tensor, k: int, train_csr=None):
+    """The scoring tail of validation (src/trainer/lightgcn.py:122-138): `user_embs[users] @ item_embs.T`,
+    -inf on the items each user has in train (`train_csr` = train_items_csr(graph, ...); None = no filter) and
+    torch.topk(scores, k) indices — gather, fp32 MFMA GEMM, and one mask + top-k workgroup per user, no Python
+    loop over users.  Returns int64 [len(users), k] (score descending, ties by ascending item id)."""
+    from . import _kernels, _lib
+
+    dev = _lib.require_gpu(user_embs, item_embs, users)
+    users = _kernels._i64c(users).view(-1)
+    rows = _kernels.gather_rows(users, user_embs.detach())
+    items = _kernels._f32c(item_embs.detach())
+    B, D, I = rows.shape[0], rows.shape[1], items.shape[0]
+    scores = torch.empty((B, I), dtype=torch.float32, device=dev)
+    _kernels.gemm(rows, items, scores, B, I, D, D, D, I, transB=True)               # rows . items^T
+    out = torch.empty((B, k), dtype=torch.int64, device=dev)
+    crow, col = (None, None) if train_csr is None else train_csr
+    _lib.check(_lib.load().mi_mask_topk_rows(scores.data_ptr(), scores.stride(0), B, I, users.data_ptr(),
+                                             _lib.ptr(crow), _lib.ptr(col), k, out.data_ptr(), None,
+                                             _lib.stream_ptr(dev)), "mi_mask_topk_rows")
+    return out

@@ -1,7 +1,8 @@
 """Losses around the path.  `BCEWithLogitsLoss` is torch.nn.BCEWithLogitsLoss
 (reduction="mean", the reference trainer's criterion, src/trainer/deepfm.py:32,51) as ONE HIP launch
 each way instead of ~8 elementwise/reduction launches — at B=4096 every launch is microseconds.
-`bpr_loss` restates src/losses.py:6-22 (tiny; stays in PyTorch ops)."""
+`bpr_loss` / `bpr_loss_rows` are src/losses.py:6-22 (optionally fused with the trainer's three index_selects)
+as one HIP launch each way."""
 import torch
 from torch import nn
 
@@ -38,7 +39,58 @@ class BCEWithLogitsLoss(nn.Module):
         return _BCEFn.apply(logits, target.float())
 
 
+class _BPRFn(torch.autograd.Function):
+    """-logsigmoid(u.p - u.n).mean() with u = U[ui], p = P[pi], n = Nn[ni] (None index = row b)."""
+
+    @staticmethod
+    def forward(ctx, U, P, Nn, ui, pi, ni):
+        dev = _lib.require_gpu(U, P, Nn)
+        lib = _lib.load()
+        U, P, Nn = _kernels._f32c(U), _kernels._f32c(P), _kernels._f32c(Nn)
+        idx = [None if t is None else _kernels._i64c(t).view(-1) for t in (ui, pi, ni)]
+        B = idx[0].numel() if idx[0] is not None else U.shape[0]
+        D = U.shape[1]
+        for t, i in zip((U, P, Nn), idx):
+            if t.dim() != 2 or t.shape[1] != D or (i.numel() if i is not None else t.shape[0]) != B:
+                raise ValueError("bpr_loss: user / positive / negative rows must be [B, D] (or tables with [B] indices)")
+        if B == 0:
+            raise ValueError("bpr_loss of an empty batch")
+        sig = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_bpr_fwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
+                                  _lib.ptr(idx[2]), B, D, sig.data_ptr(), ws.data_ptr(), loss.data_ptr(),
+                                  _lib.stream_ptr(dev)), "mi_bpr_fwd")
+        ctx.save_for_backward(U, P, Nn, sig, *[i for i in idx if i is not None])
+        ctx.has_idx = [i is not None for i in idx]
+        ctx.meta = (B, D)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        U, P, Nn, sig, *rest = ctx.saved_tensors
+        it = iter(rest)
+        idx = [next(it) if h else None for h in ctx.has_idx]
+        B, D = ctx.meta
+        g = _kernels._f32c(g).view(1)
+        grads = []
+        for need, t, i in zip(ctx.needs_input_grad[:3], (U, P, Nn), idx):
+            # rows repeat under an index array: the kernel accumulates with atomics into zeros
+            grads.append(None if not need else (torch.zeros_like(t) if i is not None else torch.empty_like(t)))
+        _lib.check(_lib.load().mi_bpr_bwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
+                                          _lib.ptr(idx[2]), B, D, sig.data_ptr(), g.data_ptr(), _lib.ptr(grads[0]),
+                                          _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.stream_ptr(U.device)),
+                   "mi_bpr_bwd")
+        return grads[0], grads[1], grads[2], None, None, None
+
+
 def bpr_loss(user_embs, pos_embs, neg_embs):
-    y_hat_pos = (user_embs * pos_embs).sum(1)
-    y_hat_neg = (user_embs * neg_embs).sum(1)
-    return -torch.nn.functional.logsigmoid(y_hat_pos - y_hat_neg).mean()
+    """src/losses.py:6-22 — one launch each way."""
+    return _BPRFn.apply(user_embs, pos_embs, neg_embs, None, None, None)
+
+
+def bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items):
+    """bpr_loss(index_select(all_user_emb, users), index_select(all_item_emb, pos), index_select(all_item_emb, neg))
+    (src/trainer/lightgcn.py:395-399) without materialising the three gathered matrices; the gradients land in
+    dense table gradients like index_select's backward."""
+    return _BPRFn.apply(all_user_emb, all_item_emb, all_item_emb, users, pos_items, neg_items)

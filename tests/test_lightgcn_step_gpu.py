@@ -1,0 +1,114 @@
+"""GPU: the LightGCN step either side of the propagation — fused BPR loss and the
+mask + top-k scoring tail — against the oracle's restatements of src/losses.py:6-22 and
+src/trainer/lightgcn.py:122-138."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+from oracle import reference_ops as ro
+from recsys_benchmark_amd import _lib
+from recsys_benchmark_amd.lightgcn import score_topk, train_items_csr
+from recsys_benchmark_amd.losses import bpr_loss, bpr_loss_rows
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("B,D", [(1, 64), (7, 5), (2048, 64), (5000, 16)])
+def test_bpr_loss_matches_reference(B, D):
+    g = torch.Generator().manual_seed(B + D)
+    u, p, n = (torch.randn(B, D, generator=g, requires_grad=True) for _ in range(3))
+    ref = ro.bpr_loss(u, p, n)
+    (ref * 1.7).backward()
+    hu, hp, hn = (t.detach().to(DEV).requires_grad_(True) for t in (u, p, n))
+    out = bpr_loss(hu, hp, hn)
+    (out * 1.7).backward()
+    # fp32 row dots of length D and a mean over B in a different order
+    assert_close(out, ref, 1e-5, 1e-6, "loss")
+    for a, b, name in ((hu, u, "du"), (hp, p, "dp"), (hn, n, "dn")):
+        assert_close(a.grad, b.grad, 1e-5, 1e-7, name)
+
+
+def test_bpr_loss_is_stable_for_huge_margins():
+    u = torch.tensor([[100.0, 0.0], [-100.0, 0.0], [0.0, 0.0]])
+    p = torch.tensor([[1.0, 0.0], [1.0, 0.0], [0.0, 0.0]])
+    n = torch.zeros(3, 2)
+    ref = ro.bpr_loss(u, p, n)
+    out = bpr_loss(u.to(DEV), p.to(DEV), n.to(DEV))
+    assert torch.isfinite(out) and abs(float(out) - float(ref)) < 1e-4
+
+
+def test_bpr_loss_rows_equals_index_select_path():
+    """The trainer's three index_selects fused in (src/trainer/lightgcn.py:395-399); users / items repeat."""
+    g = torch.Generator().manual_seed(3)
+    nu, ni, D, B = 300, 500, 64, 2048
+    U = torch.randn(nu, D, generator=g, requires_grad=True)
+    I = torch.randn(ni, D, generator=g, requires_grad=True)
+    users = torch.randint(0, nu, (B,), generator=g)
+    pos, neg = torch.randint(0, ni, (B,), generator=g), torch.randint(0, ni, (B,), generator=g)
+    ref = ro.bpr_loss(torch.index_select(U, 0, users), torch.index_select(I, 0, pos), torch.index_select(I, 0, neg))
+    ref.backward()
+    hU, hI = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    out = bpr_loss_rows(hU, hI, users.to(DEV), pos.to(DEV), neg.to(DEV))
+    out.backward()
+    assert_close(out, ref, 1e-5, 1e-6, "loss")
+    # duplicates are summed with float atomics (order varies): absolute floor for cancelling sums
+    assert_close(hU.grad, U.grad, 1e-4, 1e-7, "dU")
+    assert_close(hI.grad, I.grad, 1e-4, 1e-7, "dI")
+
+
+def _graph(nu, ni, gen, max_items=40):
+    return {u: torch.randperm(ni, generator=gen)[: int(torch.randint(0, max_items, (1,), generator=gen))].tolist()
+            for u in range(nu)}
+
+
+@pytest.mark.parametrize("nu,ni,B,k", [(50, 300, 17, 20), (200, 5000, 64, 20), (40, 25, 9, 20), (64, 38048, 32, 20),
+                                        (30, 1000, 30, 1), (30, 1000, 8, 256)])
+def test_score_topk_matches_reference_loop(nu, ni, B, k):
+    gen = torch.Generator().manual_seed(nu + ni + k)
+    D = 64
+    ue, ie = torch.randn(nu, D, generator=gen), torch.randn(ni, D, generator=gen)
+    graph = _graph(nu, ni, gen, max_items=min(40, max(1, ni - k)))
+    users = torch.randint(0, nu, (B,), generator=gen)
+    ref = ro.masked_topk(ue, ie, users, graph, k)
+    csr = train_items_csr(graph, nu, DEV)
+    got = score_topk(ue.to(DEV), ie.to(DEV), users.to(DEV), k, csr).cpu()
+    # integer output, but two scores closer than the fp32 dot-product error (different summation order on the
+    # MFMA path) may legitimately swap: wherever the indices differ the reference scores must be that close
+    scores = ue[users] @ ie.T
+    same = got == ref
+    if not bool(same.all()):
+        a = torch.gather(scores, 1, got)[~same]
+        b = torch.gather(scores, 1, ref)[~same]
+        assert_close(a, b, 1e-5, 1e-4, "swapped neighbours")
+    assert float(same.float().mean()) > 0.99
+    for i, u in enumerate(users.tolist()):                                  # no train item ever ranks
+        assert not set(got[i].tolist()) & set(graph[u])
+    no_filter = score_topk(ue.to(DEV), ie.to(DEV), users.to(DEV), k, None).cpu()
+    ref_nf = ro.masked_topk(ue, ie, users, graph, k, filter_item_on_train=False)
+    assert float((no_filter == ref_nf).float().mean()) > 0.99
+
+
+def test_topk_kernel_is_exact_on_given_scores_incl_ties_and_many_masked():
+    """The selection itself on identical floats: bit-exact vs torch.topk where scores are distinct; with
+    ties the order is score descending then index ascending; rows that are almost entirely -inf."""
+    gen = torch.Generator().manual_seed(1)
+    B, I, k = 12, 3000, 20
+    s = torch.randn(B, I, generator=gen)
+    s[3] = torch.round(s[3] * 2) / 2                                        # massive ties
+    s[4] = 0.0                                                              # all equal
+    s[5, 7:] = float("-inf")                                                # fewer finite entries than k
+    dev = s.to(DEV)
+    out = torch.empty(B, k, dtype=torch.int64, device=DEV)
+    val = torch.empty(B, k, device=DEV)
+    _lib.check(_lib.load().mi_mask_topk_rows(dev.data_ptr(), I, B, I, None, None, None, k, out.data_ptr(),
+                                             val.data_ptr(), _lib.stream_ptr(DEV)))
+    out, val = out.cpu(), val.cpu()
+    tv, ti = torch.topk(s, k)
+    assert torch.equal(val, tv)                                             # values always agree
+    distinct = [0, 1, 2, 6, 7, 8, 9, 10, 11]
+    assert torch.equal(out[distinct], ti[distinct])
+    for r in (3, 4, 5):                                                     # the stated total order
+        order = sorted(range(I), key=lambda j: (-float(s[r, j]), j))[:k]
+        assert out[r].tolist() == order
