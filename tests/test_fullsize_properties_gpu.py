@@ -129,3 +129,42 @@ def test_c5_adjointness_and_transposed_backward(yelp):
     assert_close(ATy, _kernels.spmm(A, y), 1e-4, 1e-5, "symmetric A: A^T y == A y")
     plan = _kernels.csr_plan(A)
     assert plan.long_rows.numel() > 0 and plan.pattern_symmetric
+
+
+def test_c4_billion_row_table_addressing():
+    """BASELINE config 4's table on ONE MI355X (288 GB HBM): N = 1e9 rows x 16 fp32 = 64 GB, element offsets far
+    beyond 2^31.  The table is never initialised as a whole (only the looked-up rows and their neighbours are
+    written), so the test costs milliseconds: gathered rows must be the planted rows bit for bit, the FM scalar
+    must match a float64 evaluation, and the row-form backward must address the same rows."""
+    free, _ = torch.cuda.mem_get_info()
+    N, D, B = 1_000_000_000, 16, 512
+    if free < (N * (D + 1) * 4) * 1.05:
+        pytest.skip("needs ~68 GB of free HBM")
+    gen = torch.Generator().manual_seed(44)
+    dims = [10, 1_000_000, N - 1_000_010 - 300_000_000, 300_000_000]
+    off = torch.tensor([0] + dims[:-1]).cumsum(0).view(1, -1).to(DEV)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+    x[0, 2], x[1, 3] = dims[2] - 1, dims[3] - 1                      # the last rows of the big fields (row N-1 included)
+    x = x.to(DEV)
+    rows = (x + off).view(-1)
+    assert int(rows.max()) == N - 1 and int(rows.max()) * D > 2 ** 33
+    W = torch.empty(N, D, device=DEV)
+    w1 = torch.empty(N, 1, device=DEV)
+    planted = (torch.rand(rows.numel(), D, generator=gen) - 0.5).to(DEV)
+    planted1 = torch.randn(rows.numel(), 1, generator=gen).to(DEV)
+    # duplicates: the last writer wins in both tensors consistently
+    W[rows] = planted
+    w1[rows] = planted1
+    want, want1 = W[rows], w1[rows]
+    bias = torch.tensor([0.1], device=DEV)
+    Wp, w1p = W.requires_grad_(True), w1.requires_grad_(True)
+    emb, yfm = _kernels.gather_fm(x, off, Wp, w1p, bias, sparse_W=True, sparse_w1=True)
+    assert torch.equal(emb.view(-1, D), want)
+    e64 = emb.double()
+    ref = 0.5 * (e64.sum(1).pow(2) - e64.pow(2).sum(1)).sum(1) + want1.double().view(B, -1).sum(1) + 0.1
+    assert_close(yfm.double(), ref, 1e-5, 1e-5, "FM at 64-bit offsets")
+    yfm.sum().backward()
+    assert torch.equal(Wp.grad._indices()[0], rows) and torch.equal(w1p.grad._indices()[0], rows)
+    _lib.check_index_errors()
+    del W, w1, Wp, w1p
+    torch.cuda.empty_cache()
