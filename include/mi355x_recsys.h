@@ -163,6 +163,22 @@ MI_API int mi_gather_rows_quant(const int64_t *idx, const void *W, int32_t qtype
                                 const float *scale, const void *bias, float *out, int64_t n,
                                 int32_t D, int64_t N, int32_t *err, void *stream);
 
+/* ---- §8f rank 4 (third flavour): quantisation-aware-training lookup -----------------------------
+ * QAT_EmbInt.forward = row gather + StotasticRounding (src/models/embeddings/qat_emb.py:16-45,117-119):
+ *   q = clamp(W[idx]/scale, q_min, q_max); out = (floor(q) + [u > floor(q) + 1 - q]) * scale,
+ *   q_min = -2^(n_bits-1), q_max = 2^(n_bits-1) - 1, scale a device scalar.
+ * u = prob[element] when prob != NULL (the reference's torch.rand_like draw, for parity tests), else the
+ * library's counter generator on (seed[0] + salt, element index) — the backward re-derives the same rounding.
+ * idx == NULL: rows 0..n-1 of W (rounding an already reduced bag).  Backward (:49-84): dW[idx] += g
+ * (float atomics into a caller-zeroed dense gradient; plain store when idx == NULL),
+ * dscale[0] += sum g * m, m = q_max | q_min at the clamps, else (rounded - W/scale).  dW / dscale nullable. */
+MI_API int mi_qat_gather_fwd(const int64_t *idx, const float *W, const float *scale, int32_t n_bits,
+                             const float *prob, const int64_t *seed, int64_t salt, float *out,
+                             int64_t n, int32_t D, int64_t N, int32_t *err, void *stream);
+MI_API int mi_qat_gather_bwd(const int64_t *idx, const float *W, const float *scale, int32_t n_bits,
+                             const float *prob, const int64_t *seed, int64_t salt, const float *g,
+                             float *dW, float *dscale, int64_t n, int32_t D, int64_t N, void *stream);
+
 /* ---- a11: CSR-pruned table rows (numba kernels K1/K2) ------------------------
  * src/models/embeddings/pruned_embedding.py:136-204: out[i,:] = dense row ids[i] of the
  * CSR matrix (values fp32, crow/col int64).  out fp32[n,D] need not be pre-zeroed.

@@ -326,3 +326,38 @@ def masked_topk(user_embs: torch.Tensor, item_embs: torch.Tensor, users: torch.T
             ind1.extend(graph[user])
         scores[ind0, ind1] = float("-inf")
     return torch.topk(scores, k)[1]
+
+
+# --------------------------------------------------------------------------- QAT (stochastic rounding)
+class _StochasticRounding(torch.autograd.Function):
+    """StotasticRounding — src/models/embeddings/qat_emb.py:16-84, with the torch.rand_like draw passed in."""
+
+    @staticmethod
+    def forward(ctx, scale, w, n_bits: int, prob):
+        q_min, q_max = -(1 << (n_bits - 1)), (1 << (n_bits - 1)) - 1
+        q_w_float = w / scale
+        q_w = torch.clamp(q_w_float, q_min, q_max)
+        q_w_floor = torch.floor(q_w)
+        prob_floor = q_w_floor + 1 - q_w
+        q_w = q_w_floor + (prob > prob_floor)
+        ctx.save_for_backward(q_w, q_w_float)
+        ctx.q = (q_min, q_max)
+        return q_w * scale
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        res, q_w = ctx.saved_tensors
+        q_min, q_max = ctx.q
+        scale_mask = torch.empty_like(grad_output)
+        mask1, mask2 = q_w >= q_max, q_w <= q_min
+        scale_mask[mask1] = q_max
+        scale_mask[mask2] = q_min
+        mask3 = torch.logical_and(~mask1, ~mask2)
+        scale_mask[mask3] = -(q_w[mask3] - res[mask3])
+        # autograd reduces the elementwise product to the scalar parameter's shape by summation
+        return (grad_output * scale_mask).sum().reshape(()), grad_output.clone(), None, None
+
+
+def qat_forward(idx: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, n_bits: int, prob: torch.Tensor):
+    """QAT_EmbInt.forward (qat_emb.py:117-119): nn.Embedding rows, then stochastic rounding."""
+    return _StochasticRounding.apply(scale, F.embedding(idx, weight), n_bits, prob)

@@ -77,7 +77,7 @@ class DeepFM(nn.Module):
 
     def _fm_and_embedding(self, x):
         emb_mod = self.embedding
-        if isinstance(emb_mod, VanillaEmbedding) and emb_mod._mode is None:
+        if type(emb_mod) is VanillaEmbedding and emb_mod._mode is None:      # subclasses (QAT) transform the rows
             return _kernels.gather_fm(
                 x, self.offsets, emb_mod.get_weight(), self.fc.weight, self._bias,
                 sparse_W=emb_mod.sparse_grad, sparse_w1=bool(self.fc.sparse),

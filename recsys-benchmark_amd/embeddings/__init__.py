@@ -3,7 +3,7 @@
 Same registry keys, same `get_embedding(embedding_config, field_dims, hidden_size,
 mode, field_name)` contract (config deep-copied, "name" popped and restored,
 `field_name` forwarded to pep*/cerp* classes).  Keys whose class is outside the
-hot-path scope (pep, optembed, qat, the FBTT CUDA extension) raise
+hot-path scope (the OptEmbed search classes, the FBTT CUDA extension) raise
 NotImplementedError with the reason instead of silently substituting something.
 """
 import copy
@@ -14,6 +14,7 @@ from .cerp_embedding import CerpEmbedding, RetrainCerpEmbedding
 from .dh_embedding import DHEmbedding
 from .pep_embedding import PepEmbeeding, RetrainPepEmbedding
 from .pruned_embedding import PrunedEmbedding
+from .qat_emb import QAT_EmbInt
 from .qr_embedding import QRHashingEmbedding
 from .tensortrain_embeddings import TTRecTorch
 
@@ -26,6 +27,7 @@ NAME_TO_CLS: Dict[str, type] = {
     "cerp": CerpEmbedding,
     "cerp_retrain": RetrainCerpEmbedding,
     "tt_emb_torch": TTRecTorch,
+    "qat": QAT_EmbInt,
 }
 
 # registry keys of the reference that this build deliberately does not cover
@@ -39,7 +41,6 @@ OUT_OF_SCOPE = {
     "deepfm_optembed_retrain": "OptEmbed search (SURVEY.md §2.1 #7)",
     "tt_emb": "FBTT-Embedding CUDA extension, not in the reference tree (SURVEY.md §2.3 K3-K12); "
               "use 'tt_emb_torch'",
-    "qat": "quantisation-aware training (SURVEY.md §2.1 #9)",
 }
 
 

@@ -235,6 +235,33 @@ def gen_ptq():
         save("ptq", **out)
 
 
+# ------------------------------------------------------------------ G3d: QAT (stochastic rounding)
+def gen_qat():
+    """QAT_EmbInt forward/backward with the torch.rand_like draw captured: the forward consumes exactly one
+    rand_like of the gathered rows' shape, so re-seeding and drawing the same shape reproduces it."""
+    from src.models.embeddings.qat_emb import QAT_EmbInt
+
+    gen = torch.Generator().manual_seed(41)
+    dims = [13, 29, 7]
+    N, D = sum(dims), 8
+    x = torch.randint(0, N, (6, 3), generator=gen)
+    for bits in (8, 16):
+        set_seed(2023)
+        emb = QAT_EmbInt(dims, D, None, n_bits=bits)
+        with torch.no_grad():
+            # push a few weights beyond the clamps so that both saturation branches of the backward are hit
+            emb._emb_module.weight[x[0, 0]] *= 40.0
+            emb._emb_module.weight[x[1, 1]] *= -40.0
+        torch.manual_seed(99)
+        o = emb(x)
+        torch.manual_seed(99)
+        prob = torch.rand(6, 3, D)
+        G = torch.randn(o.shape, generator=gen)
+        (o * G).sum().backward()
+        save(f"qat_int{bits}", field_dims=np.array(dims), hidden=np.array(D), n_bits=np.array(bits), x=x, prob=prob,
+             out=o, G=G, **params_of(emb), **grads_of(emb))
+
+
 # ------------------------------------------------------------------ G4: DHE
 def gen_dhe():
     gen = torch.Generator().manual_seed(13)
@@ -404,7 +431,7 @@ def gen_csr_pruned():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

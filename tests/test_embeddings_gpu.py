@@ -413,3 +413,69 @@ def test_ptq_known_codes(n_bits, tmp_path):      # tests/test_emb.py:529-561 of 
     assert (emb.weight == codes).all()
     out = emb.to(DEV)(torch.zeros(3, dtype=torch.long, device=DEV))
     assert out.cpu().isclose((codes * scale).expand(3, 8)).all()
+
+
+# ------------------------------------------------------------------ QAT (stochastic rounding)
+@pytest.mark.parametrize("name", ["qat_int8", "qat_int16"])
+def test_qat_matches_reference_golden(name):
+    g = load_golden(name)
+    bits = int(g["n_bits"])
+    emb = get_embedding({"name": "qat", "n_bits": bits}, g["field_dims"].tolist(), int(g["hidden"]))
+    assert set(emb.state_dict()) == {"_emb_module.weight", "scale"}
+    emb.load_state_dict({"_emb_module.weight": g.t("param/_emb_module.weight"), "scale": g.t("param/scale")})
+    emb.to(DEV)
+    out = emb(g.t("x").to(DEV), prob=g.t("prob").to(DEV))
+    assert_close(out, g.t("out"), 0, 0, "rounded rows (same draw): bit-exact")
+    (out * g.t("G").to(DEV)).sum().backward()
+    assert_close(emb._emb_module.weight.grad, g.t("grad/_emb_module.weight"), 1e-6, 1e-7, "row gradient")
+    # a sum of ~150 products of magnitude up to 127 * |G|: fp32 order
+    assert_close(emb.scale.grad, g.t("grad/scale"), 1e-5, 1e-4, "scale gradient")
+    assert torch.equal(emb.get_weight(), emb._emb_module.weight)
+
+
+def test_qat_initial_scale_and_rounding_statistics():
+    """scale init (qat_emb.py:111-115); with the library's own generator every output is one of the two grid
+    neighbours of w/scale, rounds up with probability frac(w/scale) (unbiased), exact values never move, and
+    the backward sees the same draw as the forward."""
+    torch.manual_seed(0)
+    emb = get_embedding({"name": "qat", "n_bits": 8}, [50, 30], 16).to(DEV)
+    W = emb._emb_module.weight.detach().clone()
+    assert_close(emb.scale.detach(), (W.max() - W.min()) / 255.0, 1e-6, 0, "scale init")
+    s = float(emb.scale.detach())
+    x = torch.randint(0, 80, (4096, 4), device=DEV)
+    q = W[x] / s
+    outs = torch.stack([emb(x).detach() for _ in range(64)])
+    lo, hi = torch.floor(q) * s, (torch.floor(q) + 1) * s
+    assert bool(((outs == lo) | (outs == hi)).all()), "only the two neighbouring grid points"
+    p_up = (outs == hi).float().mean(0)
+    assert float((p_up - (q - torch.floor(q))).abs().mean()) < 0.05          # 64 draws: sigma ~ 0.06 per element
+    assert abs(float((outs.mean(0) - W[x]).mean())) < 2e-3 * s, "unbiased on average"
+    assert float((outs[0] != outs[1]).float().mean()) > 0.2, "a fresh stream every forward"
+    with torch.no_grad():
+        emb._emb_module.weight.copy_(torch.round(W / s) * s)                  # already on the grid
+    on_grid = emb(x).detach()
+    assert_close(on_grid, emb._emb_module.weight.detach()[x], 1e-6, 1e-7, "grid points are fixed points")
+    # backward re-derives the forward's rounding: dscale = sum g * (rounded - w/scale) inside the clamps
+    with torch.no_grad():
+        emb._emb_module.weight.copy_(W)
+    out = emb(x)
+    G = torch.randn_like(out)
+    (out * G).sum().backward()
+    qf = W[x] / s
+    m = torch.where(qf >= 127, torch.full_like(qf, 127.0), torch.where(qf <= -128, torch.full_like(qf, -128.0),
+                                                                     out.detach() / s - qf))
+    want = (G * m).sum()
+    assert_close(emb.scale.grad, want, 1e-3, 1e-2, "scale gradient from the re-derived rounding")
+    dense = torch.zeros_like(W).index_add_(0, x.view(-1), G.view(-1, 16))
+    assert_close(emb._emb_module.weight.grad, dense, 1e-4, 1e-5, "straight-through rows")
+
+
+def test_qat_bag_mode_rounds_the_reduced_bag():
+    torch.manual_seed(1)
+    emb = get_embedding({"name": "qat", "n_bits": 16}, [40], 8, mode="sum").to(DEV)
+    x = torch.randint(0, 40, (9, 3), device=DEV)
+    prob = torch.rand(9, 8, device=DEV)
+    out = emb(x, prob=prob)
+    W, s = emb._emb_module.weight.detach().cpu(), emb.scale.detach().cpu()
+    ref = ro.qat_forward(torch.arange(9), W[x.cpu()].sum(1), s, 16, prob.cpu())
+    assert_close(out, ref, 1e-6, 1e-7, "bag then round")
