@@ -246,6 +246,11 @@ MI_API int mi_tt_bwd(const int64_t *idx, const float *g_out, const float *const 
  *     are skipped (the rows of a group are padded to whole tiles).
  *   mi_gemm_f32_k_groups: for each segment s: C[kseg[s][2]*sC ...][M,N] += A[k0:k0+K, :M]^T . B[k0:k0+K, :N]
  *     with (k0, K) = kseg[s][0:2], float atomics, C zeroed by the caller.
+ *   mi_tt_plan_level: counting sort of the lookups by digit[n] in [0, p), p <= 4096: pos[i] = first row of lookup i in the
+ *     level's layout (groups in digit order, each padded to whole 64-row tiles, H rows per lookup; order inside a
+ *     group unspecified), mtile_b[ntiles] = group of every row tile (-1 unused), kseg[nseg][3] = the groups' rows
+ *     cut into segments of <= seg rows, pbeg[p] = first row of every group.  ntiles >= ceil(n*H/64) + p,
+ *     nseg >= ceil(n*H/seg) + p; workspace: 2*p int32.
  *   mi_segment_sum: out[kseg[s][2]*ldo + j] += sum_{r<K} X[(k0+r)*ldx + j], j < width (core 0's gradient:
  *     the lookups sharing a first digit are consecutive rows).                                          */
 MI_API int mi_tt_digits(const int64_t *idx, int64_t n, int64_t N, const int32_t *p_shapes,
@@ -256,6 +261,22 @@ MI_API int mi_move_chunks(const float *src, const int64_t *src_row, int64_t src_
 MI_API int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, int32_t N,
                                   int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t transB,
                                   int64_t sB, const int32_t *mtile_b, void *stream);
+/*   mi_tt_last_fwd / mi_tt_last_bwd: the LAST level (rank 1 on the right, q = q_last output columns) without a GEMM:
+ *     out[l, h*q + j] = sum_k chunk_l[h, k] * core[digit[l]][k, j], chunk_l = src + src_row[l]*src_stride (H x K floats);
+ *     bwd: dst + dst_row[l]*dst_stride <- dchunk_l[h, k] = sum_j g[l, h*q+j] * core[digit[l]][k, j]   (dst nullable);
+ *          gcore[grp][k, j] += sum over each kseg segment (first, count, grp) of lookups order[first + r]   (gcore nullable,
+ *          caller-zeroed, float atomics).  H*q <= 64 and a divisor of 64, H*K <= 512, K*q <= 512.                                   */
+MI_API int mi_tt_last_fwd(const float *src, const int64_t *src_row, int64_t src_stride, const float *core,
+                          const int32_t *digit, const uint8_t *valid, int32_t H, int32_t K, int32_t q,
+                          float *out, int64_t n, void *stream);
+MI_API int mi_tt_last_bwd(const float *src, const int64_t *src_row, int64_t src_stride, const float *core,
+                          const int32_t *digit, const uint8_t *valid, int32_t H, int32_t K, int32_t q,
+                          const float *g, float *dst, const int64_t *dst_row, int64_t dst_stride,
+                          const int64_t *order, const int64_t *kseg, int32_t nseg, float *gcore,
+                          int64_t n, void *stream);
+MI_API int mi_tt_plan_level(const int32_t *digit, int64_t n, int32_t p, int32_t H, int32_t seg,
+                            int32_t *workspace, int64_t *pbeg, int64_t *pos, int32_t *mtile_b,
+                            int32_t ntiles, int64_t *kseg, int32_t nseg, void *stream);
 MI_API int mi_segment_sum(const float *X, int64_t ldx, int32_t width, const int64_t *kseg,
                           int32_t nseg, float *out, int64_t ldo, void *stream);
 MI_API int mi_gemm_f32_k_groups(const float *A, const float *B, float *C, int32_t M, int32_t N,

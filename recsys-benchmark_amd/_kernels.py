@@ -620,6 +620,7 @@ _TT_SEG = 2048           # reduction rows per slice-gradient segment (long group
 _TT_SEG0 = 256           # rows per segment of core 0's gradient sum
 _TT_GROUPED_MIN = 4096   # below this many lookups the sort / planning launches cost more than they save
 _TT_MAX_TILES = 65535    # gridDim.y
+_TT_PLAN_MAX_P = 4096    # digits per level the device planner handles (beyond: torch sort / searchsorted)
 
 
 class _TTLevelPlan:
@@ -629,6 +630,21 @@ class _TTLevelPlan:
 
     def __init__(self, digit: torch.Tensor, H: int, p: int, seg: int):
         dev, n = digit.device, digit.numel()
+        if p <= _TT_PLAN_MAX_P:
+            # counting sort on the device: 3 launches instead of ~25 torch ops
+            self.ntiles = (n * H + _TT_TILE - 1) // _TT_TILE + p
+            self.mpad = self.ntiles * _TT_TILE
+            self.nseg = (n * H + seg - 1) // seg + p
+            ws = torch.empty(2 * p, dtype=torch.int32, device=dev)
+            pbeg = torch.empty(p, dtype=torch.int64, device=dev)
+            self.pos = torch.empty(n, dtype=torch.int64, device=dev)
+            self.mtile_b = torch.empty(self.ntiles, dtype=torch.int32, device=dev)
+            self.kseg = torch.empty((self.nseg, 3), dtype=torch.int64, device=dev)
+            _lib.check(_lib.load().mi_tt_plan_level(digit.data_ptr(), n, p, H, seg, ws.data_ptr(), pbeg.data_ptr(),
+                                                    self.pos.data_ptr(), self.mtile_b.data_ptr(), self.ntiles,
+                                                    self.kseg.data_ptr(), self.nseg, _lib.stream_ptr(dev)),
+                       "mi_tt_plan_level")
+            return
         sorted_d, perm = torch.sort(digit, stable=True)
         bounds = torch.searchsorted(sorted_d, torch.arange(p + 1, device=dev, dtype=digit.dtype))   # [p+1]
         starts, cnt = bounds[:-1], bounds[1:] - bounds[:-1]
@@ -682,8 +698,15 @@ def tt_grouped_supported(n: int, q_shapes, ranks) -> bool:
     return H % 4 == 0
 
 
+def _tt_last_fast(H: int, K: int, q: int) -> bool:
+    """The last level (rank 1 on the right) has a dedicated kernel when its H*q outputs tile a wave."""
+    D = H * q
+    return D <= 64 and 64 % D == 0 and K * q <= 512 and H * K <= 512
+
+
 class TTLookupGrouped(torch.autograd.Function):
-    """out[n, D] = TT-Rec rows, every level as GEMMs grouped by that level's digit."""
+    """out[n, D] = TT-Rec rows: levels 1..n-2 as GEMMs grouped by that level's digit, the last level (q_last
+    columns wide) by its own kernel straight from the previous level's layout."""
 
     @staticmethod
     def forward(ctx, idx, num_item: int, p_shapes, q_shapes, ranks, *cores):
@@ -701,15 +724,20 @@ class TTLookupGrouped(torch.autograd.Function):
         for q in q_shapes:
             Hs.append(Hs[-1] * q)                                   # Hs[c] = rows per lookup entering level c
         D = Hs[-1]
-        plans = {c: _TTLevelPlan(digits[c], Hs[c], p_shapes[c], _TT_SEG) for c in range(1, nc)}
+        last = nc - 1
+        fast_last = _tt_last_fast(Hs[last], ranks[last], q_shapes[last])
+        gemm_levels = list(range(1, last if fast_last else nc))
+        plans = {c: _TTLevelPlan(digits[c], Hs[c], p_shapes[c], _TT_SEG) for c in gemm_levels}
         d0 = digits[0].to(torch.int64)
-        # level 1 operand: core 0's slices [q_0, r_1] dropped into level 1's layout
         w0 = q_shapes[0] * ranks[1]
-        A = torch.empty((plans[1].mpad, ranks[1]), dtype=torch.float32, device=dev)
-        _move(cs[0], d0, w0, A, plans[1].pos, ranks[1], w0, n, mask=valid)
-        saved_A = []
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
-        for c in range(1, nc):
+        saved_A = []
+        src, src_row, src_stride = cs[0], d0, w0                    # where the next level finds a lookup's rows
+        if gemm_levels:
+            # level 1 operand: core 0's slices [q_0, r_1] dropped into level 1's layout
+            A = torch.empty((plans[1].mpad, ranks[1]), dtype=torch.float32, device=dev)
+            _move(cs[0], d0, w0, A, plans[1].pos, ranks[1], w0, n, mask=valid)
+        for c in gemm_levels:
             K, Nn = ranks[c], q_shapes[c] * ranks[c + 1]
             C = torch.empty((plans[c].mpad, Nn), dtype=torch.float32, device=dev)
             _lib.check(lib.mi_gemm_f32_row_groups(A.data_ptr(), cs[c].data_ptr(), C.data_ptr(), plans[c].mpad, Nn, K,
@@ -717,21 +745,27 @@ class TTLookupGrouped(torch.autograd.Function):
                        "mi_gemm_f32_row_groups")
             saved_A.append(A)
             width = Hs[c] * Nn                                      # a lookup's rows, contiguous
-            if c + 1 < nc:
+            if c + 1 in plans:
                 A = torch.empty((plans[c + 1].mpad, ranks[c + 1]), dtype=torch.float32, device=dev)
                 _move(C, plans[c].pos, Nn, A, plans[c + 1].pos, ranks[c + 1], width, n)
-            else:
+            elif c == last:
                 _move(C, plans[c].pos, Nn, out, None, D, width, n)
-        ctx.save_for_backward(d0, valid, *cs, *saved_A)
+            else:
+                src, src_row, src_stride = C, plans[c].pos, Nn      # feeds the last level where it lies
+        if fast_last:
+            _lib.check(lib.mi_tt_last_fwd(src.data_ptr(), src_row.data_ptr(), src_stride, cs[last].data_ptr(),
+                                          digits[last].data_ptr(), valid.data_ptr(), Hs[last], ranks[last],
+                                          q_shapes[last], out.data_ptr(), n, stream), "mi_tt_last_fwd")
+        ctx.save_for_backward(digits, valid, src if fast_last else digits, *cs, *saved_A)
         ctx.plans = plans
-        ctx.meta = (num_item, list(p_shapes), list(q_shapes), list(ranks), Hs, n)
+        ctx.meta = (num_item, list(p_shapes), list(q_shapes), list(ranks), Hs, n, fast_last)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        num_item, p_shapes, q_shapes, ranks, Hs, n = ctx.meta
+        num_item, p_shapes, q_shapes, ranks, Hs, n, fast_last = ctx.meta
         nc = len(p_shapes)
-        d0, valid, *rest = ctx.saved_tensors
+        digits, valid, last_src, *rest = ctx.saved_tensors
         cs, As = rest[:nc], rest[nc:]
         plans = ctx.plans
         dev = g.device
@@ -741,10 +775,41 @@ class TTLookupGrouped(torch.autograd.Function):
         D = Hs[-1]
         gcs = [torch.zeros_like(c) for c in cs]
         last = nc - 1
-        N_last = q_shapes[last] * ranks[last + 1]
-        dC = torch.empty((plans[last].mpad, N_last), dtype=torch.float32, device=dev)
-        _move(g, None, D, dC, plans[last].pos, N_last, D, n, mask=valid)
-        for c in range(last, 0, -1):
+        d0 = digits[0].to(torch.int64)
+        w0 = q_shapes[0] * ranks[1]
+        plan0 = X = None
+
+        def level0_buffer():
+            # core 0's gradient: the lookups ordered by their first digit, each group's rows summed
+            nonlocal plan0, X
+            plan0 = _TTLevelPlan(digits[0], 1, p_shapes[0], _TT_SEG0)
+            X = torch.empty((plan0.mpad, w0), dtype=torch.float32, device=dev)
+
+        dC = None
+        if fast_last:
+            H, K, q = Hs[last], ranks[last], q_shapes[last]
+            planL = _TTLevelPlan(digits[last], 1, p_shapes[last], 16)          # digit order, <= 16 lookups per wave
+            order = torch.empty(planL.mpad, dtype=torch.int64, device=dev)
+            order[planL.pos] = torch.arange(n, device=dev)
+            if nc == 2:
+                level0_buffer()
+                src_row, src_stride, dst, dst_row, dst_stride = d0, w0, X, plan0.pos, w0
+            else:
+                Np = q_shapes[last - 1] * ranks[last]
+                dC = torch.empty((plans[last - 1].mpad, Np), dtype=torch.float32, device=dev)
+                src_row, src_stride, dst, dst_row, dst_stride = plans[last - 1].pos, Np, dC, plans[last - 1].pos, Np
+            _lib.check(lib.mi_tt_last_bwd(last_src.data_ptr(), src_row.data_ptr(), src_stride, cs[last].data_ptr(),
+                                          digits[last].data_ptr(), valid.data_ptr(), H, K, q, g.data_ptr(),
+                                          dst.data_ptr(), dst_row.data_ptr(), dst_stride, order.data_ptr(),
+                                          planL.kseg.data_ptr(), planL.nseg, gcs[last].data_ptr(), n, stream),
+                       "mi_tt_last_bwd")
+            top = last - 1
+        else:
+            N_last = q_shapes[last] * ranks[last + 1]
+            dC = torch.empty((plans[last].mpad, N_last), dtype=torch.float32, device=dev)
+            _move(g, None, D, dC, plans[last].pos, N_last, D, n, mask=valid)
+            top = last
+        for c in range(top, 0, -1):
             K, Nn = ranks[c], q_shapes[c] * ranks[c + 1]
             A = As[c - 1]
             # slice gradients: gcore_c[i] += A_rows(i)^T . dC_rows(i)
@@ -761,13 +826,11 @@ class TTLookupGrouped(torch.autograd.Function):
                 dC = torch.empty((plans[c - 1].mpad, Np), dtype=torch.float32, device=dev)
                 _move(dA, plans[c].pos, K, dC, plans[c - 1].pos, Np, width, n)
             else:
-                # core 0: order the lookups by their first digit and sum each group's rows
-                w0 = q_shapes[0] * ranks[1]
-                plan0 = _TTLevelPlan(d0.to(torch.int32), 1, p_shapes[0], _TT_SEG0)
-                X = torch.empty((plan0.mpad, w0), dtype=torch.float32, device=dev)
+                level0_buffer()
                 _move(dA, plans[1].pos, K, X, plan0.pos, w0, w0, n, mask=valid)
-                _lib.check(lib.mi_segment_sum(X.data_ptr(), w0, w0, plan0.kseg.data_ptr(), plan0.nseg,
-                                              gcs[0].data_ptr(), w0, stream), "mi_segment_sum")
+        if X is not None:
+            _lib.check(lib.mi_segment_sum(X.data_ptr(), w0, w0, plan0.kseg.data_ptr(), plan0.nseg,
+                                          gcs[0].data_ptr(), w0, stream), "mi_segment_sum")
         return (None, None, None, None, None, *gcs)
 
 

@@ -101,9 +101,353 @@ __global__ __launch_bounds__(kBlock) void k_segment_sum(const float *__restrict_
   atomicAdd(out + g * ldo + col, (a0 + a1) + (a2 + a3));
 }
 
+// ---- the LAST level (r_{n} = 1): res[(l,h), j] = sum_k chunk_l[h, k] * core[i(l)][k, j], j < q ------------
+// Only q (2..4) output columns: as a GEMM its 64-wide tiles are 15/16 padding.  Here one wave owns a lookup:
+// its chunk (H x K floats, contiguous in the previous level's layout) and its core slice (K x q floats, the
+// whole last core is ~200 KB and stays in L2) are staged in a wave-private LDS slab, the H*q = D outputs are
+// D lanes x (64/D) partial sums over k joined by shuffles.  No ordering of the lookups is needed forward; the
+// slice gradient walks the lookups in digit order (segments of <= 64) and keeps K*q partial sums in registers.
+struct LastArgs {
+  const float *src;          // chunks: src + src_row[l] * src_stride, H*K floats each
+  const int64_t *src_row;
+  int64_t src_stride;
+  const float *core;         // [p, K, q]
+  const int32_t *digit;      // [n]
+  const uint8_t *valid;      // nullable
+  int H, K, q;
+  int64_t n;
+};
+
+constexpr int kLastMaxU = 8;   // K*q <= 512 partial sums per wave in the slice gradient
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kLastRegs = 8;   // floats per lane of a staged chunk / slice: H*K, K*q <= 512
+
+// stage `count` floats of a contiguous run into registers (lane-strided), clamped to the run
+__device__ __forceinline__ void fetch_run(const float *__restrict__ p, int count, int lane, bool live, float (&r)[kLastRegs]) {
+#pragma unroll
+  for (int u = 0; u < kLastRegs; ++u) {
+    const int e = lane + u * kWave;
+    r[u] = (live && e < count) ? p[e] : 0.f;
+  }
+}
+__device__ __forceinline__ void spill_run(float *lds, int count, int lane, const float (&r)[kLastRegs]) {
+#pragma unroll
+  for (int u = 0; u < kLastRegs; ++u) {
+    const int e = lane + u * kWave;
+    if (e < count) lds[e] = r[u];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tt_last_fwd(LastArgs a, float *__restrict__ out) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int HK = a.H * a.K, Kq = a.K * a.q, D = a.H * a.q;
+  float *c = lds + wv * (HK + Kq), *sl = c + HK;
+  const int o = lane % D, kp = lane / D, KP = kWave / D;
+  const int h = o / a.q, j = o - h * a.q;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  // the next lookup's rows travel to registers while the current one is contracted out of LDS
+  float rc[kLastRegs], rs[kLastRegs];
+  if (wave0 < a.n) {
+    const bool ok = !a.valid || a.valid[wave0];
+    fetch_run(a.src + a.src_row[wave0] * a.src_stride, HK, lane, ok, rc);
+    fetch_run(a.core + (int64_t)a.digit[wave0] * Kq, Kq, lane, true, rs);
+  }
+  for (int64_t l = wave0; l < a.n; l += nwaves) {
+    spill_run(c, HK, lane, rc);
+    spill_run(sl, Kq, lane, rs);
+    wave_lds_sync();
+    const int64_t ln = l + nwaves < a.n ? l + nwaves : l;      // (the last iteration re-fetches itself: no branch)
+    const bool okn = !a.valid || a.valid[ln];
+    fetch_run(a.src + a.src_row[ln] * a.src_stride, HK, lane, okn, rc);
+    fetch_run(a.core + (int64_t)a.digit[ln] * Kq, Kq, lane, true, rs);
+    float acc = 0.f;
+    for (int k = kp; k < a.K; k += KP) acc += c[h * a.K + k] * sl[k * a.q + j];
+    for (int m = D; m < kWave; m <<= 1) acc += __shfl_xor(acc, m);
+    if (kp == 0) out[l * D + o] = acc;
+    wave_lds_sync();
+  }
+}
+
+// dchunk_l[h, k] = sum_j g[l, h*q + j] * core[i(l)][k, j]  -> dst + dst_row[l] * dst_stride
+__global__ __launch_bounds__(kBlock) void k_tt_last_bwd_in(LastArgs a, const float *__restrict__ g,
+                                                           float *__restrict__ dst,
+                                                           const int64_t *__restrict__ dst_row,
+                                                           int64_t dst_stride) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int HK = a.H * a.K, Kq = a.K * a.q, D = a.H * a.q;
+  float *sl = lds + wv * (Kq + D), *gl = sl + Kq;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t l = wave0; l < a.n; l += nwaves) {
+    const bool ok = !a.valid || a.valid[l];
+    const float *S = a.core + (int64_t)a.digit[l] * Kq;
+    for (int e = lane; e < Kq; e += kWave) sl[e] = S[e];
+    for (int e = lane; e < D; e += kWave) gl[e] = ok ? g[l * D + e] : 0.f;
+    wave_lds_sync();
+    float *d = dst + dst_row[l] * dst_stride;
+    for (int e = lane; e < HK; e += kWave) {
+      const int h = e / a.K, k = e - h * a.K;
+      float v = 0.f;
+      for (int j = 0; j < a.q; ++j) v += gl[h * a.q + j] * sl[k * a.q + j];
+      d[e] = v;
+    }
+    wave_lds_sync();
+  }
+}
+
+// gcore[group][k, j] += sum over the segment's lookups l, sum_h chunk_l[h, k] * g[l, h*q + j]
+// one wave per segment (first sorted position, count, group); order[] maps sorted positions to lookups
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_tt_last_bwd_core(LastArgs a, const float *__restrict__ g,
+                                                             const int64_t *__restrict__ order,
+                                                             const long long *__restrict__ kseg, int nseg,
+                                                             float *__restrict__ gcore) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int HK = a.H * a.K, Kq = a.K * a.q, D = a.H * a.q;
+  float *c = lds + wv * (HK + D), *gl = c + HK;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t sgi = wave0; sgi < nseg; sgi += nwaves) {
+    const long long first = kseg[sgi * 3], cnt = kseg[sgi * 3 + 1], grp = kseg[sgi * 3 + 2];
+    if (cnt <= 0) continue;
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.f;
+    float rc[kLastRegs], rg;
+    {
+      const int64_t l = order[first];
+      fetch_run(a.src + a.src_row[l] * a.src_stride, HK, lane, !a.valid || a.valid[l], rc);
+      rg = lane < D ? g[l * D + lane] : 0.f;
+    }
+    for (long long r = 0; r < cnt; ++r) {
+      spill_run(c, HK, lane, rc);
+      if (lane < D) gl[lane] = rg;
+      wave_lds_sync();
+      const int64_t ln = order[first + (r + 1 < cnt ? r + 1 : r)];
+      fetch_run(a.src + a.src_row[ln] * a.src_stride, HK, lane, !a.valid || a.valid[ln], rc);
+      rg = lane < D ? g[ln * D + lane] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = lane + u * kWave;
+        if (e < Kq) {
+          const int k = e / a.q, j = e - k * a.q;
+          float v = 0.f;
+          for (int h = 0; h < a.H; ++h) v += c[h * a.K + k] * gl[h * a.q + j];
+          acc[u] += v;
+        }
+      }
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = lane + u * kWave;
+      if (e < Kq) atomicAdd(gcore + grp * Kq + e, acc[u]);
+    }
+  }
+}
+
+inline int last_check(LastArgs &a, const float *src, const int64_t *src_row, int64_t src_stride, const float *core,
+                      const int32_t *digit, const uint8_t *valid, int H, int K, int q, int64_t n) {
+  if (n < 0 || H < 1 || K < 1 || q < 1 || src_stride < 0) return MI_ERR_INVALID_ARG;
+  if (n > 0 && (!src || !src_row || !core || !digit)) return MI_ERR_INVALID_ARG;
+  const int D = H * q;
+  if (D > kWave || (kWave % D) != 0 || K * q > kLastMaxU * kWave || H * K > kLastRegs * kWave) return MI_ERR_UNSUPPORTED;
+  a.src = src; a.src_row = src_row; a.src_stride = src_stride; a.core = core; a.digit = digit; a.valid = valid;
+  a.H = H; a.K = K; a.q = q; a.n = n;
+  return MI_OK;
+}
+
+// ---- level planner: a counting sort by digit, all on the device --------------------------------------
+// digit[n] in [0, p) -> for every lookup its first row in the level's layout (groups in digit order, each
+// padded to whole 64-row tiles, H rows per lookup), the B slice of every row tile, and the reduction
+// segments of every group.  Order inside a group is arrival order of the atomics (any order is valid: rows
+// of a group are independent in the level GEMM and summed in the slice gradient).
+constexpr int kPlanMaxP = 4096;
+constexpr int kPlanTile = 64;
+
+__global__ __launch_bounds__(kBlock) void k_plan_count(const int32_t *__restrict__ digit, int64_t n, int p,
+                                                       int32_t *__restrict__ counts) {
+  extern __shared__ int hist[];
+  for (int g = threadIdx.x; g < p; g += blockDim.x) hist[g] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&hist[digit[i]], 1);
+  __syncthreads();
+  for (int g = threadIdx.x; g < p; g += blockDim.x)
+    if (hist[g]) atomicAdd(counts + g, hist[g]);
+}
+
+// one workgroup of 1024 threads: scans over the p groups, tile map, segment table; zeroes the cursors
+__global__ __launch_bounds__(1024) void k_plan_scan(const int32_t *__restrict__ counts, int p, int H, int seg,
+                                                    int64_t *__restrict__ pbeg, int32_t *__restrict__ cursor,
+                                                    int32_t *__restrict__ mtile_b, int ntiles,
+                                                    long long *__restrict__ kseg, int nseg) {
+  __shared__ long long scan_a[kPlanMaxP], scan_b[kPlanMaxP];   // padded rows / segment counts (inclusive)
+  const int t = threadIdx.x;
+  for (int g = t; g < p; g += 1024) {
+    const long long rows = (long long)counts[g] * H;
+    scan_a[g] = (rows + kPlanTile - 1) / kPlanTile * kPlanTile;
+    scan_b[g] = (rows + seg - 1) / seg;
+    cursor[g] = 0;
+  }
+  for (int j = t; j < ntiles; j += 1024) mtile_b[j] = -1;
+  for (int j = t; j < nseg; j += 1024) { kseg[j * 3] = 0; kseg[j * 3 + 1] = 0; kseg[j * 3 + 2] = 0; }
+  __syncthreads();
+  // inclusive scans (Hillis-Steele over <= 4096 entries, 4 per thread)
+  for (int d = 1; d < p; d <<= 1) {
+    long long va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = t + u * 1024;
+      va[u] = (g < p && g >= d) ? scan_a[g - d] : 0;
+      vb[u] = (g < p && g >= d) ? scan_b[g - d] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = t + u * 1024;
+      if (g < p) { scan_a[g] += va[u]; scan_b[g] += vb[u]; }
+    }
+    __syncthreads();
+  }
+  for (int g = t; g < p; g += 1024) {
+    const long long rows = (long long)counts[g] * H;
+    const long long rpad = (rows + kPlanTile - 1) / kPlanTile * kPlanTile;
+    const long long beg = scan_a[g] - rpad;
+    pbeg[g] = beg;
+    for (long long j = 0; j < rpad / kPlanTile; ++j) mtile_b[beg / kPlanTile + j] = g;
+    const long long chunks = (rows + seg - 1) / seg, c0 = scan_b[g] - chunks;
+    for (long long j = 0; j < chunks; ++j) {
+      const long long k0 = j * seg;
+      kseg[(c0 + j) * 3] = beg + k0;
+      kseg[(c0 + j) * 3 + 1] = (rows - k0 < seg) ? rows - k0 : seg;
+      kseg[(c0 + j) * 3 + 2] = g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_plan_assign(const int32_t *__restrict__ digit, int64_t n, int p, int H,
+                                                        const int64_t *__restrict__ pbeg,
+                                                        int32_t *__restrict__ cursor,
+                                                        int64_t *__restrict__ pos) {
+  extern __shared__ int sh[];          // [p] local counts, then [p] bases
+  int *cnt = sh, *base = sh + p;
+  for (int g = threadIdx.x; g < p; g += blockDim.x) cnt[g] = 0;
+  __syncthreads();
+  // each workgroup owns one contiguous chunk of lookups: rank inside the chunk, then one global reservation
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  for (int64_t i0 = lo; i0 < hi; i0 += blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
+    if (i < hi) pos[i] = atomicAdd(&cnt[digit[i]], 1);          // local rank, finalised below
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < p; g += blockDim.x) base[g] = cnt[g] ? atomicAdd(cursor + g, cnt[g]) : 0;
+  __syncthreads();
+  for (int64_t i0 = lo; i0 < hi; i0 += blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
+    if (i < hi) {
+      const int g = digit[i];
+      pos[i] = pbeg[g] + (int64_t)(base[g] + (int)pos[i]) * H;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mi_tt_last_fwd(const float *src, const int64_t *src_row, int64_t src_stride, const float *core,
+                   const int32_t *digit, const uint8_t *valid, int32_t H, int32_t K, int32_t q, float *out,
+                   int64_t n, void *stream) {
+  LastArgs a;
+  const int rc = last_check(a, src, src_row, src_stride, core, digit, valid, H, K, q, n);
+  if (rc != MI_OK) return rc;
+  if (n == 0) return MI_OK;
+  if (!out) return MI_ERR_INVALID_ARG;
+  const size_t lds = sizeof(float) * kWavesPerBlock * (size_t)(H * K + K * q);
+  hipEvent_t ea, eb;
+  if (mi::prof_acquire("tt_last_fwd", &ea, &eb))
+    hipExtLaunchKernelGGL(k_tt_last_fwd, dim3(grid_for_waves(n)), dim3(kBlock), lds, (hipStream_t)stream, ea, eb, 0, a, out);
+  else
+    hipLaunchKernelGGL(k_tt_last_fwd, dim3(grid_for_waves(n)), dim3(kBlock), lds, (hipStream_t)stream, a, out);
+  return launch_status();
+}
+
+int mi_tt_last_bwd(const float *src, const int64_t *src_row, int64_t src_stride, const float *core,
+                   const int32_t *digit, const uint8_t *valid, int32_t H, int32_t K, int32_t q, const float *g,
+                   float *dst, const int64_t *dst_row, int64_t dst_stride, const int64_t *order,
+                   const int64_t *kseg, int32_t nseg, float *gcore, int64_t n, void *stream) {
+  LastArgs a;
+  const int rc = last_check(a, src, src_row, src_stride, core, digit, valid, H, K, q, n);
+  if (rc != MI_OK) return rc;
+  if (n == 0) return MI_OK;
+  if (!g) return MI_ERR_INVALID_ARG;
+  const hipStream_t st = (hipStream_t)stream;
+  hipEvent_t ea, eb;
+  if (dst) {   // input gradient, written in the previous level's layout
+    if (!dst_row) return MI_ERR_INVALID_ARG;
+    const size_t lds = sizeof(float) * kWavesPerBlock * (size_t)(K * q + H * q);
+    if (mi::prof_acquire("tt_last_bwd_in", &ea, &eb))
+      hipExtLaunchKernelGGL(k_tt_last_bwd_in, dim3(grid_for_waves(n)), dim3(kBlock), lds, st, ea, eb, 0, a, g, dst, dst_row, dst_stride);
+    else
+      hipLaunchKernelGGL(k_tt_last_bwd_in, dim3(grid_for_waves(n)), dim3(kBlock), lds, st, a, g, dst, dst_row, dst_stride);
+  }
+  if (gcore) {  // slice gradients, lookups walked in digit order
+    if (!order || !kseg || nseg < 0) return MI_ERR_INVALID_ARG;
+    const size_t lds = sizeof(float) * kWavesPerBlock * (size_t)(H * K + H * q);
+    const int U = (K * q + kWave - 1) / kWave;
+    const dim3 grid(grid_for_waves(nseg));
+    const long long *ks = reinterpret_cast<const long long *>(kseg);
+    const bool prof = mi::prof_acquire("tt_last_bwd_core", &ea, &eb);
+#define GO(UU)                                                                                              \
+  do {                                                                                                      \
+    if (prof) hipExtLaunchKernelGGL((k_tt_last_bwd_core<UU>), grid, dim3(kBlock), lds, st, ea, eb, 0, a, g, order, ks, nseg, gcore); \
+    else hipLaunchKernelGGL((k_tt_last_bwd_core<UU>), grid, dim3(kBlock), lds, st, a, g, order, ks, nseg, gcore);  \
+  } while (0)
+    switch (U) {
+      case 1: GO(1); break;
+      case 2: GO(2); break;
+      case 3: GO(3); break;
+      case 4: GO(4); break;
+      case 5: GO(5); break;
+      case 6: GO(6); break;
+      case 7: GO(7); break;
+      default: GO(8); break;
+    }
+#undef GO
+  }
+  return launch_status();
+}
+
+int mi_tt_plan_level(const int32_t *digit, int64_t n, int32_t p, int32_t H, int32_t seg, int32_t *workspace,
+                     int64_t *pbeg, int64_t *pos, int32_t *mtile_b, int32_t ntiles, int64_t *kseg,
+                     int32_t nseg, void *stream) {
+  if (n < 0 || p < 1 || H < 1 || seg < 1 || ntiles < 0 || nseg < 0) return MI_ERR_INVALID_ARG;
+  if (p > kPlanMaxP) return MI_ERR_UNSUPPORTED;
+  if (!workspace || !pbeg || !mtile_b || !kseg || (n > 0 && (!digit || !pos))) return MI_ERR_INVALID_ARG;
+  // the caller sized the tables for the worst case: every group wastes less than one tile / segment
+  if ((int64_t)ntiles < (n * H + kPlanTile - 1) / kPlanTile + p || (int64_t)nseg < (n * H + seg - 1) / seg + p)
+    return MI_ERR_INVALID_ARG;
+  int32_t *counts = workspace, *cursor = workspace + p;
+  if (hipMemsetAsync(counts, 0, sizeof(int32_t) * p, (hipStream_t)stream) != hipSuccess) return MI_ERR_LAUNCH;
+  int64_t g = (n + 1023) / 1024;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  const hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_plan_count, dim3((int)g), dim3(kBlock), sizeof(int) * p, st, digit, n, p, counts);
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, counts, p, H, seg, pbeg, cursor, mtile_b, ntiles,
+                     reinterpret_cast<long long *>(kseg), nseg);
+  hipLaunchKernelGGL(k_plan_assign, dim3((int)g), dim3(kBlock), sizeof(int) * 2 * p, st, digit, n, p, H, pbeg, cursor, pos);
+  return launch_status();
+}
 
 int mi_segment_sum(const float *X, int64_t ldx, int32_t width, const int64_t *kseg, int32_t nseg,
                    float *out, int64_t ldo, void *stream) {

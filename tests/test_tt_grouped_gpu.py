@@ -104,3 +104,32 @@ def test_get_weight_goes_through_in_pieces(monkeypatch):
     ref = ro.tt_forward(torch.arange(N), emb.tt_p_shapes, emb.tt_q_shapes, emb.tt_ranks,
                         [c.detach().cpu() for c in emb.tt_cores])
     assert_close(full, ref, 1e-4, 1e-5, "get_weight")
+
+
+def test_device_planner_and_torch_planner_agree(monkeypatch):
+    """The counting-sort planner (mi_tt_plan_level) and the torch sort / searchsorted planner describe the same
+    layout: identical tile map and segment table, and the same multiset of rows per group (order inside a
+    group is free); the lookup result is the same either way."""
+    gen = torch.Generator().manual_seed(2)
+    n, p, H, seg = 5000, 37, 2, 256
+    digit = (37 * torch.rand(n, generator=gen) ** 3).to(torch.int32).clamp_(0, p - 1).to(DEV)
+    dev_plan = _kernels._TTLevelPlan(digit, H, p, seg)
+    monkeypatch.setattr(_kernels, "_TT_PLAN_MAX_P", 0)
+    ref_plan = _kernels._TTLevelPlan(digit, H, p, seg)
+    assert dev_plan.ntiles == ref_plan.ntiles and dev_plan.nseg == ref_plan.nseg
+    assert torch.equal(dev_plan.mtile_b, ref_plan.mtile_b)
+    live = ref_plan.kseg[:, 1] > 0
+    assert torch.equal(dev_plan.kseg[live], ref_plan.kseg[live]) and not bool(dev_plan.kseg[~live][:, 1].any())
+    for g in range(p):
+        a = torch.sort(dev_plan.pos[digit == g])[0]
+        b = torch.sort(ref_plan.pos[digit == g])[0]
+        assert torch.equal(a, b), f"group {g}"
+    N = 20000
+    emb, gen2 = _emb(N, [16, 8], [10, 50, 40], [2, 2, 4], 9)
+    emb.to(DEV)
+    idx = torch.randint(0, N, (6000,), generator=gen2).to(DEV)
+    with torch.no_grad():
+        a = emb(idx)
+        monkeypatch.setattr(_kernels, "_TT_PLAN_MAX_P", 4096)
+        b = emb(idx)
+    assert_close(a, b, 1e-6, 1e-7, "planner does not change the lookup")
