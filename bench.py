@@ -118,13 +118,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     import torch.distributed as dist
 
+    # Rehearsal knobs (NOT a measurement mode): MI_BENCH_REHEARSE=1 runs N ranks on ONE GPU with gloo carrying the
+    # collectives (RCCL refuses two ranks on a device), to exercise the N>1 launch contract on a 1-GPU box.
+    rehearse = os.environ.get("MI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.sharded
     if sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import recsys_benchmark_amd as pkg
     from recsys_benchmark_amd.profiling import KernelTimer
@@ -138,7 +146,7 @@ def main():
         from recsys_benchmark_amd.sharded import ShardedDeepFM
 
         model = ShardedDeepFM(dims, D, hidden, p_dropout=p_drop, use_batchnorm=True, device=dev)
-        parallelism = f"table row-sharded x{world} (RCCL all-to-all) + dp{world} MLP"
+        parallelism = f"table row-sharded x{world} (RCCL all-to-all) + dp{world} MLP" + (" [REHEARSAL: one GPU, gloo]" if rehearse else "")
     else:
         model = pkg.DeepFM(dims, D, hidden, p_dropout=p_drop, use_batchnorm=True,
                            embedding_config=emb_cfg, fc_sparse=sparse).to(dev)

@@ -70,3 +70,23 @@ def test_graphed_local_compute_matches_eager():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graphed_sharded_check.py"), str(port)],
                        capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "GRAPHED_SHARDED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_two_ranks_sharing_one_gpu_match_the_unsharded_model():
+    """world = 2 through the HIP routing kernels end to end (see tests/_two_rank_gpu_check.py)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    script = os.path.join(ROOT, "tests", "_two_rank_gpu_check.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    if any("GLOO_NO_CUDA_ALLTOALL" in o for o, _ in outs):
+        pytest.skip("this gloo build has no all_to_all on device tensors: " + outs[0][0].strip()[:200])
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "TWO_RANK_OK" in o, f"rank {r}:\n{o[-1500:]}\n{e[-3000:]}"
