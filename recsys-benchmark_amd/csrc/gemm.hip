@@ -102,6 +102,38 @@ __device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int ro
   return s;
 }
 
+// The two float4 addresses a thread fetches of a [64 rows][32 k] tile at k offset k0 (same mapping as
+// stage_load_fast); consecutive k-tiles are a constant stride apart, so the pipelined loop keeps these as
+// loop-carried registers and never recomputes an address next to an in-flight load.
+struct TilePtr {
+  const float *p[2];
+};
+template <int TRANS>
+__device__ __forceinline__ TilePtr tile_ptrs(const float *P, int ld, int row0, int nrows, int k0) {
+  TilePtr tp;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = t + i * 256;
+    if constexpr (!TRANS) {
+      int r = row0 + (f >> 3);
+      r = r < nrows ? r : nrows - 1;
+      tp.p[i] = P + (long long)r * ld + k0 + (f & 7) * 4;
+    } else {
+      int r = row0 + (f & 15) * 4;
+      r = r < nrows ? r : nrows - 4;
+      tp.p[i] = P + (long long)(k0 + (f >> 4)) * ld + r;
+    }
+  }
+  return tp;
+}
+__device__ __forceinline__ Staged load_tile(const TilePtr &tp) {
+  Staged s;
+  s.v[0] = *reinterpret_cast<const float4 *>(tp.p[0]);
+  s.v[1] = *reinterpret_cast<const float4 *>(tp.p[1]);
+  return s;
+}
+
 template <int TRANS>
 __device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int row0, int nrows, int k0, int K,
                                                      bool aligned) {
@@ -202,8 +234,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     // Pipelined over FULL k-tiles only; a partial last tile of a group is a guarded step.
     const int kfull = a.K / BK;                       // full tiles per group
     auto is_full = [&](int step) { return (step % ktiles) < kfull; };
-    auto fa = [&](int step) { return stage_load_fast<TA>(A + (step / ktiles) * a.gA, a.lda, m0, a.M, (step % ktiles) * BK); };
-    auto fb = [&](int step) { return stage_load_fast<BT>(B + (step / ktiles) * a.gB, a.ldb, n0, a.N, (step % ktiles) * BK); };
     int it = first;
     while (it < total) {
       if (!is_full(it)) {   // K tail of a group: one unpipelined guarded tile
@@ -217,28 +247,63 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         ++it;
         continue;
       }
-      // run of consecutive full tiles [it, run_end)
-      int run_end = it;
-      while (run_end < total && is_full(run_end)) ++run_end;
+      // run of consecutive full tiles [it, run_end) of ONE k-group
+      const int grp = it / ktiles;
+      int run_end = (grp * ktiles + kfull < total) ? grp * ktiles + kfull : total;
+      // Two register sets with FIXED roles, the loop unrolled by two k-tiles: the loads of tile s+2 are issued
+      // before the MFMAs of tile s and written to LDS after the MFMAs of tile s+1, i.e. every tile's loads have
+      // two MFMA phases to land.  (A rotating "next = next2" hand-over costs a register move of an in-flight
+      // load's result, which forces vmcnt(0) at the top of every iteration and halves the prefetch distance:
+      // seen in the ISA of the previous version.)  Loads past the run are clamped re-loads, never stored.
+      const int last = run_end - 1;
+      TilePtr pa = tile_ptrs<TA>(A + grp * a.gA, a.lda, m0, a.M, (it % ktiles) * BK);
+      TilePtr pb = tile_ptrs<BT>(B + grp * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK);
+      const long long stepA = TA ? (long long)BK * a.lda : BK, stepB = BT ? (long long)BK * a.ldb : BK;
+      int tl = it;                                   // the tile the running pointers address
+      auto advance = [&]() {
+        const long long da = tl < last ? stepA : 0, db = tl < last ? stepB : 0;
+        tl += tl < last ? 1 : 0;
+        pa.p[0] += da; pa.p[1] += da;
+        pb.p[0] += db; pb.p[1] += db;
+      };
       __syncthreads();
-      Staged sa = fa(it), sb = fb(it);
-      stage_store<TA>(As[0], sa);
-      stage_store<BT>(Bs[0], sb);
-      Staged na = sa, nb = sb;
-      if (it + 1 < run_end) { na = fa(it + 1); nb = fb(it + 1); }
+      Staged r0a = load_tile(pa), r0b = load_tile(pb);
+      advance();
+      stage_store<TA>(As[0], r0a);
+      stage_store<BT>(Bs[0], r0b);
+      r0a = load_tile(pa);
+      r0b = load_tile(pb);
+      advance();
+      Staged r1a, r1b;
       __syncthreads();
-      for (int s2 = it; s2 < run_end; ++s2) {
-        const int cur = (s2 - it) & 1;
-        Staged f2a = na, f2b = nb;
-        if (s2 + 2 < run_end) { f2a = fa(s2 + 2); f2b = fb(s2 + 2); }   // tile s2+2: in flight over two MFMA phases
-        mma_tile(acc, As[cur], Bs[cur], ar, br, kh);
+      int s2 = it;
+      while (true) {
+        // LDS[0] = tile s2, R0 = tile s2+1
+        r1a = load_tile(pa);
+        r1b = load_tile(pb);
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(acc, As[0], Bs[0], ar, br, kh);
+        __builtin_amdgcn_sched_barrier(0);
         if (s2 + 1 < run_end) {
-          stage_store<TA>(As[cur ^ 1], na);
-          stage_store<BT>(Bs[cur ^ 1], nb);
+          stage_store<TA>(As[1], r0a);
+          stage_store<BT>(Bs[1], r0b);
         }
         __syncthreads();
-        na = f2a;
-        nb = f2b;
+        if (++s2 >= run_end) break;
+        // LDS[1] = tile s2, R1 = tile s2+1
+        r0a = load_tile(pa);
+        r0b = load_tile(pb);
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(acc, As[1], Bs[1], ar, br, kh);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2 + 1 < run_end) {
+          stage_store<TA>(As[0], r1a);
+          stage_store<BT>(Bs[0], r1b);
+        }
+        __syncthreads();
+        if (++s2 >= run_end) break;
       }
       it = run_end;
     }
