@@ -212,8 +212,9 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
+        one = torch.ones((), device=dev)          # d(loss)/d(loss): without it every backward() fills a fresh scalar
         with torch.cuda.graph(graph):
-            lossf(model(x), y).backward()
+            lossf(model(x), y).backward(one)
 
         def step():
             next_batch()

@@ -74,10 +74,12 @@ MI_API int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets,
  * gradient of W / w1.  Autograd equivalent: embedding_dense_backward +
  * _embedding_bag_dense_backward of src/models/deepfm.py:89,95 before the
  * duplicate-row sum.  g_emb is nullable (no deep branch).
+  * gbias (nullable, both backward forms and mi_slot_fm_bwd): receives sum_b g_y[b], the gradient of the
+ * scalar bias (src/models/deepfm.py:51,95), added up in a fixed order by workgroup 0 of the same launch.
  */
 MI_API int mi_gather_fm_bwd_rows(const float *emb, const float *g_y,
                                  const float *g_emb, float *gvals, float *g1vals,
-                                 int64_t B, int32_t F, int32_t D, void *stream);
+                                 float *gbias, int64_t B, int32_t F, int32_t D, void *stream);
 
 /* Backward, dense form (the reference's weight.grad semantics): scatter-adds
  * the same rows into caller-zeroed gW fp32[N,D] / gw1 fp32[N] with float
@@ -86,7 +88,7 @@ MI_API int mi_gather_fm_bwd_rows(const float *emb, const float *g_y,
  */
 MI_API int mi_gather_fm_bwd_dense(const int64_t *rows, const float *emb,
                                   const float *g_y, const float *g_emb,
-                                  float *gW, float *gw1, int64_t B, int32_t F,
+                                  float *gW, float *gw1, float *gbias, int64_t B, int32_t F,
                                   int32_t D, int64_t N, void *stream);
 
 /* ---- a2: plain row gather (IEmbedding.forward on a vanilla table) ----------
@@ -423,8 +425,8 @@ MI_API int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, 
                           float *emb_out, float *yfm_out, int64_t B, int32_t F, int32_t D,
                           int32_t *err, void *stream);
 MI_API int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y,
-                          const float *g_emb, float *gbuf, int64_t nslot, int64_t B, int32_t F,
-                          int32_t D, void *stream);
+                          const float *g_emb, float *gbuf, float *gbias, int64_t nslot, int64_t B,
+                          int32_t F, int32_t D, void *stream);
 
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the

@@ -84,14 +84,18 @@ class GatherFM(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         rows_form = (sparse_W and need_W) or (sparse_w1 and need_w1)
         dense_form = (need_W and not sparse_W) or (need_w1 and not sparse_w1)
+        # the bias gradient (sum of g_y) rides in whichever backward kernel runs first
+        gb = torch.empty((1,), dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        gb_done = False
         if rows_form:
             gvals = torch.empty((B * F, D), dtype=torch.float32, device=dev)
             g1vals = torch.empty((B * F,), dtype=torch.float32, device=dev)
             _lib.check(
                 lib.mi_gather_fm_bwd_rows(emb.data_ptr(), g_y.data_ptr(), _lib.ptr(g_emb),
-                                          gvals.data_ptr(), g1vals.data_ptr(), B, F, D, stream),
+                                          gvals.data_ptr(), g1vals.data_ptr(), _lib.ptr(gb), B, F, D, stream),
                 "mi_gather_fm_bwd_rows",
             )
+            gb_done = True
             if sparse_W and need_W:
                 gW = _coo(rows, gvals, Wshape)
             if sparse_w1 and need_w1:
@@ -102,14 +106,16 @@ class GatherFM(torch.autograd.Function):
             _lib.check(
                 lib.mi_gather_fm_bwd_dense(rows.data_ptr(), emb.data_ptr(), g_y.data_ptr(),
                                            _lib.ptr(g_emb), gWd.data_ptr(), gw1d.data_ptr(),
-                                           B, F, D, N, stream),
+                                           None if gb_done else _lib.ptr(gb), B, F, D, N, stream),
                 "mi_gather_fm_bwd_dense",
             )
+            gb_done = True
             if need_W and not sparse_W:
                 gW = gWd.view(Wshape)
             if need_w1 and not sparse_w1:
                 gw1 = gw1d.view(w1shape)
-        gb = g_y.sum().view(1) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        if gb is not None and not gb_done:          # neither table needs a gradient: nothing was launched
+            gb = g_y.sum().view(1)
         return None, None, gW, gw1, gb, None, None
 
 
@@ -207,9 +213,10 @@ class FMFirstOrder(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         g_emb = torch.empty((B, F, D), dtype=torch.float32, device=dev)
         g1vals = torch.empty((B * F,), dtype=torch.float32, device=dev)
+        gb = torch.empty((1,), dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[3]) else None
         _lib.check(
             lib.mi_gather_fm_bwd_rows(embc.data_ptr(), g_y.data_ptr(), None, g_emb.data_ptr(),
-                                      g1vals.data_ptr(), B, F, D, stream),
+                                      g1vals.data_ptr(), _lib.ptr(gb), B, F, D, stream),
             "mi_gather_fm_bwd_rows",
         )
         gw1 = None
@@ -221,7 +228,6 @@ class FMFirstOrder(torch.autograd.Function):
                 _lib.check(lib.mi_scatter_add_rows(rowsc.data_ptr(), g1vals.data_ptr(), gw1.data_ptr(),
                                                    B * F, 1, N, stream), "mi_scatter_add_rows")
                 gw1 = gw1.view(w1shape)
-        gb = g_y.sum().view(1) if (has_bias and ctx.needs_input_grad[3]) else None
         return (g_emb if ctx.needs_input_grad[0] else None), None, gw1, gb, None
 
 
@@ -1012,15 +1018,18 @@ class SlotFM(torch.autograd.Function):
         g_y = _f32c(g_y)
         g_emb = None if g_emb is None else _f32c(g_emb)
         gbuf = None
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        gb = torch.empty((1,), dtype=torch.float32, device=dev) if want_gb else None
         if ctx.needs_input_grad[0]:
             gbuf = torch.empty((rows, D + 4), dtype=torch.float32, device=dev)
             # the kernel zeroes rows [0, S) itself; the dump row's gradient is never read
             _lib.check(
                 lib.mi_slot_fm_bwd(slot.data_ptr(), emb.data_ptr(), g_y.data_ptr(), _lib.ptr(g_emb),
-                                   gbuf.data_ptr(), rows - 1, B, F, D, _lib.stream_ptr(dev)),
+                                   gbuf.data_ptr(), _lib.ptr(gb), rows - 1, B, F, D, _lib.stream_ptr(dev)),
                 "mi_slot_fm_bwd",
             )
-        gb = g_y.sum().view(1) if (has_bias and ctx.needs_input_grad[2]) else None
+        elif want_gb:
+            gb = g_y.sum().view(1)
         return gbuf, None, gb
 
 

@@ -24,8 +24,8 @@ SIGNATURES = {
     "mi_abi_version": [],
     "mi_strerror": [ctypes.c_int],
     "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
-    "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
-    "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
+    "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
+    "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
     "mi_gather_rows_fwd": [_p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_scatter_add_rows": [_p, _p, _p, _i64, _i32, _i64, _p],
     "mi_fm_fwd": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
@@ -74,7 +74,7 @@ SIGNATURES = {
     "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_slot_fm_fwd": [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p],
-    "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
+    "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
     "mi_prof_enable": [_i32],
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],

@@ -134,6 +134,24 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
 }
 
+// bias gradient = sum_b g_y[b] (the bias is added to every sample's y_fm): workgroup 0 of a backward kernel
+// adds it up in a fixed order (deterministic, no atomics, no zero-fill) before its own share of the rows —
+// one launch less per step than a separate reduction.
+__device__ __forceinline__ void bias_grad_block0(const float *__restrict__ g_y, int64_t B, float *__restrict__ gbias) {
+  if (!gbias || blockIdx.x != 0) return;
+  __shared__ float part[kWavesPerBlock];
+  float s = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += kBlock) s += g_y[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int j = 0; j < kWavesPerBlock; ++j) t += part[j];
+    gbias[0] = t;
+  }
+}
+
 // ----------------------------------------------------- backward, row form ----
 // SLOT = false: gvals[b,f,:] / g1vals[b,f] in lookup order (the reference's COO values).
 // SLOT = true : the row goes to gvals + slot[b,f]*(D+4), its first-order gradient into column D of
@@ -142,9 +160,10 @@ template <int LPR, int NIT, bool SLOT>
 __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
     const float *__restrict__ emb, const float *__restrict__ g_y,
     const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
-    int64_t B, int F, const int64_t *__restrict__ slot, int64_t nslot) {
+    int64_t B, int F, const int64_t *__restrict__ slot, int64_t nslot, float *__restrict__ gbias) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
+  bias_grad_block0(g_y, B, gbias);
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, r = lane / LPR;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
 __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows_anyD(
     const float *__restrict__ emb, const float *__restrict__ g_y,
     const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
-    int64_t B, int F, int D) {
+    int64_t B, int F, int D, float *__restrict__ gbias) {
+  bias_grad_block0(g_y, B, gbias);
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -254,10 +274,11 @@ template <int LPR, int NIT>
 __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense(
     const int64_t *__restrict__ rows, const float *__restrict__ emb,
     const float *__restrict__ g_y, const float *__restrict__ g_emb,
-    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int64_t N) {
+    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int64_t N, float *__restrict__ gbias) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   __shared__ float slab[kWavesPerBlock][kWave * 4];
+  bias_grad_block0(g_y, B, gbias);
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int q = lane % LPR, r = lane / LPR;
@@ -314,7 +335,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense(
 __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense_anyD(
     const int64_t *__restrict__ rows, const float *__restrict__ emb,
     const float *__restrict__ g_y, const float *__restrict__ g_emb,
-    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int D, int64_t N) {
+    float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int D, int64_t N, float *__restrict__ gbias) {
+  bias_grad_block0(g_y, B, gbias);
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -511,7 +533,7 @@ int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W,
 }
 
 int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb, float *gvals,
-                          float *g1vals, int64_t B, int32_t F, int32_t D, void *stream) {
+                          float *g1vals, float *gbias, int64_t B, int32_t F, int32_t D, void *stream) {
   if (B < 0 || F < 0 || D <= 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!emb || !g_y || !gvals || !g1vals) return MI_ERR_INVALID_ARG;
@@ -520,19 +542,19 @@ int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                      \
   MI_LAUNCH("gather_fm_bwd_rows", (k_gather_fm_bwd_rows<LPR, NIT, false>), grid, kBlock, stream, \
-            emb, g_y, g_emb, gvals, g1vals, B, F, (const int64_t *)nullptr, (int64_t)0)
+            emb, g_y, g_emb, gvals, g1vals, B, F, (const int64_t *)nullptr, (int64_t)0, gbias)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   } else {
     MI_LAUNCH("gather_fm_bwd_rows", k_gather_fm_bwd_rows_anyD, grid, kBlock, stream, emb, g_y,
-              g_emb, gvals, g1vals, B, F, D);
+              g_emb, gvals, g1vals, B, F, D, gbias);
   }
   return launch_status();
 }
 
 int mi_gather_fm_bwd_dense(const int64_t *rows, const float *emb, const float *g_y,
-                           const float *g_emb, float *gW, float *gw1, int64_t B, int32_t F,
-                           int32_t D, int64_t N, void *stream) {
+                           const float *g_emb, float *gW, float *gw1, float *gbias, int64_t B,
+                           int32_t F, int32_t D, int64_t N, void *stream) {
   if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!rows || !emb || !g_y || !gW || !gw1) return MI_ERR_INVALID_ARG;
@@ -541,12 +563,12 @@ int mi_gather_fm_bwd_dense(const int64_t *rows, const float *emb, const float *g
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                         \
   MI_LAUNCH("gather_fm_bwd_dense", (k_gather_fm_bwd_dense<LPR, NIT>), grid, kBlock, stream, rows, \
-            emb, g_y, g_emb, gW, gw1, B, F, N)
+            emb, g_y, g_emb, gW, gw1, B, F, N, gbias)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   } else {
     MI_LAUNCH("gather_fm_bwd_dense", k_gather_fm_bwd_dense_anyD, grid, kBlock, stream, rows, emb,
-              g_y, g_emb, gW, gw1, B, F, D, N);
+              g_y, g_emb, gW, gw1, B, F, D, N, gbias);
   }
   return launch_status();
 }
@@ -612,7 +634,7 @@ int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const f
 }
 
 int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y, const float *g_emb,
-                   float *gbuf, int64_t nslot, int64_t B, int32_t F, int32_t D, void *stream) {
+                   float *gbuf, float *gbias, int64_t nslot, int64_t B, int32_t F, int32_t D, void *stream) {
   if (B < 0 || F < 0 || D <= 0 || nslot < 0) return MI_ERR_INVALID_ARG;
   if (nslot > 0 && !gbuf) return MI_ERR_INVALID_ARG;
   if (!vec_ok(D) || !aligned16(gbuf) || (emb && !aligned16(emb)) || (g_emb && !aligned16(g_emb)))
@@ -627,7 +649,7 @@ int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y, cons
   const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                         \
   MI_LAUNCH("slot_fm_bwd", (k_gather_fm_bwd_rows<LPR, NIT, true>), grid, kBlock, stream, emb,  \
-            g_y, g_emb, gbuf, (float *)nullptr, B, F, slot, nslot)
+            g_y, g_emb, gbuf, (float *)nullptr, B, F, slot, nslot, gbias)
   MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   return launch_status();

@@ -67,8 +67,9 @@ class _Linear1Fn(torch.autograd.Function):
     hipBLASLt spent ~40 us per step on it at [4096, 400] (rocprof r01)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, addend):
-        """addend (optional, [M]): added to the output row-wise inside the same kernel (DeepFM's y_fm)."""
+    def forward(ctx, x, W, b, addend, red_buf=None):
+        """addend (optional, [M]): added to the output row-wise inside the same kernel (DeepFM's y_fm).
+        red_buf (optional): N+1 zeroed floats of the pass workspace for the backward's two column sums."""
         dev = _lib.require_gpu(x, W)
         x = _kernels._f32c(x)
         M, N = x.shape
@@ -76,14 +77,14 @@ class _Linear1Fn(torch.autograd.Function):
         add = None if addend is None else _kernels._f32c(addend)
         _lib.check(_lib.load().mi_rowdot(x.data_ptr(), N, W.data_ptr(), _lib.ptr(b), _lib.ptr(add), out.data_ptr(), M, N,
                                          _lib.stream_ptr(dev)), "mi_rowdot")
-        ctx.save_for_backward(x, W)
+        ctx.save_for_backward(x, W, red_buf)
         ctx.has_bias = b is not None
         ctx.add_shape = None if addend is None else tuple(addend.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, W, red_buf = ctx.saved_tensors
         dev = x.device
         M, N = x.shape
         g = _kernels._f32c(g).view(M)
@@ -92,7 +93,7 @@ class _Linear1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, N), dtype=torch.float32, device=dev)
             _lib.check(lib.mi_outer(g.data_ptr(), W.data_ptr(), dx.data_ptr(), M, N, s), "mi_outer")
-        red = torch.zeros((N + 1,), dtype=torch.float32, device=dev)
+        red = red_buf if red_buf is not None else torch.zeros((N + 1,), dtype=torch.float32, device=dev)
         if ctx.needs_input_grad[1]:
             _lib.check(lib.mi_colsum(x.data_ptr(), N, g.data_ptr(), 1, red.data_ptr(), M, N, s), "mi_colsum")
             dW = red[:N].view(1, N)
@@ -100,7 +101,7 @@ class _Linear1Fn(torch.autograd.Function):
             _lib.check(lib.mi_colsum(g.data_ptr(), 1, None, 0, red[N:].data_ptr(), M, 1, s), "mi_colsum")
             db = red[N:]
         dadd = g.view(ctx.add_shape) if (ctx.add_shape is not None and ctx.needs_input_grad[3]) else None
-        return dx, dW, db, dadd
+        return dx, dW, db, dadd, None
 
 
 class _BNReLUDropFn(torch.autograd.Function):
@@ -189,6 +190,8 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         lin = grp[1]
         if isinstance(lin, nn.Linear):
             need += _pad4(lin.out_features) * (5 if grp[0] == "fused" else 1)
+            if grp[0] == "plain" and lin.out_features == 1:
+                need += _pad4(lin.in_features + 1)       # the rank-1 layer's backward column sums
     ws = torch.zeros((need,), dtype=torch.float32, device=dev) if (need and torch.is_grad_enabled()) else None
     if ws is None and need:
         ws = torch.zeros((need,), dtype=torch.float32, device=dev)
@@ -205,9 +208,9 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         if grp[0] == "plain":
             m = grp[1]
             if isinstance(m, nn.Linear) and m.out_features == 1 and x.dim() == 2:
-                take(1)
+                red = take(m.in_features + 1)
                 fuse = last_add is not None and k == len(groups) - 1
-                x = _Linear1Fn.apply(x, m.weight, m.bias, last_add if fuse else None)
+                x = _Linear1Fn.apply(x, m.weight, m.bias, last_add if fuse else None, red)
                 if fuse:
                     last_add = None
             elif isinstance(m, nn.Linear):

@@ -66,10 +66,10 @@ def main():
         def bwd():
             if a.dense:
                 _lib.check(lib.mi_gather_fm_bwd_dense(rows.data_ptr(), emb.data_ptr(), g_y.data_ptr(), g_emb.data_ptr(),
-                                                      gW.data_ptr(), gw1.data_ptr(), B, F, D, N, s))
+                                                      gW.data_ptr(), gw1.data_ptr(), None, B, F, D, N, s))
             else:
                 _lib.check(lib.mi_gather_fm_bwd_rows(emb.data_ptr(), g_y.data_ptr(), g_emb.data_ptr(), gvals.data_ptr(),
-                                                     g1.data_ptr(), B, F, D, s))
+                                                     g1.data_ptr(), None, B, F, D, s))
 
         for _ in range(5):
             fwd(); bwd()
