@@ -309,7 +309,8 @@ MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int3
 
 /* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
  *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
- *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients)
+ *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients);
+ *                     rs_sum[0] += sum_m rs(m) if given (a 1-output Linear's dW and db in one launch)
  *   mi_rowdot:        out[m]  = sum_n X[m,n]*v[n] (+ bias[0]) (+ addend[m])   (also the forward of a 1-output Linear)
  *   mi_outer:         out[m,n] = g[m]*w[n]                       (its backward w.r.t. the input)
  *   mi_mix_gate_bwd:  dgate[m,e] = sum_k dH2g*H2 + dgsum[m]; dZ2 = dH2g*gate[m,e]*(1-H2^2)   ([M,E*r] operands)
@@ -317,7 +318,7 @@ MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int3
 MI_API int mi_cross_bwd_pre(const float *g, const float *x0, const float *lin, float *dlin,
                             float *dx0, int64_t n, int32_t accumulate, void *stream);
 MI_API int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs,
-                     float *out, int32_t M, int32_t N, void *stream);
+                     float *out, float *rs_sum, int32_t M, int32_t N, void *stream);
 MI_API int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias,
                      const float *addend, float *out, int32_t M, int32_t N, void *stream);
 /* The trainer's loss on the logits (src/trainer/deepfm.py:32,51: BCEWithLogitsLoss, reduction "mean"):

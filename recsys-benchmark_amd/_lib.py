@@ -42,7 +42,7 @@ SIGNATURES = {
     "mi_gemm_f32": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64,
                     _i64, _i32, _p, _p, _i32, _i64, _p, _i32, _i64, _p, _i32, _p, _i32, _i64, _i32, _p],
     "mi_cross_bwd_pre": [_p, _p, _p, _p, _p, _i64, _i32, _p],
-    "mi_colsum": [_p, _i32, _p, _i32, _p, _i32, _i32, _p],
+    "mi_colsum": [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _p],
     "mi_rowdot": [_p, _i32, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_bce_logits_fwd": [_p, _p, _p, _i64, _p],
     "mi_bce_logits_bwd": [_p, _p, _p, _p, _i64, _p],

@@ -18,12 +18,17 @@ __global__ __launch_bounds__(kBlock) void k_cross_bwd_pre(const float *__restric
 }
 
 // out[n] += sum_m X[m,n] * rs(m),  rs(m) = sum_{e<nrs} rowscale[m*nrs+e] (1 if null).  out caller-zeroed.
+// rs_sum (nullable, caller-zeroed): += sum_m rs(m) — the bias gradient of a 1-output Linear, whose weight
+// gradient is this very column sum (dW = g^T x, db = sum g): one launch for both.
 __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int ldx, const float *__restrict__ rowscale,
-                                                   int nrs, float *__restrict__ out, int M, int N) {
+                                                   int nrs, float *__restrict__ out, int M, int N,
+                                                   float *__restrict__ rs_sum) {
   __shared__ float part[4][64];
+  __shared__ float part_rs[4];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
-  float s = 0.f;
+  const bool tally = rs_sum && blockIdx.x == 0 && c == 0;   // column 0's lanes see every row of their row block
+  float s = 0.f, t = 0.f;
   if (n < N) {
     const int stride = gridDim.y * 4;
     int m = blockIdx.y * 4 + rl;
@@ -36,7 +41,10 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
           rs[u] = rowscale ? rowscale[m + u * stride] : 1.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u] * rs[u];
+        for (int u = 0; u < 8; ++u) {
+          s += v[u] * rs[u];
+          t += rs[u];
+        }
       }
     }
     for (; m < M; m += stride) {
@@ -46,11 +54,14 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
         for (int e = 0; e < nrs; ++e) rs += rowscale[(int64_t)m * nrs + e];
       }
       s += X[(int64_t)m * ldx + n] * rs;
+      t += rs;
     }
   }
   part[rl][c] = s;
+  if (tally) part_rs[rl] = t;
   __syncthreads();
   if (rl == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+  if (tally && rl == 0) atomicAdd(rs_sum, part_rs[0] + part_rs[1] + part_rs[2] + part_rs[3]);
 }
 
 // out[m] = sum_n X[m,n] * v[n] (+ bias[0]) (+ addend[m])
@@ -163,8 +174,8 @@ int mi_cross_bwd_pre(const float *g, const float *x0, const float *lin, float *d
   return launch_status();
 }
 
-int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, float *out, int32_t M, int32_t N,
-              void *stream) {
+int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, float *out, float *rs_sum, int32_t M,
+              int32_t N, void *stream) {
   if (M < 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
   if (!X || !out) return MI_ERR_INVALID_ARG;
@@ -174,7 +185,7 @@ int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t nrs, f
   if (rb > want) rb = want;
   if (rb < 1) rb = 1;
   dim3 grid(cb, rb);
-  MI_LAUNCH("colsum", k_colsum, grid, kBlock, stream, X, ldx, rowscale, nrs, out, M, N);
+  MI_LAUNCH("colsum", k_colsum, grid, kBlock, stream, X, ldx, rowscale, nrs, out, M, N, rs_sum);
   return launch_status();
 }
 

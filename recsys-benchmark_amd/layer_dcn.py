@@ -63,7 +63,7 @@ class _DCNHeadFn(torch.autograd.Function):
             _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), lins[l].data_ptr(), dlin.data_ptr(),
                                             dx0.data_ptr(), M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
             db = torch.zeros((d,), dtype=torch.float32, device=dev)
-            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, db.data_ptr(), M, d, s), "mi_colsum")
+            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, db.data_ptr(), None, M, d, s), "mi_colsum")
             dW = _new((d, d), dev)
             gemm(dlin, xs[l], dW, d, d, M, d, d, d, transA=True)                 # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
             gn = _new((M, d), dev)
@@ -146,7 +146,7 @@ class _DCNMixFn(torch.autograd.Function):
             _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), T.data_ptr(), dT.data_ptr(), dx0.data_ptr(),
                                             M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
             db = torch.zeros((1, d), dtype=torch.float32, device=dev)
-            _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), M, d, s), "mi_colsum")
+            _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), None, M, d, s), "mi_colsum")
             dgsum = _new((M,), dev)
             _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), None, None, dgsum.data_ptr(), M, d, s), "mi_rowdot")
             dH2g = _new((M, Er), dev)

@@ -56,7 +56,7 @@ class _LinearFn(torch.autograd.Function):
             M, N = g.shape
             db = db_buf if db_buf is not None else torch.zeros((N,), dtype=torch.float32, device=g.device)
             if not ctx.zero_db:
-                _lib.check(_lib.load().mi_colsum(g.data_ptr(), N, None, 0, db.data_ptr(), M, N,
+                _lib.check(_lib.load().mi_colsum(g.data_ptr(), N, None, 0, db.data_ptr(), None, M, N,
                                                  _lib.stream_ptr(g.device)), "mi_colsum")
         return dx, dW, db, None, None
 
@@ -94,11 +94,15 @@ class _Linear1Fn(torch.autograd.Function):
             dx = torch.empty((M, N), dtype=torch.float32, device=dev)
             _lib.check(lib.mi_outer(g.data_ptr(), W.data_ptr(), dx.data_ptr(), M, N, s), "mi_outer")
         red = red_buf if red_buf is not None else torch.zeros((N + 1,), dtype=torch.float32, device=dev)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            _lib.check(lib.mi_colsum(x.data_ptr(), N, g.data_ptr(), 1, red.data_ptr(), M, N, s), "mi_colsum")
+            # dW = g^T x and db = sum g in ONE launch (db is the sum of the very row scales dW is weighted with)
+            _lib.check(lib.mi_colsum(x.data_ptr(), N, g.data_ptr(), 1, red.data_ptr(),
+                                     red[N:].data_ptr() if want_db else None, M, N, s), "mi_colsum")
             dW = red[:N].view(1, N)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            _lib.check(lib.mi_colsum(g.data_ptr(), 1, None, 0, red[N:].data_ptr(), M, 1, s), "mi_colsum")
+        elif want_db:
+            _lib.check(lib.mi_colsum(g.data_ptr(), 1, None, 0, red[N:].data_ptr(), None, M, 1, s), "mi_colsum")
+        if want_db:
             db = red[N:]
         dadd = g.view(ctx.add_shape) if (ctx.add_shape is not None and ctx.needs_input_grad[3]) else None
         return dx, dW, db, dadd, None
