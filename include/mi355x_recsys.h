@@ -181,6 +181,21 @@ MI_API int mi_qat_gather_bwd(const int64_t *idx, const float *W, const float *sc
                              const float *prob, const int64_t *seed, int64_t salt, const float *g,
                              float *dW, float *dscale, int64_t n, int32_t D, int64_t N, void *stream);
 
+/* ---- §8f rank 4 (fourth flavour): OptEmbed supernet lookup ---------------------------------------
+ * OptEmbed.forward / get_weight (src/models/embeddings/deepfm_opt_embed.py:150-243) with _MaskEmbeddingModule
+ * and BinaryStep (optembed_utils.py:10-112):
+ *   y[i,:] = W[idx[i],:] * [ ||W[idx[i]]||_norm - t[tix] > 0 ] * [dim <= dmax[i]]
+ * tix = tix[i] if given, else i % F (one threshold per field of a [B, F] lookup); t NULL = no row mask,
+ * dmax NULL = all dimensions.  Backward: dW (dense, caller-zeroed, float atomics) gets the masked g plus the
+ * straight-through term (sum_d g_d m_d w_d) * a(u) * d||w||/dw with BinaryStep's surrogate a(u); dt[tix] -= the
+ * same scalar (caller-zeroed).  dW / dt nullable.                                                        */
+MI_API int mi_optembed_fwd(const int64_t *idx, const float *W, const float *t, const int64_t *tix,
+                           int32_t F, const int64_t *dmax, int32_t norm, float *out, int64_t n,
+                           int32_t D, int64_t N, int32_t *err, void *stream);
+MI_API int mi_optembed_bwd(const int64_t *idx, const float *W, const float *t, const int64_t *tix,
+                           int32_t F, const int64_t *dmax, int32_t norm, const float *g, float *dW,
+                           float *dt, int64_t n, int32_t D, int64_t N, void *stream);
+
 /* ---- a11: CSR-pruned table rows (numba kernels K1/K2) ------------------------
  * src/models/embeddings/pruned_embedding.py:136-204: out[i,:] = dense row ids[i] of the
  * CSR matrix (values fp32, crow/col int64).  out fp32[n,D] need not be pre-zeroed.

@@ -361,3 +361,47 @@ class _StochasticRounding(torch.autograd.Function):
 def qat_forward(idx: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, n_bits: int, prob: torch.Tensor):
     """QAT_EmbInt.forward (qat_emb.py:117-119): nn.Embedding rows, then stochastic rounding."""
     return _StochasticRounding.apply(scale, F.embedding(idx, weight), n_bits, prob)
+
+
+# --------------------------------------------------------------------------- OptEmbed supernet lookup
+class _BinaryStep(torch.autograd.Function):
+    """optembed_utils.py:25-43."""
+
+    @staticmethod
+    def forward(ctx, inp):
+        ctx.save_for_backward(inp)
+        return (inp > 0.0).float()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (inp,) = ctx.saved_tensors
+        additional = 2 - 4 * torch.abs(inp)
+        additional[torch.abs(inp) > 1] = 0.0
+        additional[(torch.abs(inp) <= 1) * (torch.abs(inp) > 0.4)] = 0.4
+        return grad_output.clone() * additional
+
+
+def optembed_train_forward(x, weight, t_param, mask_d_idx, norm: int = 1):
+    """OptEmbed.forward in training (deepfm_opt_embed.py:219-228): x [B,F] rows, one threshold per field, mask_d_idx [B,F]
+    the torch.randint draw (number of kept dimensions - 1)."""
+    D = weight.shape[1]
+    emb = F.embedding(x, weight)
+    if t_param is not None:
+        emb = emb * _BinaryStep.apply(torch.norm(emb, norm, dim=2) - t_param).unsqueeze(-1)
+    full_mask_d = torch.tril(torch.ones((D, D), dtype=torch.bool))
+    return F.embedding(mask_d_idx, full_mask_d) * emb
+
+
+def optembed_weight(weight, t_param, field_dims, mode_threshold_e: str, mask_d_idx=None, mode_threshold_d: str = "field",
+                    norm: int = 1):
+    """OptEmbed.get_weight in eval (deepfm_opt_embed.py:148-200): the masked table."""
+    N, D = weight.shape
+    fd = torch.as_tensor(field_dims)
+    emb = weight
+    if t_param is not None:
+        t = t_param if mode_threshold_e == "feature" else torch.repeat_interleave(t_param, fd, dim=0, output_size=N)
+        emb = weight * _BinaryStep.apply(torch.norm(weight, norm, dim=1) - t).unsqueeze(-1)
+    if mask_d_idx is not None:
+        m = mask_d_idx if mode_threshold_d == "feature" else torch.repeat_interleave(mask_d_idx, fd, dim=0, output_size=N)
+        emb = emb * F.embedding(m, torch.tril(torch.ones((D, D), dtype=torch.bool))).to(weight)
+    return emb

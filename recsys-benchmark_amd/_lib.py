@@ -70,6 +70,8 @@ SIGNATURES = {
     "mi_mask_topk_rows": [_p, _i64, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p],
     "mi_qat_gather_fwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _i64, _i32, _i64, _p, _p],
     "mi_qat_gather_bwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i64, _p],
+    "mi_optembed_fwd": [_p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i64, _p, _p],
+    "mi_optembed_bwd": [_p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_route_workspace_elems": [_i64, _i32],
     "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],

@@ -11,6 +11,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 
 from .base import IEmbedding, VanillaEmbedding
 from .cerp_embedding import CerpEmbedding, RetrainCerpEmbedding
+from .deepfm_opt_embed import OptEmbed as DeepFMOptEmbed
 from .dh_embedding import DHEmbedding
 from .pep_embedding import PepEmbeeding, RetrainPepEmbedding
 from .pruned_embedding import PrunedEmbedding
@@ -28,17 +29,17 @@ NAME_TO_CLS: Dict[str, type] = {
     "cerp_retrain": RetrainCerpEmbedding,
     "tt_emb_torch": TTRecTorch,
     "qat": QAT_EmbInt,
+    "deepfm_optembed": DeepFMOptEmbed,
+    "deepfm_optembed_d": DeepFMOptEmbed,      # dimension mask only (t_init forced to None below)
 }
 
 # registry keys of the reference that this build deliberately does not cover
 OUT_OF_SCOPE = {
-    "optembed_d": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "optembed_d_retrain": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "optembed": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "optembed_retrain": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "deepfm_optembed": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "deepfm_optembed_d": "OptEmbed search (SURVEY.md §2.1 #7)",
-    "deepfm_optembed_retrain": "OptEmbed search (SURVEY.md §2.1 #7)",
+    "optembed_d": "LightGCN OptEmbed search classes (SURVEY.md §2.1 #7); the supernet lookup is 'deepfm_optembed'",
+    "optembed_d_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
+    "optembed": "LightGCN OptEmbed search classes (SURVEY.md §2.1 #7); the supernet lookup is 'deepfm_optembed'",
+    "optembed_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
+    "deepfm_optembed_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
     "tt_emb": "FBTT-Embedding CUDA extension, not in the reference tree (SURVEY.md §2.3 K3-K12); "
               "use 'tt_emb_torch'",
 }
@@ -65,6 +66,8 @@ def get_embedding(
     else:
         if name.startswith("pep") or name.startswith("cerp"):
             embedding_config["field_name"] = field_name
+        if name == "deepfm_optembed_d":
+            embedding_config["t_init"] = None      # mask E disabled (reference __init__.py:65-67)
         cls = NAME_TO_CLS[name]
         emb = cls(field_dims, hidden_size, mode=mode, **embedding_config)
 

@@ -262,6 +262,56 @@ def gen_qat():
              out=o, G=G, **params_of(emb), **grads_of(emb))
 
 
+# ------------------------------------------------------------------ G3e: OptEmbed supernet lookup (DeepFM variant)
+def gen_optembed():
+    """Training forward/backward with the torch.randint dimension-mask draw captured (first RNG use of the forward),
+    thresholds placed near the row norms so that BinaryStep's surrogate gradient is exercised; eval get_weight with
+    and without a dimension mask for field / feature thresholds."""
+    from src.models.embeddings.deepfm_opt_embed import OptEmbed
+
+    gen = torch.Generator().manual_seed(43)
+    dims = [13, 29, 7]
+    N, D, B = sum(dims), 8, 6
+    offs = torch.tensor([0, 13, 42])
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1) + offs
+    for norm in (1, 2):
+        set_seed(2023)
+        emb = OptEmbed(dims, D, None, t_init=0.0, mode_threshold_e="field", mode_threshold_d="field", norm=norm)
+        with torch.no_grad():
+            typical = torch.norm(emb._weight, norm, dim=1).mean()
+            emb._mask_e_module._t_param.copy_(typical + torch.tensor([-0.3, 0.05, 0.6]) * typical)
+        emb.train()
+        torch.manual_seed(77)
+        o = emb(x)
+        torch.manual_seed(77)
+        mask_d = torch.randint(0, D, size=(B, len(dims)))
+        G = torch.randn(o.shape, generator=gen)
+        (o * G).sum().backward()
+        out = dict(field_dims=np.array(dims), hidden=np.array(D), norm=np.array(norm), x=x, mask_d=mask_d, out=o, G=G,
+                   l_s=emb.get_l_s(), **params_of(emb), **grads_of(emb))
+        emb.zero_grad()
+        emb.eval()
+        out["weight_eval"] = emb.get_weight().clone()
+        md = torch.randint(0, D, (len(dims),), generator=gen)
+        out["mask_d_field"] = md
+        out["weight_eval_masked"] = emb.get_weight(md).clone()
+        out["lookup_eval_masked"] = emb(x).clone()
+        sp, nnz = emb.get_sparsity(True)
+        out["nnz"] = np.array(nnz)
+        save(f"optembed_l{norm}", **out)
+    # per-feature thresholds and per-feature dimension masks (eval only: the training forward asserts field thresholds)
+    set_seed(7)
+    emb = OptEmbed(dims, D, None, t_init=0.0, mode_threshold_e="feature", mode_threshold_d="feature", norm=1)
+    with torch.no_grad():
+        nrm = torch.norm(emb._weight, 1, dim=1)
+        emb._mask_e_module._t_param.copy_(nrm + (torch.rand(N, generator=gen) - 0.5))
+    emb.eval()
+    md = torch.randint(0, D, (N,), generator=gen)
+    save("optembed_feature", field_dims=np.array(dims), hidden=np.array(D), x=x, mask_d=md,
+         weight_eval=emb.get_weight().clone(), weight_eval_masked=emb.get_weight(md).clone(),
+         lookup_eval_masked=emb(x).clone(), **params_of(emb))
+
+
 # ------------------------------------------------------------------ G4: DHE
 def gen_dhe():
     gen = torch.Generator().manual_seed(13)
@@ -431,7 +481,7 @@ def gen_csr_pruned():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

@@ -479,3 +479,55 @@ def test_qat_bag_mode_rounds_the_reduced_bag():
     W, s = emb._emb_module.weight.detach().cpu(), emb.scale.detach().cpu()
     ref = ro.qat_forward(torch.arange(9), W[x.cpu()].sum(1), s, 16, prob.cpu())
     assert_close(out, ref, 1e-6, 1e-7, "bag then round")
+
+
+# ------------------------------------------------------------------ OptEmbed supernet lookup (DeepFM variant)
+@pytest.mark.parametrize("name", ["optembed_l1", "optembed_l2"])
+def test_optembed_matches_reference_golden(name):
+    g = load_golden(name)
+    dims, D, norm = g["field_dims"].tolist(), int(g["hidden"]), int(g["norm"])
+    emb = get_embedding({"name": "deepfm_optembed", "t_init": 0.0, "norm": norm}, dims, D)
+    want = {"_weight", "_mask_e_module._t_param", "_mask_e_module._field_dims", "_full_mask_d"}
+    assert set(emb.state_dict()) == want
+    emb.load_state_dict({k: g.t("param/" + k) for k in want})
+    emb.to(DEV).train()
+    emb._forced_mask_d = g.t("mask_d").to(DEV)            # the reference's torch.randint draw
+    out = emb(g.t("x").to(DEV))
+    assert_close(out, g.t("out"), 0, 0, "masked rows: exact copies or zeros")
+    (out * g.t("G").to(DEV)).sum().backward()
+    # straight-through terms: a wave reduction of D products, scattered with float atomics
+    assert_close(emb._weight.grad, g.t("grad/_weight"), 1e-5, 1e-6, "table gradient")
+    assert_close(emb._mask_e_module._t_param.grad, g.t("grad/_mask_e_module._t_param"), 1e-5, 1e-6, "threshold gradient")
+    assert_close(emb.get_l_s(), g.t("l_s"), 1e-6, 0)
+    del emb._forced_mask_d
+    emb.eval()
+    assert_close(emb.get_weight(), g.t("weight_eval"), 0, 0, "row-masked table")
+    assert_close(emb.get_weight(g.t("mask_d_field").to(DEV)), g.t("weight_eval_masked"), 0, 0, "row + dimension masks")
+    assert_close(emb(g.t("x").to(DEV)), g.t("lookup_eval_masked"), 0, 0, "eval lookups reuse the mask given to get_weight")
+    assert emb.get_num_params() == int(g["nnz"])
+    sub = emb.get_submask()
+    alive = (g.t("weight_eval").abs().sum(1) > 0).long()
+    assert sub.tolist() == [int(alive[a:b].sum()) for a, b in ((0, 13), (13, 42), (42, 49))]
+
+
+def test_optembed_feature_thresholds_and_own_sampling():
+    g = load_golden("optembed_feature")
+    dims, D = g["field_dims"].tolist(), int(g["hidden"])
+    emb = get_embedding({"name": "deepfm_optembed", "t_init": 0.0, "mode_threshold_e": "feature",
+                         "mode_threshold_d": "feature"}, dims, D)
+    emb.load_state_dict({k: g.t("param/" + k) for k in emb.state_dict()})
+    emb.to(DEV).eval()
+    assert_close(emb.get_weight(), g.t("weight_eval"), 0, 0)
+    assert_close(emb.get_weight(g.t("mask_d").to(DEV)), g.t("weight_eval_masked"), 0, 0)
+    assert_close(emb(g.t("x").to(DEV)), g.t("lookup_eval_masked"), 0, 0)
+    # 'deepfm_optembed_d': no row mask; training draws a fresh prefix mask per (sample, field)
+    torch.manual_seed(0)
+    d_only = get_embedding({"name": "deepfm_optembed_d"}, dims, D).to(DEV).train()
+    assert "_mask_e_module._t_param" not in d_only.state_dict()
+    x = g.t("x").to(DEV)
+    a, b = d_only(x).detach(), d_only(x).detach()
+    full = d_only._weight.detach()[x]
+    kept = a != 0
+    assert bool((a[kept] == full[kept]).all()) and bool(kept[..., 0].all()), "kept entries are the table's, dim 0 always kept"
+    assert bool((kept[..., :-1] >= kept[..., 1:]).all()), "prefix masks"
+    assert not torch.equal(a, b), "a new draw every forward"
