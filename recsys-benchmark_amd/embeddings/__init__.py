@@ -19,60 +19,48 @@ from .qat_emb import QAT_EmbInt
 from .qr_embedding import QRHashingEmbedding
 from .tensortrain_embeddings import TTRecTorch
 
-NAME_TO_CLS: Dict[str, type] = {
-    "vanilla": VanillaEmbedding,
-    "qr": QRHashingEmbedding,
-    "dhe": DHEmbedding,
-    "pep": PepEmbeeding,
-    "pep_retrain": RetrainPepEmbedding,
-    "cerp": CerpEmbedding,
-    "cerp_retrain": RetrainCerpEmbedding,
-    "tt_emb_torch": TTRecTorch,
-    "qat": QAT_EmbInt,
-    "deepfm_optembed": DeepFMOptEmbed,
-    "deepfm_optembed_d": DeepFMOptEmbed,      # dimension mask only (t_init forced to None below)
-}
+# (class, extra constructor arguments forced by the key, whether the class takes `field_name`)
+_REGISTRY = (
+    ("vanilla", VanillaEmbedding, {}, False),
+    ("qr", QRHashingEmbedding, {}, False),
+    ("dhe", DHEmbedding, {}, False),
+    ("pep", PepEmbeeding, {}, True),
+    ("pep_retrain", RetrainPepEmbedding, {}, True),
+    ("cerp", CerpEmbedding, {}, True),
+    ("cerp_retrain", RetrainCerpEmbedding, {}, True),
+    ("tt_emb_torch", TTRecTorch, {}, False),
+    ("qat", QAT_EmbInt, {}, False),
+    ("deepfm_optembed", DeepFMOptEmbed, {}, False),
+    ("deepfm_optembed_d", DeepFMOptEmbed, {"t_init": None}, False),   # mask E disabled (reference __init__.py:65-67)
+)
+NAME_TO_CLS: Dict[str, type] = {key: cls for key, cls, _, _ in _REGISTRY}
+_FORCED = {key: forced for key, _, forced, _ in _REGISTRY}
+_WANTS_FIELD_NAME = {key for key, _, _, named in _REGISTRY if named}
 
 # registry keys of the reference that this build deliberately does not cover
+_SEARCH = "OptEmbed search / retraining classes (SURVEY.md §2.1 #7); the supernet lookup is 'deepfm_optembed'"
 OUT_OF_SCOPE = {
-    "optembed_d": "LightGCN OptEmbed search classes (SURVEY.md §2.1 #7); the supernet lookup is 'deepfm_optembed'",
-    "optembed_d_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
-    "optembed": "LightGCN OptEmbed search classes (SURVEY.md §2.1 #7); the supernet lookup is 'deepfm_optembed'",
-    "optembed_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
-    "deepfm_optembed_retrain": "OptEmbed retraining from a searched mask (SURVEY.md §2.1 #7)",
-    "tt_emb": "FBTT-Embedding CUDA extension, not in the reference tree (SURVEY.md §2.3 K3-K12); "
-              "use 'tt_emb_torch'",
+    **{key: _SEARCH for key in ("optembed_d", "optembed_d_retrain", "optembed", "optembed_retrain",
+                                "deepfm_optembed_retrain")},
+    "tt_emb": "FBTT-Embedding CUDA extension, not in the reference tree (SURVEY.md §2.3 K3-K12); use 'tt_emb_torch'",
 }
 
 
-def get_embedding(
-    embedding_config: Dict,
-    field_dims: Union[int, List[int]],
-    hidden_size: int,
-    mode: Optional[str] = None,
-    field_name: str = "",
-) -> IEmbedding:
+def get_embedding(embedding_config: Dict, field_dims: Union[int, List[int]], hidden_size: int,
+                  mode: Optional[str] = None, field_name: str = "") -> IEmbedding:
+    """Build the embedding a config names.  The caller's dict is left as it was (the reference pops "name" from a
+    deep copy and puts it back)."""
     assert mode in [None, "sum", "mean", "max"], "Unsupported mode"
-    name = embedding_config["name"]
-    embedding_config = copy.deepcopy(embedding_config)
-    embedding_config.pop("name")
-
-    if name == "vanilla":
-        emb = VanillaEmbedding(field_dims, hidden_size, mode=mode, **embedding_config)
-    elif name in OUT_OF_SCOPE:
+    kwargs = copy.deepcopy(embedding_config)
+    name = kwargs.pop("name")
+    if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"embedding '{name}' is outside this build's scope: {OUT_OF_SCOPE[name]}")
-    elif name not in NAME_TO_CLS:
+    if name not in NAME_TO_CLS:
         raise NotImplementedError(f"{name} not found in mapping from name to class")
-    else:
-        if name.startswith("pep") or name.startswith("cerp"):
-            embedding_config["field_name"] = field_name
-        if name == "deepfm_optembed_d":
-            embedding_config["t_init"] = None      # mask E disabled (reference __init__.py:65-67)
-        cls = NAME_TO_CLS[name]
-        emb = cls(field_dims, hidden_size, mode=mode, **embedding_config)
-
-    embedding_config["name"] = name
-    return emb
+    kwargs.update(_FORCED[name])
+    if name in _WANTS_FIELD_NAME:
+        kwargs["field_name"] = field_name
+    return NAME_TO_CLS[name](field_dims, hidden_size, mode=mode, **kwargs)
 
 
 def detect_special(config: Dict[str, Any]) -> Tuple[Optional[str], bool]:
