@@ -57,11 +57,13 @@ struct GemmArgs {
 };
 
 constexpr int BM = 64, BN = 64, BK = 32, LDSS = BK + 4;
+constexpr int NLD = BM * BK / 4 / 256;   // float4 loads per thread and operand tile
+constexpr int KQ = BK / 4;               // float4 per tile row (k contiguous)
 
 // Stage a [64 rows][32 k] tile of an operand into LDS (row = output index, k contiguous).
 // trans == 0: global is [row][k] (k contiguous);  trans == 1: global is [k][row].
 struct Staged {
-  float4 v[2];
+  float4 v[NLD];
 };
 
 __device__ __forceinline__ float4 guarded4(const float *p, long long off, int nvalid, bool aligned) {
@@ -87,12 +89,12 @@ __device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int ro
   Staged s;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = t + i * 256;
     if constexpr (!TRANS) {
-      int r = row0 + (f >> 3);
+      int r = row0 + (f / KQ);
       r = r < nrows ? r : nrows - 1;
-      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)r * ld + k0 + (f & 7) * 4);
+      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)r * ld + k0 + (f % KQ) * 4);
     } else {
       int r = row0 + (f & 15) * 4;          // nrows % 4 == 0 on this path: a group is all-in or all-out
       r = r < nrows ? r : nrows - 4;
@@ -106,19 +108,19 @@ __device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int ro
 // stage_load_fast); consecutive k-tiles are a constant stride apart, so the pipelined loop keeps these as
 // loop-carried registers and never recomputes an address next to an in-flight load.
 struct TilePtr {
-  const float *p[2];
+  const float *p[NLD];
 };
 template <int TRANS>
 __device__ __forceinline__ TilePtr tile_ptrs(const float *P, int ld, int row0, int nrows, int k0) {
   TilePtr tp;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = t + i * 256;
     if constexpr (!TRANS) {
-      int r = row0 + (f >> 3);
+      int r = row0 + (f / KQ);
       r = r < nrows ? r : nrows - 1;
-      tp.p[i] = P + (long long)r * ld + k0 + (f & 7) * 4;
+      tp.p[i] = P + (long long)r * ld + k0 + (f % KQ) * 4;
     } else {
       int r = row0 + (f & 15) * 4;
       r = r < nrows ? r : nrows - 4;
@@ -129,8 +131,8 @@ __device__ __forceinline__ TilePtr tile_ptrs(const float *P, int ld, int row0, i
 }
 __device__ __forceinline__ Staged load_tile(const TilePtr &tp) {
   Staged s;
-  s.v[0] = *reinterpret_cast<const float4 *>(tp.p[0]);
-  s.v[1] = *reinterpret_cast<const float4 *>(tp.p[1]);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) s.v[i] = *reinterpret_cast<const float4 *>(tp.p[i]);
   return s;
 }
 
@@ -140,10 +142,10 @@ __device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int
   Staged s;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = t + i * 256;
     if constexpr (!TRANS) {
-      const int row = f >> 3, kq = (f & 7) * 4;
+      const int row = f / KQ, kq = (f % KQ) * 4;
       const int r = row0 + row, k = k0 + kq;
       const int nv = (r < nrows) ? (K - k) : 0;
       s.v[i] = guarded4(P, (long long)r * ld + k, nv, aligned);
@@ -161,10 +163,10 @@ template <int TRANS>
 __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = t + i * 256;
     if constexpr (!TRANS) {
-      const int row = f >> 3, kq = (f & 7) * 4;
+      const int row = f / KQ, kq = (f % KQ) * 4;
       *reinterpret_cast<float4 *>(&T[row][kq]) = s.v[i];
     } else {
       const int kk = f >> 4, mq = (f & 15) * 4;
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
       auto advance = [&]() {
         const long long da = tl < last ? stepA : 0, db = tl < last ? stepB : 0;
         tl += tl < last ? 1 : 0;
-        pa.p[0] += da; pa.p[1] += da;
-        pb.p[0] += db; pb.p[1] += db;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { pa.p[i] += da; pb.p[i] += db; }
       };
       __syncthreads();
       Staged r0a = load_tile(pa), r0b = load_tile(pb);

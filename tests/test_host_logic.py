@@ -103,3 +103,69 @@ def test_dhe_seeded_constants_and_counter():
 def test_cerp_threshold_init_and_entity_per_row():
     emb = get_embedding({"name": "cerp", "bucket_size": 10}, [13, 29, 7], 8, field_name="x")
     assert emb.q_entity_per_row == 5 and torch.all(emb.q_threshold == -100.0)
+
+
+# ------------------------------------------------------------------ sharded lookup: host-side pieces
+def test_bucket_capacity_and_row_ownership():
+    from recsys_benchmark_amd.sharded import bucket_capacity, local_num_rows
+
+    assert bucket_capacity(1000, 1, 1.25) == 1000                       # one rank: every lookup stays home
+    n = 4096 * 26
+    for world in (2, 4, 8):
+        cap = bucket_capacity(n, world, 1.25)
+        mean = -(-n // world)
+        assert mean < cap <= n and cap >= int(mean * 1.25)
+        assert bucket_capacity(n, world, float(world)) == n             # slack = world can never overflow
+    assert sum(local_num_rows(33_762_577, r, 8) for r in range(8)) == 33_762_577
+
+
+def test_routing_restatement_properties():
+    """The torch restatement the HIP router is checked against (oracle/sharded_ops.py): every lookup gets a unique
+    slot in its owner's bucket in lookup order; unused slots address the owner's sink row; overflow and
+    out-of-range lookups land on the dump slot."""
+    from oracle.sharded_ops import TorchOps
+
+    gen = torch.Generator().manual_seed(0)
+    world, N, cap = 4, 1003, 90
+    x = torch.randint(0, N, (60, 5), generator=gen)
+    x[3, 2], x[7, 0] = N + 5, -2
+    of = torch.zeros(1, dtype=torch.int32)
+    send, slot = TorchOps.route_buckets(x, None, world, N, cap, of)
+    flat, s = x.view(-1), slot.view(-1)
+    ok = (flat >= 0) & (flat < N)
+    assert bool((s[~ok] == world * cap).all()) and int(of) == 0
+    live = s[ok]
+    assert live.unique().numel() == live.numel() and bool((live // cap == flat[ok] % world).all())
+    assert torch.equal(send[live], flat[ok] // world)
+    for w in range(world):
+        mine = live[live // cap == w]
+        assert torch.equal(mine, torch.sort(mine)[0]) and int(mine.min()) == w * cap    # lookup order, packed from the left
+        pad = torch.ones(cap, dtype=torch.bool)
+        pad[mine - w * cap] = False
+        assert bool((send[w * cap:(w + 1) * cap][pad] == (N - w + world - 1) // world).all())   # sink row
+    of2 = torch.zeros(1, dtype=torch.int32)
+    _, slot2 = TorchOps.route_buckets(torch.zeros(50, 1, dtype=torch.int64), None, world, N, 8, of2)
+    assert int(of2) == 1 and int((slot2 == world * 8).sum()) == 42
+
+
+def test_tt_grouped_path_selection():
+    from recsys_benchmark_amd import _kernels
+
+    assert _kernels.tt_grouped_supported(100_000, [2, 2, 4], [1, 128, 96, 1])
+    assert not _kernels.tt_grouped_supported(100, [2, 2, 4], [1, 128, 96, 1])            # too few lookups
+    assert not _kernels.tt_grouped_supported(100_000, [16], [1, 1])                      # a single core is a plain table
+    assert not _kernels.tt_grouped_supported(100_000, [4, 4], [1, 6, 1])                 # rank not a multiple of 4
+    assert _kernels._tt_last_fast(4, 96, 4) and _kernels._tt_last_fast(2, 64, 8)
+    assert not _kernels._tt_last_fast(4, 96, 3)                                          # 12 outputs do not tile a wave
+    assert not _kernels._tt_last_fast(8, 128, 4)                                         # chunk of 1024 floats > 512
+
+
+def test_registry_forced_arguments_and_field_name():
+    from recsys_benchmark_amd.embeddings import _FORCED, _WANTS_FIELD_NAME
+
+    assert _FORCED["deepfm_optembed_d"] == {"t_init": None} and _FORCED["deepfm_optembed"] == {}
+    assert _WANTS_FIELD_NAME == {"pep", "pep_retrain", "cerp", "cerp_retrain"}
+    cfg = {"name": "qr", "divider": 3}
+    import recsys_benchmark_amd.embeddings as E
+    emb = E.get_embedding(cfg, [5, 7], 8)
+    assert cfg == {"name": "qr", "divider": 3} and type(emb).__name__ == "QRHashingEmbedding"
