@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--ring", type=int, default=16, help="distinct pre-generated id batches rotated through, one per step")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded model even on 1 GPU (exercises the N>1 path)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
     args = ap.parse_args()
 
     # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
@@ -135,7 +136,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import recsys_benchmark_amd as pkg
+    from recsys_benchmark_amd import mlp as _mlp
     from recsys_benchmark_amd.profiling import KernelTimer
+
+    # the MLP's two backward GEMMs per layer: let PyTorch pick the fastest rocBLAS/hipBLASLt solution per shape
+    # (searched once, during the warm-up steps)
+    _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
 
     dims, D, hidden, p_drop = CRITEO_KAGGLE_26, 16, [400, 400, 400], 0.5
     F, B = len(dims), args.batch

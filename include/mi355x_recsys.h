@@ -356,6 +356,9 @@ MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate
  * 1/(1-p); the keep mask (1 byte/element) and save_mean/save_rstd fp32[N] feed the backward.
  * bump_seed (training BN only): the statistics launch first does seed[0] += 1 — one new dropout
  * stream per pass without a separate launch; num_batches_tracked (nullable) gets += 1.
+ * mean_offset (nullable, training BN): added to the batch mean in the running_mean update only.  A Linear's
+ * bias cancels inside a training-mode BatchNorm (it shifts z and its batch mean alike), so the caller may run the
+ * contraction WITHOUT the bias, pass the bias here, and get the same y, gradients and running statistics.
  * Backward: dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
  * dZ = gamma*rstd*(dyh - dbeta/M - zh*dgamma/M) in training.
  */
@@ -364,8 +367,8 @@ MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_
                                   const float *beta, float *running_mean, float *running_var,
                                   float momentum, float eps, float p, int64_t *seed,
                                   int64_t salt, int32_t bump_seed, int64_t *num_batches_tracked,
-                                  float *stats, float *Y, uint8_t *keep, float *save_mean,
-                                  float *save_rstd, void *stream);
+                                  float *stats, const float *mean_offset, float *Y, uint8_t *keep,
+                                  float *save_mean, float *save_rstd, void *stream);
 MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M,
                                   int32_t N, int32_t has_bn, int32_t training,
                                   const uint8_t *keep, float p, const float *gamma,

@@ -121,6 +121,7 @@ struct BnArgs {
   int M, N;
   int has_bn, training;
   const float *s1, *s2;          // training stats (shifted sums)
+  const float *mean_offset;      // [N] added to the batch mean in the running_mean update only (nullable)
   const float *gamma, *beta;     // nullable = 1 / 0
   float *running_mean, *running_var;
   float momentum, eps;
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_relu_drop_fwd(BnArgs a) {
             const float ub = a.M > 1 ? (float)a.M / (float)(a.M - 1) : 1.f;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-              a.running_mean[n0 + j] = (1.f - a.momentum) * a.running_mean[n0 + j] + a.momentum * mean.v[j];
+              const float mo = a.mean_offset ? a.mean_offset[n0 + j] : 0.f;
+              a.running_mean[n0 + j] = (1.f - a.momentum) * a.running_mean[n0 + j] + a.momentum * (mean.v[j] + mo);
               a.running_var[n0 + j] = (1.f - a.momentum) * a.running_var[n0 + j] + a.momentum * var.v[j] * ub;
             }
           }
@@ -447,8 +449,8 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
                            const float *gamma, const float *beta, float *running_mean, float *running_var,
                            float momentum, float eps, float p, int64_t *seed, int64_t salt, int32_t bump_seed,
                            int64_t *num_batches_tracked,
-                           float *stats /*[2,N] caller-zeroed; training BN only*/, float *Y, uint8_t *keep,
-                           float *save_mean, float *save_rstd, void *stream) {
+                           float *stats /*[2,N] caller-zeroed; training BN only*/, const float *mean_offset,
+                           float *Y, uint8_t *keep, float *save_mean, float *save_rstd, void *stream) {
   if (M < 0 || N < 0 || p < 0.f || p >= 1.f) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
   if (!Z || !Y) return MI_ERR_INVALID_ARG;
@@ -468,6 +470,7 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   BnArgs a;
   a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = has_bn; a.training = training;
   a.s1 = stats; a.s2 = stats ? stats + N : nullptr;
+  a.mean_offset = (has_bn && training) ? mean_offset : nullptr;
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.momentum = momentum; a.eps = eps; a.p = p; a.seed = seed; a.salt = salt;
   a.Y = Y; a.keep = drop ? keep : nullptr; a.save_mean = save_mean; a.save_rstd = save_rstd;

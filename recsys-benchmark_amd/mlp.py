@@ -30,6 +30,37 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
     return w
 
 
+# PyTorch's TunableOp searches the rocBLAS / hipBLASLt solutions for each GEMM shape at its first call (~1 s per
+# shape) and then always launches the fastest.  Measured on the tail's shapes: input-gradient
+# 20 -> 16.5 us, weight-gradient 27 -> 25 us, but the bias-fused forward gets slower — so it is applied to the two
+# backward products only, and only when a training loop opts in (it makes the first step of every new shape slow).
+TUNE_BACKWARD_GEMMS = False
+
+
+class _tuned_gemms:
+    _named = False
+
+    def __enter__(self):
+        self.on = bool(TUNE_BACKWARD_GEMMS)
+        if self.on:
+            self.was = torch.cuda.tunable.is_enabled()
+            if not _tuned_gemms._named:      # keep its results file out of the working directory
+                import os
+                import tempfile
+
+                torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), "mi355x_recsys_tunableop.csv"), True)
+                torch.cuda.tunable.set_max_tuning_duration(10)       # ms per candidate: ~20 us GEMMs need no more
+                torch.cuda.tunable.set_max_tuning_iterations(50)
+                _tuned_gemms._named = True
+            torch.cuda.tunable.enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.tunable.enable(self.was)
+        return False
+
+
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -39,18 +70,25 @@ class _LinearFn(torch.autograd.Function):
     workspace slice), or — zero_db — that zeroed slice itself when z feeds a training BatchNorm."""
 
     @staticmethod
-    def forward(ctx, x, W, b, db_buf, zero_db: bool):
+    def forward(ctx, x, W, b, db_buf, zero_db: bool, skip_bias: bool = False):
+        """skip_bias: z feeds a training-mode BatchNorm, where the bias cancels (it shifts z and its batch mean
+        alike): the contraction runs without it — a plain GEMM, which TunableOp serves better than the
+        bias-fused one — and the BatchNorm pass adds it to the running mean (mean_offset)."""
         ctx.save_for_backward(x, W, db_buf)
         ctx.has_bias = b is not None
         ctx.zero_db = zero_db
-        return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+        if b is None or skip_bias:
+            with _tuned_gemms():
+                return x @ W.t()
+        return torch.addmm(b, x, W.t())
 
     @staticmethod
     def backward(ctx, g):
         x, W, db_buf = ctx.saved_tensors
         g = g.contiguous()
-        dx = g @ W if ctx.needs_input_grad[0] else None
-        dW = g.t() @ x if ctx.needs_input_grad[1] else None
+        with _tuned_gemms():
+            dx = g @ W if ctx.needs_input_grad[0] else None
+            dW = g.t() @ x if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             M, N = g.shape
@@ -58,7 +96,7 @@ class _LinearFn(torch.autograd.Function):
             if not ctx.zero_db:
                 _lib.check(_lib.load().mi_colsum(g.data_ptr(), N, None, 0, db.data_ptr(), None, M, N,
                                                  _lib.stream_ptr(g.device)), "mi_colsum")
-        return dx, dW, db, None, None
+        return dx, dW, db, None, None, None
 
 
 class _Linear1Fn(torch.autograd.Function):
@@ -111,7 +149,7 @@ class _Linear1Fn(torch.autograd.Function):
 class _BNReLUDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, has_bn, training, momentum, eps, p, seed, salt,
-                bump_seed, stats, dgb):
+                bump_seed, stats, dgb, mean_offset=None):
         dev = _lib.require_gpu(z)
         z = _kernels._f32c(z)
         M, N = z.shape
@@ -127,7 +165,8 @@ class _BNReLUDropFn(torch.autograd.Function):
                 z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(gamma), _lib.ptr(beta),
                 _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps), float(p if drop else 0.0),
                 _lib.ptr(seed), int(salt), int(bool(bump_seed and bn_train)), _lib.ptr(nbt) if bn_train else None,
-                _lib.ptr(stats) if bn_train else None, y.data_ptr(), _lib.ptr(keep),
+                _lib.ptr(stats) if bn_train else None, _lib.ptr(mean_offset) if bn_train else None, y.data_ptr(),
+                _lib.ptr(keep),
                 save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None, _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_fwd",
         )
@@ -153,7 +192,7 @@ class _BNReLUDropFn(torch.autograd.Function):
         )
         dgamma = dgb[:N] if (has_bn and gamma is not None and ctx.needs_input_grad[1]) else None
         dbeta = dgb[N:2 * N] if (has_bn and beta is not None and ctx.needs_input_grad[2]) else None
-        return (dz, dgamma, dbeta) + (None,) * 13
+        return (dz, dgamma, dbeta) + (None,) * 14
 
 
 def _groups(seq: nn.Sequential) -> List[List]:
@@ -226,7 +265,8 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         N = lin.out_features
         training_bn = bn is not None and bn.training
         p = dp.p if (dp is not None and dp.training) else 0.0
-        z = _LinearFn.apply(x, lin.weight, lin.bias, take(N), bool(training_bn))
+        skip_bias = bool(training_bn and lin.bias is not None)
+        z = _LinearFn.apply(x, lin.weight, lin.bias, take(N), bool(training_bn), skip_bias)
         stats, dgb = take(2 * N), take(2 * N)
         bump_in_kernel = False
         if p > 0.0 and need_bump:
@@ -241,7 +281,7 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
             bn.num_batches_tracked if bn is not None else None,
             bn is not None, bool(p > 0.0) if bn is None else bool(bn.training),
             bn.momentum if bn is not None else 0.0, bn.eps if bn is not None else 0.0, p, seed, 7919 * (k + 1),
-            bump_in_kernel, stats, dgb)
+            bump_in_kernel, stats, dgb, lin.bias if skip_bias else None)
     if last_add is not None:
         x = x + last_add.view(-1, *([1] * (x.dim() - 1)))
     return x
