@@ -56,14 +56,16 @@ struct GemmArgs {
   const long long *kseg;  // [batch][3] = (first reduction row, rows, C slice): per-z K range, C + slice*sC, atomic adds
 };
 
-constexpr int BM = 64, BN = 64, BK = 32, LDSS = BK + 4;
-constexpr int NLD = BM * BK / 4 / 256;   // float4 loads per thread and operand tile
+constexpr int BN = 64, BK = 32, LDSS = BK + 4;
 constexpr int KQ = BK / 4;               // float4 per tile row (k contiguous)
+// The A/C tile is 64 or 128 rows (template BMT): 128 x 64 feeds two MFMA blocks per B fragment read and is used for
+// large problems only (see mi_gemm_f32).
 
 // Stage a [64 rows][32 k] tile of an operand into LDS (row = output index, k contiguous).
 // trans == 0: global is [row][k] (k contiguous);  trans == 1: global is [k][row].
+template <int ROWS>
 struct Staged {
-  float4 v[NLD];
+  float4 v[ROWS * BK / 4 / 256];   // float4 loads per thread for a [ROWS][BK] operand tile
 };
 
 __device__ __forceinline__ float4 guarded4(const float *p, long long off, int nvalid, bool aligned) {
@@ -84,9 +86,10 @@ __device__ __forceinline__ float4 guarded4(const float *p, long long off, int nv
 // Rows past the operand's end (edge workgroups) are CLAMPED to the last valid row / row group: the
 // duplicated data only feeds output rows or columns the epilogue never stores, and every address
 // stays inside the buffer — so edge workgroups run the same branch-free pipeline.
-template <int TRANS>
-__device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int row0, int nrows, int k0) {
-  Staged s;
+template <int TRANS, int ROWS>
+__device__ __forceinline__ Staged<ROWS> stage_load_fast(const float *P, int ld, int row0, int nrows, int k0) {
+  Staged<ROWS> s;
+  constexpr int NLD = ROWS * BK / 4 / 256, RQ = ROWS / 4;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -96,9 +99,9 @@ __device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int ro
       r = r < nrows ? r : nrows - 1;
       s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)r * ld + k0 + (f % KQ) * 4);
     } else {
-      int r = row0 + (f & 15) * 4;          // nrows % 4 == 0 on this path: a group is all-in or all-out
+      int r = row0 + (f % RQ) * 4;          // nrows % 4 == 0 on this path: a group is all-in or all-out
       r = r < nrows ? r : nrows - 4;
-      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(k0 + (f >> 4)) * ld + r);
+      s.v[i] = *reinterpret_cast<const float4 *>(P + (long long)(k0 + (f / RQ)) * ld + r);
     }
   }
   return s;
@@ -107,12 +110,14 @@ __device__ __forceinline__ Staged stage_load_fast(const float *P, int ld, int ro
 // The two float4 addresses a thread fetches of a [64 rows][32 k] tile at k offset k0 (same mapping as
 // stage_load_fast); consecutive k-tiles are a constant stride apart, so the pipelined loop keeps these as
 // loop-carried registers and never recomputes an address next to an in-flight load.
+template <int ROWS>
 struct TilePtr {
-  const float *p[NLD];
+  const float *p[ROWS * BK / 4 / 256];
 };
-template <int TRANS>
-__device__ __forceinline__ TilePtr tile_ptrs(const float *P, int ld, int row0, int nrows, int k0) {
-  TilePtr tp;
+template <int TRANS, int ROWS>
+__device__ __forceinline__ TilePtr<ROWS> tile_ptrs(const float *P, int ld, int row0, int nrows, int k0) {
+  TilePtr<ROWS> tp;
+  constexpr int NLD = ROWS * BK / 4 / 256, RQ = ROWS / 4;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -122,24 +127,26 @@ __device__ __forceinline__ TilePtr tile_ptrs(const float *P, int ld, int row0, i
       r = r < nrows ? r : nrows - 1;
       tp.p[i] = P + (long long)r * ld + k0 + (f % KQ) * 4;
     } else {
-      int r = row0 + (f & 15) * 4;
+      int r = row0 + (f % RQ) * 4;
       r = r < nrows ? r : nrows - 4;
-      tp.p[i] = P + (long long)(k0 + (f >> 4)) * ld + r;
+      tp.p[i] = P + (long long)(k0 + (f / RQ)) * ld + r;
     }
   }
   return tp;
 }
-__device__ __forceinline__ Staged load_tile(const TilePtr &tp) {
-  Staged s;
+template <int ROWS>
+__device__ __forceinline__ Staged<ROWS> load_tile(const TilePtr<ROWS> &tp) {
+  Staged<ROWS> s;
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) s.v[i] = *reinterpret_cast<const float4 *>(tp.p[i]);
+  for (int i = 0; i < ROWS * BK / 4 / 256; ++i) s.v[i] = *reinterpret_cast<const float4 *>(tp.p[i]);
   return s;
 }
 
-template <int TRANS>
-__device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int row0, int nrows, int k0, int K,
-                                                     bool aligned) {
-  Staged s;
+template <int TRANS, int ROWS>
+__device__ __forceinline__ Staged<ROWS> stage_load_guarded(const float *P, int ld, int row0, int nrows, int k0, int K,
+                                                           bool aligned) {
+  Staged<ROWS> s;
+  constexpr int NLD = ROWS * BK / 4 / 256, RQ = ROWS / 4;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -150,7 +157,7 @@ __device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int
       const int nv = (r < nrows) ? (K - k) : 0;
       s.v[i] = guarded4(P, (long long)r * ld + k, nv, aligned);
     } else {
-      const int kk = f >> 4, mq = (f & 15) * 4;
+      const int kk = f / RQ, mq = (f % RQ) * 4;
       const int k = k0 + kk, r = row0 + mq;
       const int nv = (k < K) ? (nrows - r) : 0;
       s.v[i] = guarded4(P, (long long)k * ld + r, nv, aligned);
@@ -159,8 +166,9 @@ __device__ __forceinline__ Staged stage_load_guarded(const float *P, int ld, int
   return s;
 }
 
-template <int TRANS>
-__device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
+template <int TRANS, int ROWS>
+__device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged<ROWS> &s) {
+  constexpr int NLD = ROWS * BK / 4 / 256, RQ = ROWS / 4;
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -169,7 +177,7 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
       const int row = f / KQ, kq = (f % KQ) * 4;
       *reinterpret_cast<float4 *>(&T[row][kq]) = s.v[i];
     } else {
-      const int kk = f >> 4, mq = (f & 15) * 4;
+      const int kk = f / RQ, mq = (f % RQ) * 4;
       T[mq + 0][kk] = s.v[i].x;
       T[mq + 1][kk] = s.v[i].y;
       T[mq + 2][kk] = s.v[i].z;
@@ -178,21 +186,27 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged &s) {
   }
 }
 
-__device__ __forceinline__ void mma_tile(floatx16 &acc, float (*As)[LDSS], float (*Bs)[LDSS], int ar, int br, int kh) {
+// RB 32-row blocks of A per wave against one 32-column block of B: the B fragment is read once per RB MFMA groups
+template <int RB>
+__device__ __forceinline__ void mma_tile(floatx16 (&acc)[RB], float (*As)[LDSS], float (*Bs)[LDSS], int ar, int br, int kh) {
 #pragma unroll
   for (int c = 0; c < BK / 8; ++c) {
-    const float4 av = *reinterpret_cast<const float4 *>(&As[ar][c * 8 + kh * 4]);
     const float4 bv = *reinterpret_cast<const float4 *>(&Bs[br][c * 8 + kh * 4]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const float4 av = *reinterpret_cast<const float4 *>(&As[ar + rb * 32][c * 8 + kh * 4]);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[rb], 0, 0, 0);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[rb], 0, 0, 0);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[rb], 0, 0, 0);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[rb], 0, 0, 0);
+    }
   }
 }
 
 // TA: A is [k][m] in memory; BT: B is staged transposed, i.e. B is [k][n] in memory (transB == 0)
-template <int TA, int BT>
+template <int TA, int BT, int BMT>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+  constexpr int BM = BMT, RB = BMT / 64, WROWS = BMT / 2;   // rows per workgroup tile / 32-row blocks and rows per wave
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDSS];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
   const int z = blockIdx.z / a.splitk;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int i = lane & 31, kh = lane >> 5;
-  const int ar = wr * 32 + i, br = wc * 32 + i;
+  const int ar = wr * WROWS + i, br = wc * 32 + i;
 
   const float *A = a.A + z * a.sA;
   const float *B = a.B + z * a.sB;
@@ -219,9 +233,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     B = a.B + k0 * (BT ? a.ldb : 1);
   }
 
-  floatx16 acc;
+  floatx16 acc[RB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
 
   const int ktiles = (a.K + BK - 1) / BK;
   const int all = ktiles * a.kgroups;
@@ -239,13 +255,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     int it = first;
     while (it < total) {
       if (!is_full(it)) {   // K tail of a group: one unpipelined guarded tile
-        const Staged ta = stage_load_guarded<TA>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, true);
-        const Staged tb = stage_load_guarded<BT>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, true);
+        const Staged<BM> ta = stage_load_guarded<TA, BM>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, true);
+        const Staged<BN> tb = stage_load_guarded<BT, BN>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, true);
         __syncthreads();
-        stage_store<TA>(As[0], ta);
-        stage_store<BT>(Bs[0], tb);
+        stage_store<TA, BM>(As[0], ta);
+        stage_store<BT, BN>(Bs[0], tb);
         __syncthreads();
-        mma_tile(acc, As[0], Bs[0], ar, br, kh);
+        mma_tile<RB>(acc, As[0], Bs[0], ar, br, kh);
         ++it;
         continue;
       }
@@ -258,25 +274,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
       // load's result, which forces vmcnt(0) at the top of every iteration and halves the prefetch distance:
       // seen in the ISA of the previous version.)  Loads past the run are clamped re-loads, never stored.
       const int last = run_end - 1;
-      TilePtr pa = tile_ptrs<TA>(A + grp * a.gA, a.lda, m0, a.M, (it % ktiles) * BK);
-      TilePtr pb = tile_ptrs<BT>(B + grp * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK);
+      TilePtr<BM> pa = tile_ptrs<TA, BM>(A + grp * a.gA, a.lda, m0, a.M, (it % ktiles) * BK);
+      TilePtr<BN> pb = tile_ptrs<BT, BN>(B + grp * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK);
       const long long stepA = TA ? (long long)BK * a.lda : BK, stepB = BT ? (long long)BK * a.ldb : BK;
       int tl = it;                                   // the tile the running pointers address
       auto advance = [&]() {
         const long long da = tl < last ? stepA : 0, db = tl < last ? stepB : 0;
         tl += tl < last ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) { pa.p[i] += da; pb.p[i] += db; }
+        for (int q = 0; q < BM * BK / 4 / 256; ++q) pa.p[q] += da;
+#pragma unroll
+        for (int q = 0; q < BN * BK / 4 / 256; ++q) pb.p[q] += db;
       };
       __syncthreads();
-      Staged r0a = load_tile(pa), r0b = load_tile(pb);
+      Staged<BM> r0a = load_tile(pa);
+      Staged<BN> r0b = load_tile(pb);
       advance();
-      stage_store<TA>(As[0], r0a);
-      stage_store<BT>(Bs[0], r0b);
+      stage_store<TA, BM>(As[0], r0a);
+      stage_store<BT, BN>(Bs[0], r0b);
       r0a = load_tile(pa);
       r0b = load_tile(pb);
       advance();
-      Staged r1a, r1b;
+      Staged<BM> r1a;
+      Staged<BN> r1b;
       __syncthreads();
       int s2 = it;
       while (true) {
@@ -285,11 +305,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         r1b = load_tile(pb);
         advance();
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(acc, As[0], Bs[0], ar, br, kh);
+        mma_tile<RB>(acc, As[0], Bs[0], ar, br, kh);
         __builtin_amdgcn_sched_barrier(0);
         if (s2 + 1 < run_end) {
-          stage_store<TA>(As[1], r0a);
-          stage_store<BT>(Bs[1], r0b);
+          stage_store<TA, BM>(As[1], r0a);
+          stage_store<BT, BN>(Bs[1], r0b);
         }
         __syncthreads();
         if (++s2 >= run_end) break;
@@ -298,11 +318,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         r0b = load_tile(pb);
         advance();
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(acc, As[1], Bs[1], ar, br, kh);
+        mma_tile<RB>(acc, As[1], Bs[1], ar, br, kh);
         __builtin_amdgcn_sched_barrier(0);
         if (s2 + 1 < run_end) {
-          stage_store<TA>(As[0], r1a);
-          stage_store<BT>(Bs[0], r1b);
+          stage_store<TA, BM>(As[0], r1a);
+          stage_store<BT, BN>(Bs[0], r1b);
         }
         __syncthreads();
         if (++s2 >= run_end) break;
@@ -311,13 +331,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     }
   } else {
     for (int it = first; it < total; ++it) {
-      const Staged ta = stage_load_guarded<TA>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, a.alignedA);
-      const Staged tb = stage_load_guarded<BT>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, a.alignedB);
+      const Staged<BM> ta = stage_load_guarded<TA, BM>(A + (it / ktiles) * a.gA, a.lda, m0, a.M, (it % ktiles) * BK, a.K, a.alignedA);
+      const Staged<BN> tb = stage_load_guarded<BT, BN>(B + (it / ktiles) * a.gB, a.ldb, n0, a.N, (it % ktiles) * BK, a.K, a.alignedB);
       __syncthreads();
-      stage_store<TA>(As[0], ta);
-      stage_store<BT>(Bs[0], tb);
+      stage_store<TA, BM>(As[0], ta);
+      stage_store<BT, BN>(Bs[0], tb);
       __syncthreads();
-      mma_tile(acc, As[0], Bs[0], ar, br, kh);
+      mma_tile<RB>(acc, As[0], Bs[0], ar, br, kh);
     }
   }
 
@@ -330,10 +350,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   float *C2 = a.C2 ? a.C2 + z * a.sC2 : nullptr;
   const float bn = (a.bias && (a.epi == EPI_BIAS || a.epi == EPI_CROSS)) ? a.bias[n] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+  for (int rr = 0; rr < 16 * RB; ++rr) {
+    const int rb = rr >> 4, r = rr & 15;
+    const int m = m0 + wr * WROWS + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
     if (m >= a.M) continue;
-    const float v = acc[r];
+    const float v = acc[rb][r];
     const long long co = (long long)m * a.ldc + n;
     if (a.splitk > 1 || a.kseg) {
       atomicAdd(C + co, v);
@@ -409,14 +430,25 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   a.kseg = nullptr;
   a.alignedA = aligned16(A) && (lda % 4 == 0) && (sA % 4 == 0) && (gA % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0) && (gB % 4 == 0);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splitk);
+  // 128-row tiles only where they still leave >= 4 workgroups per CU (8192^3: 119 -> 125 TFLOP/s).  At the tail /
+  // CrossNet shapes (M = 4096, N ~ 400) they are SLOWER (26 vs 23 us): 224 workgroups = one per CU leaves nothing to
+  // overlap a workgroup's barrier and LDS phases with, while 448 64-row workgroups run 1.75 per CU.
+  const long long tiles128 = (long long)((N + BN - 1) / BN) * ((M + 127) / 128) * batch;
+  const bool tall = splitk == 1 && tiles128 >= 1024;
+  const int bm = tall ? 128 : 64;
+  dim3 grid((N + BN - 1) / BN, (M + bm - 1) / bm, batch * splitk);
   if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
   hipEvent_t ea, eb;
   const bool prof = mi::prof_acquire("gemm_f32", &ea, &eb);
 #define GO(TA, BT)                                                                                      \
   do {                                                                                                  \
-    if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
-    else hipLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, a);          \
+    if (tall) {                                                                                         \
+      if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT, 128>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
+      else hipLaunchKernelGGL((k_gemm_f32<TA, BT, 128>), grid, dim3(256), 0, (hipStream_t)stream, a);   \
+    } else {                                                                                            \
+      if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT, 64>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
+      else hipLaunchKernelGGL((k_gemm_f32<TA, BT, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);    \
+    }                                                                                                   \
   } while (0)
   if (a.transA) { if (a.transB) GO(1, 0); else GO(1, 1); }
   else { if (a.transB) GO(0, 0); else GO(0, 1); }
@@ -430,8 +462,8 @@ static int launch_grouped(GemmArgs &a, dim3 grid, const char *name, void *stream
   const bool prof = mi::prof_acquire(name, &ea, &eb);
 #define GO(TA, BT)                                                                                      \
   do {                                                                                                  \
-    if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
-    else hipLaunchKernelGGL((k_gemm_f32<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, a);          \
+    if (prof) hipExtLaunchKernelGGL((k_gemm_f32<TA, BT, 64>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, a); \
+    else hipLaunchKernelGGL((k_gemm_f32<TA, BT, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);      \
   } while (0)
   if (a.transA) { if (a.transB) GO(1, 0); else GO(1, 1); }
   else { if (a.transB) GO(0, 0); else GO(0, 1); }
@@ -467,7 +499,7 @@ int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, 
   a.mtile_b = mtile_b;
   a.alignedA = aligned16(A) && (lda % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
+  dim3 grid((N + BN - 1) / BN, (M + 63) / 64, 1);
   if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
   return launch_grouped(a, grid, "gemm_row_groups", stream);
 }
@@ -485,7 +517,7 @@ int mi_gemm_f32_k_groups(const float *A, const float *B, float *C, int32_t M, in
   a.kseg = reinterpret_cast<const long long *>(kseg);
   a.alignedA = aligned16(A) && (lda % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nseg);
+  dim3 grid((N + BN - 1) / BN, (M + 63) / 64, nseg);
   if (grid.y > 65535) return MI_ERR_UNSUPPORTED;
   return launch_grouped(a, grid, "gemm_k_groups", stream);
 }
