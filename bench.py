@@ -207,12 +207,12 @@ def main():
     if sharded and not args.no_graph:
         # everything between the collectives (gather+FM+MLP forward, criterion, whole backward) as ONE hipGraph
         try:
-            graphed_step = model.make_graphed_step(lossf, B)
+            graphed_step = model.make_graphed_step(lossf, B, static_labels=y)   # y is refreshed by the batch copy
             graphed_local = True
 
             def step():
                 next_batch()
-                graphed_step(x, y)
+                graphed_step(x)
         except Exception as e:  # noqa: BLE001 - keep the run alive: the eager step is always valid
             print(f"[bench] rank {rank}: capturing the local compute failed ({type(e).__name__}: {e}); eager",
                   file=sys.stderr, flush=True)

@@ -241,7 +241,7 @@ class ShardedDeepFM(nn.Module):
         torch.cuda.synchronize(dev)
         dist.barrier(group=self.group)
 
-    def make_graphed_step(self, criterion, batch_size: int):
+    def make_graphed_step(self, criterion, batch_size: int, static_labels: Optional[torch.Tensor] = None):
         """A whole training step `step(x, y) -> loss` for a fixed batch size with everything between the
         collectives — slot gather + FM + MLP forward, the criterion, and the complete backward down to the
         outgoing gradient rows and one FLAT buffer of the replicated tail's gradients — replayed as ONE
@@ -249,7 +249,9 @@ class ShardedDeepFM(nn.Module):
         two strided scales that form the shards' COO gradients, and the flat all-reduce: no autograd
         bookkeeping, no host sync.  After a step `p.grad` of every parameter is set exactly as by
         `criterion(model(x), y).backward(); model.allreduce_dense_grads()` (dense gradients are views of
-        the flat buffer); the returned loss is a device scalar that the next step overwrites."""
+        the flat buffer); the returned loss is a device scalar that the next step overwrites.
+        static_labels ([batch_size] float, optional): a buffer the caller refreshes itself before every step
+        (then `step(x)` needs no label copy)."""
         F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
         dev = self.embedding_shard.device
         world, group = self.world, self.group
@@ -258,11 +260,14 @@ class ShardedDeepFM(nn.Module):
         dense = self.dense_parameters()
         recv = torch.zeros(S + 1, D + 4, device=dev).requires_grad_(True)
         slot = (torch.arange(batch_size * F, device=dev) % max(S, 1)).view(batch_size, F)
-        ys = torch.zeros(batch_size, device=dev)
+        ys = static_labels if static_labels is not None else torch.zeros(batch_size, device=dev)
+        # d(global-batch mean loss)/d(this rank's mean loss) = 1/world: seeded into the backward so that the table
+        # gradients arrive already averaged and the dense ones only need a SUM all-reduce
+        seed_grad = torch.full((), 1.0 / self.world, device=dev)
 
         def local():
             loss = criterion(self._local_compute(recv, slot), ys)
-            grads = torch.autograd.grad(loss, [recv] + dense)
+            grads = torch.autograd.grad(loss, [recv] + dense, grad_outputs=seed_grad)
             return loss, grads[0], torch.cat([g.reshape(-1) for g in grads[1:]])
 
         torch.cuda.synchronize(dev)
@@ -286,14 +291,13 @@ class ShardedDeepFM(nn.Module):
 
         sizes = [p.numel() for p in dense]
         views = [v.view_as(p) for v, p in zip(flat.split(sizes), dense)]
-        avg = dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else None
-        inv = 1.0 / world
         Wshape, w1shape = tuple(self.embedding_shard.shape), tuple(self.fc_shard.shape)
 
-        def step(x, y):
+        def step(x, y=None):
             if tuple(x.shape) != (batch_size, F):
                 raise ValueError(f"this step was captured for x of shape {(batch_size, F)}, got {tuple(x.shape)}")
-            ys.copy_(y)
+            if y is not None and y.data_ptr() != ys.data_ptr():
+                ys.copy_(y)
             send_rows, _ = self.ops.route_buckets(x, self.offsets, world, self.num_rows, cap, self.bucket_overflow,
                                                   slot_out=slot)
             local_rows = torch.empty_like(send_rows)
@@ -305,19 +309,18 @@ class ShardedDeepFM(nn.Module):
                 g_owner = torch.empty_like(packed)
                 dist.all_to_all_single(g_owner, g_recv[:S], group=group)
                 idx = local_rows.view(1, -1)
-                self.embedding_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, :D] * inv, Wshape,
+                # the received rows are already scaled by 1/world; COO values must be contiguous (torch's sparse
+                # kernels read strided values wrongly), so the two column blocks are copied out
+                self.embedding_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, :D].contiguous(), Wshape,
                                                                     check_invariants=False)
-                self.fc_shard.grad = torch.sparse_coo_tensor(idx, (g_owner[:, D] * inv).view(-1, 1), w1shape,
+                self.fc_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, D:D + 1].contiguous(), w1shape,
                                                              check_invariants=False)
-                if avg is not None:
-                    dist.all_reduce(flat, op=avg, group=group)
-                else:
-                    dist.all_reduce(flat, group=group)
-                    flat.mul_(inv)
+                dist.all_reduce(flat, group=group)
             for p, v in zip(dense, views):
                 p.grad = v
             return loss
 
+        step.keepalive = (seed_grad,)      # read by every replay: must outlive this function's frame
         return step
 
     def forward(self, x):
