@@ -245,6 +245,12 @@ def main():
     pkg.check_index_errors()
     if sharded:
         model.check_overflow()
+    # the timed steps really produced gradients (a replayed graph reading a freed seed tensor would give zeros)
+    # (weights only: a Linear bias in front of a training-mode BatchNorm has an exactly zero gradient)
+    probe = [model._bias.grad] + [p.grad for p in model._deep_branch.parameters() if p.grad is not None and p.dim() == 2][:2]
+    for gprobe in probe:
+        if gprobe is None or not bool(torch.isfinite(gprobe).all()) or float(gprobe.abs().sum()) == 0.0:
+            raise SystemExit("bench: a gradient of the timed steps is missing, zero or non-finite")
 
     # roofline leg: the same step launched eagerly, every library kernel timed by its own dispatch
     # begin/end events (a graph replay cannot carry per-kernel events: probed, they are not stamped).
