@@ -54,6 +54,7 @@ struct GemmArgs {
   // grouped forms (TT-Rec levels, tt_grouped.hip): both null for a plain GEMM
   const int *mtile_b;     // [gridDim.y] B slice of each 64-row tile of A/C (B + idx*sB), -1: tile unused
   const long long *kseg;  // [batch][3] = (first reduction row, rows, C slice): per-z K range, C + slice*sC, atomic adds
+  int xcd_swizzle;        // remap workgroup ids so that the tiles of one XCD are neighbours (plain GEMMs)
 };
 
 constexpr int BN = 64, BK = 32, LDSS = BK + 4;
@@ -211,7 +212,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
   const int z = blockIdx.z / a.splitk;
   const int slice = blockIdx.z % a.splitk;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2: with the natural
+  // order the 7 column tiles of one row tile land on 7 different XCDs and every L2 fetches that A tile again.  The
+  // remap gives XCD x the contiguous range of tiles [x * total/8, ...): neighbours in (row tile, column tile) order
+  // share an L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_swizzle) {
+    const int total = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+    const int x = id & 7, slot = id >> 3, chunk = total >> 3, rem = total & 7;
+    const int logical = x * chunk + (x < rem ? x : rem) + slot;
+    bx = logical % gridDim.x;
+    by = logical / gridDim.x;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wr = w >> 1, wc = w & 1;
   const int i = lane & 31, kh = lane >> 5;
@@ -428,6 +441,7 @@ int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, 
   a.C2 = C2; a.ldc2 = ldc2; a.sC2 = sC2;
   a.mtile_b = nullptr;
   a.kseg = nullptr;
+  a.xcd_swizzle = 1;
   a.alignedA = aligned16(A) && (lda % 4 == 0) && (sA % 4 == 0) && (gA % 4 == 0);
   a.alignedB = aligned16(B) && (ldb % 4 == 0) && (sB % 4 == 0) && (gB % 4 == 0);
   // 128-row tiles only where they still leave >= 4 workgroups per CU (8192^3: 119 -> 125 TFLOP/s).  At the tail /
@@ -485,6 +499,7 @@ static void plain_args(GemmArgs &a, const float *A, const float *B, float *C, in
   a.rowscale = nullptr; a.nrs = 0;
   a.C2 = nullptr; a.ldc2 = 0; a.sC2 = 0;
   a.mtile_b = nullptr; a.kseg = nullptr;
+  a.xcd_swizzle = 0;
 }
 
 int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K,
