@@ -405,6 +405,16 @@ MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha,
  *   scores[b, col[crow[u] .. crow[u+1])] = -inf (in place; crow may be NULL = no mask), then the
  *   indices (and optionally values) of the k largest entries, score descending, ties by ascending
  *   index.  k <= 256.                                                                               */
+/* mi_rowsq_fwd/bwd: LightGCN.get_reg_loss (src/models/lightgcn.py:90-100) on plain tables:
+ *   out = (sum_b |U[ui[b]]|^2 + |P[pi[b]]|^2 + |Nn[ni[b]]|^2) / (2B), joined in index order;
+ *   bwd: dU[ui[b]] += g U[ui[b]] / B (and likewise dP, dN; float atomics, caller-zeroed, nullable).
+ *   workspace: mi_bpr_workspace_elems(B) floats.                                                      */
+MI_API int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, float *workspace,
+                        float *out, void *stream);
+MI_API int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, const float *g,
+                        float *dU, float *dP, float *dN, void *stream);
 MI_API int64_t mi_bpr_workspace_elems(int64_t B);
 MI_API int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                       const float *Nn, const int64_t *ni, int64_t B, int32_t D, float *sig,

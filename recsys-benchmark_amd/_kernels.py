@@ -401,7 +401,12 @@ class CsrPlan:
                 self._sym_vals_key = key
             if self._sym_vals:
                 return val
-        return val.index_select(0, self.perm)
+        # the adjacency values are constants between SparseDropout draws: permute them once per tensor version
+        key = (val.data_ptr(), val._version, val.numel())
+        if key != self.__dict__.get("_tv_key"):
+            self._tv = val.index_select(0, self.perm)
+            self._tv_key = key
+        return self._tv
 
 
 _plans = {}
@@ -477,19 +482,29 @@ class LightGCNPropagate(torch.autograd.Function):
         ctx.plan, ctx.num_layers = plan, num_layers
         ctx.split = Xac.shape[0] if Xbc is not None else None
         ctx.save_for_backward(valc)
-        return _propagate(plan, False, valc, Xac, Xbc, num_layers)
+        res = _propagate(plan, False, valc, Xac, Xbc, num_layers)
+        if ctx.split is None:
+            return res
+        # two tables in, two tables out (LightGCN splits the result anyway, src/models/lightgcn.py:87): the backward
+        # then receives the two gradients separately and reads them as two row segments — no cat, no split
+        return res[: ctx.split], res[ctx.split:]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         (valc,) = ctx.saved_tensors
         plan = ctx.plan
-        g = _f32c(g)
         val_t = plan.transposed_values(valc)
-        gX = _propagate(plan, True, val_t, g, None, ctx.num_layers)
-        if ctx.num_layers == 0:
-            gX = g / 1.0
         if ctx.split is None:
+            g = _f32c(gs[0])
+            gX = _propagate(plan, True, val_t, g, None, ctx.num_layers)
             return None, gX, None, None, None
+        ga, gb = gs
+        n_a, n_b = ctx.split, plan.shape[0] - ctx.split
+        D = (ga if ga is not None else gb).shape[1]
+        dev = valc.device
+        ga = _f32c(ga) if ga is not None else torch.zeros((n_a, D), dtype=torch.float32, device=dev)
+        gb = _f32c(gb) if gb is not None else torch.zeros((n_b, D), dtype=torch.float32, device=dev)
+        gX = _propagate(plan, True, val_t, ga, gb, ctx.num_layers)
         return None, gX[: ctx.split], gX[ctx.split:], None, None
 
 

@@ -94,6 +94,70 @@ __global__ __launch_bounds__(kBlock) void k_bpr_bwd(
   }
 }
 
+// ---- L2 regulariser over the batch rows: LightGCN.get_reg_loss (src/models/lightgcn.py:90-100) ----------------
+//   reg = ( ||U[ui]||_F^2 + ||P[pi]||_F^2 + ||Nn[ni]||_F^2 ) / (2 B)
+// (x.norm(2).pow(2) of the three gathered [B, D] blocks): gathers, squares and the deterministic mean-style join in
+// one launch; backward dU[ui[b]] += g * U[ui[b]] / B etc. (float atomics into caller-zeroed dense gradients).
+__global__ __launch_bounds__(kBlock) void k_rowsq_fwd(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, float *__restrict__ part, unsigned *ticket, float *__restrict__ out) {
+  __shared__ float red[kWavesPerBlock];
+  __shared__ bool last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc = 0.f;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const float *u = U + ui[b] * D, *p = P + pi[b] * D, *q = Nn + ni[b] * D;
+    for (int j = lane; j < D; j += kWave) acc += u[j] * u[j] + p[j] * p[j] + q[j] * q[j];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < kWavesPerBlock; ++j) s += red[j];
+    part[blockIdx.x] = s;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < gridDim.x; j += kBlock) s += ((volatile float *)part)[j];
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int j = 0; j < kWavesPerBlock; ++j) t += red[j];
+      out[0] = t / (2.f * (float)B);
+      *ticket = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rowsq_bwd(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, const float *__restrict__ g, float *__restrict__ dU, float *__restrict__ dP,
+    float *__restrict__ dN) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const float c = g[0] / (float)B;          // d/dw of w^2 / (2B) = w / B
+  for (int64_t b = wave0; b < B; b += nwaves) {
+    const int64_t ur = ui[b], pr = pi[b], nr = ni[b];
+    for (int j = lane; j < D; j += kWave) {
+      if (dU) atomicAdd(dU + ur * D + j, c * U[ur * D + j]);
+      if (dP) atomicAdd(dP + pr * D + j, c * P[pr * D + j]);
+      if (dN) atomicAdd(dN + nr * D + j, c * Nn[nr * D + j]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ mask + top-k per row ----
 constexpr int kCand = 2048;   // candidate slots in LDS
 constexpr int kSample = 4096; // row prefix that sets the candidate bound
@@ -273,6 +337,27 @@ int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t 
   if (!U || !P || !Nn || !sig || !g) return MI_ERR_INVALID_ARG;
   MI_LAUNCH("bpr_bwd", k_bpr_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, sig, g,
             dU, dP, dN);
+  return launch_status();
+}
+
+int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                 const int64_t *ni, int64_t B, int32_t D, float *workspace, float *out, void *stream) {
+  if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (!U || !P || !Nn || !ui || !pi || !ni || !workspace || !out) return MI_ERR_INVALID_ARG;
+  const int grid = grid_for_waves(B);
+  if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+    return MI_ERR_LAUNCH;
+  MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, workspace,
+            reinterpret_cast<unsigned *>(workspace + grid), out);
+  return launch_status();
+}
+
+int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                 const int64_t *ni, int64_t B, int32_t D, const float *g, float *dU, float *dP, float *dN,
+                 void *stream) {
+  if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (!U || !P || !Nn || !ui || !pi || !ni || !g) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("rowsq_bwd", k_rowsq_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, g, dU, dP, dN);
   return launch_status();
 }
 

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _kernels
-from .embeddings import IEmbedding, get_embedding
+from .embeddings import IEmbedding, VanillaEmbedding, get_embedding
 from .layers import SparseDropout
 
 
@@ -61,14 +61,20 @@ class LightGCN(IGraphBaseCore):
         """matrix: sparse (num_user+num_item)^2 normalised adjacency -> (user_emb, item_emb)."""
         matrix = self.sparse_dropout(matrix)
         # E^0 = [user table; item table] is read as two row segments: no torch.cat copy
-        res = _kernels.lightgcn_propagate(
+        return _kernels.lightgcn_propagate(
             matrix, self.user_emb_table.get_weight(), self.item_emb_table.get_weight(), self.num_layers)
-        return torch.split(res, (self._num_user, self._num_item))
 
     def get_reg_loss(self, users, pos_items, neg_items) -> torch.Tensor:
-        user_emb = self.user_emb_table(users)
-        pos_item_emb = self.item_emb_table(pos_items)
-        neg_item_emb = self.item_emb_table(neg_items)
+        ut, it = self.user_emb_table, self.item_emb_table
+        if (type(ut) is VanillaEmbedding and type(it) is VanillaEmbedding and ut._mode is None and it._mode is None
+                and not ut.sparse_grad and not it.sparse_grad and users.dim() == 1):
+            # plain tables: gathers, squares and the sum in one launch each way (~30 small launches otherwise)
+            from .losses import reg_loss_rows
+
+            return reg_loss_rows(ut.get_weight(), it.get_weight(), users, pos_items, neg_items)
+        user_emb = ut(users)
+        pos_item_emb = it(pos_items)
+        neg_item_emb = it(neg_items)
         reg_loss = (
             user_emb.norm(2).pow(2) + pos_item_emb.norm(2).pow(2) + neg_item_emb.norm(2).pow(2)
         ) / (2 * len(users))

@@ -94,3 +94,42 @@ def bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items):
     (src/trainer/lightgcn.py:395-399) without materialising the three gathered matrices; the gradients land in
     dense table gradients like index_select's backward."""
     return _BPRFn.apply(all_user_emb, all_item_emb, all_item_emb, users, pos_items, neg_items)
+
+
+class _RowSqFn(torch.autograd.Function):
+    """(|U[ui]|^2 + |P[pi]|^2 + |Nn[ni]|^2) / (2B) over plain tables — LightGCN.get_reg_loss, src/models/lightgcn.py:90-100."""
+
+    @staticmethod
+    def forward(ctx, U, P, Nn, ui, pi, ni):
+        dev = _lib.require_gpu(U, P, Nn, ui)
+        lib = _lib.load()
+        U, P, Nn = _kernels._f32c(U), _kernels._f32c(P), _kernels._f32c(Nn)
+        ui, pi, ni = (_kernels._i64c(t).view(-1) for t in (ui, pi, ni))
+        B, D = ui.numel(), U.shape[1]
+        if pi.numel() != B or ni.numel() != B or P.shape[1] != D or Nn.shape[1] != D or B == 0:
+            raise ValueError("reg loss: users / positives / negatives must be [B] indices into [*, D] tables")
+        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_rowsq_fwd(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(), ni.data_ptr(),
+                                    B, D, ws.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
+        ctx.save_for_backward(U, P, Nn, ui, pi, ni)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        U, P, Nn, ui, pi, ni = ctx.saved_tensors
+        g = _kernels._f32c(g).view(1)
+        same = P.data_ptr() == Nn.data_ptr() and P.shape == Nn.shape      # positives and negatives share the item table
+        dU = torch.zeros_like(U) if ctx.needs_input_grad[0] else None
+        dP = torch.zeros_like(P) if (ctx.needs_input_grad[1] or (same and ctx.needs_input_grad[2])) else None
+        dN = dP if same else (torch.zeros_like(Nn) if ctx.needs_input_grad[2] else None)
+        _lib.check(_lib.load().mi_rowsq_bwd(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(),
+                                            ni.data_ptr(), ui.numel(), U.shape[1], g.data_ptr(), _lib.ptr(dU),
+                                            _lib.ptr(dP), _lib.ptr(dN), _lib.stream_ptr(g.device)), "mi_rowsq_bwd")
+        # one buffer holds both item contributions when the tables coincide: hand it to the first, nothing to the second
+        return dU, dP, (None if same else dN), None, None, None
+
+
+def reg_loss_rows(user_table, item_table, users, pos_items, neg_items):
+    """LightGCN.get_reg_loss on plain [N, D] tables in one launch each way."""
+    return _RowSqFn.apply(user_table, item_table, item_table, users, pos_items, neg_items)

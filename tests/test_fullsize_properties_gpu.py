@@ -76,9 +76,11 @@ def test_c2_backward_forms_agree_and_sum_rule(c2):
     rows = gs._indices()[0]
     assert torch.equal(rows, (x + off).view(-1)), "COO indices are idx + offsets, bit-exact"
     touched = torch.unique(rows)
-    assert_close(gs.coalesce().to_dense()[touched], gd[touched], 1e-4, 1e-5, "rows form vs dense form")
+    # fields with 3-4 values put >1000 duplicate gradient rows of magnitude ~1 on one table row: two summation
+    # orders (coalesce vs float atomics) differ by ~sqrt(n) * eps * |partial sums| ~ 1e-4 on sums that cancel
+    assert_close(gs.coalesce().to_dense()[touched], gd[touched], 1e-4, 1e-3, "rows form vs dense form")
     assert not bool(gd.index_fill(0, touched, 0.0).any()), "dense form touches only looked-up rows"
-    assert_close(g1s.coalesce().to_dense()[touched], g1d[touched], 1e-4, 1e-5)
+    assert_close(g1s.coalesce().to_dense()[touched], g1d[touched], 1e-4, 1e-3)
     vals = gs._values().view(B, F, 16)
     S = emb.sum(1)
     assert_close((vals - g_emb).sum(1), g_y[:, None] * (F - 1) * S, 1e-3, 1e-4, "sum rule")
@@ -105,7 +107,7 @@ def test_c5_fixed_point_of_the_normalised_adjacency(yelp):
     mean propagation of v = D^1/2 1 (broadcast over D columns) returns v."""
     A, deg, U, I = yelp
     v = deg.sqrt()[:, None].expand(-1, 64).contiguous()
-    out = _kernels.lightgcn_propagate(A, v[:U].contiguous(), v[U:].contiguous(), 3)
+    out = torch.cat(_kernels.lightgcn_propagate(A, v[:U].contiguous(), v[U:].contiguous(), 3))
     keep = deg > 0
     assert_close(out[keep], v[keep], 2e-5, 1e-4, "fixed point")
     iso = ~keep                                   # isolated nodes: A_hat row empty -> (v + 0 + 0 + 0) / 4

@@ -112,3 +112,33 @@ def test_topk_kernel_is_exact_on_given_scores_incl_ties_and_many_masked():
     for r in (3, 4, 5):                                                     # the stated total order
         order = sorted(range(I), key=lambda j: (-float(s[r, j]), j))[:k]
         assert out[r].tolist() == order
+
+
+def test_reg_loss_rows_matches_reference_formula_and_model_uses_it():
+    """LightGCN.get_reg_loss (src/models/lightgcn.py:90-100) on plain tables: fused kernel vs the oracle's formula,
+    value and both table gradients (rows repeat; positives and negatives share the item table)."""
+    from recsys_benchmark_amd.lightgcn import LightGCN
+    from recsys_benchmark_amd.losses import reg_loss_rows
+
+    g = torch.Generator().manual_seed(11)
+    nu, ni, D, B = 300, 500, 64, 2048
+    U = torch.randn(nu, D, generator=g, requires_grad=True)
+    I = torch.randn(ni, D, generator=g, requires_grad=True)
+    users = torch.randint(0, nu, (B,), generator=g)
+    pos, neg = torch.randint(0, ni, (B,), generator=g), torch.randint(0, ni, (B,), generator=g)
+    ref = ro.l2_reg_loss(U[users], I[pos], I[neg])
+    (ref * 3.0).backward()
+    hU, hI = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    out = reg_loss_rows(hU, hI, users.to(DEV), pos.to(DEV), neg.to(DEV))
+    (out * 3.0).backward()
+    assert_close(out, ref, 1e-5, 1e-5, "reg loss")              # a sum of 393 216 squares in a different order
+    assert_close(hU.grad, U.grad, 1e-4, 1e-7, "dU")
+    assert_close(hI.grad, I.grad, 1e-4, 1e-7, "dI (positives + negatives)")
+    model = LightGCN(nu, ni, num_layers=1, hidden_size=D).to(DEV)
+    with torch.no_grad():
+        model.user_emb_table._emb_module.weight.copy_(U)
+        model.item_emb_table._emb_module.weight.copy_(I)
+    got = model.get_reg_loss(users.to(DEV), pos.to(DEV), neg.to(DEV))
+    assert_close(got, ref, 1e-5, 1e-5, "LightGCN.get_reg_loss")
+    got.backward()
+    assert_close(model.user_emb_table._emb_module.weight.grad * 3.0, U.grad, 1e-4, 1e-7)

@@ -54,7 +54,7 @@ def main():
     G = torch.randn(N, D, device=dev)
 
     def fwd():
-        return _kernels.lightgcn_propagate(adj, Eu, Ei, L)
+        return torch.cat(_kernels.lightgcn_propagate(adj, Eu, Ei, L))
 
     ks, wall = timed(fwd)
     per_layer = 8 * nnz + 4 * (N + 1) + 2 * 4 * N * D + 8 * N * D      # compulsory + fused running sum
