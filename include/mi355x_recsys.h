@@ -359,7 +359,9 @@ MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate
  * mean_offset (nullable, training BN): added to the batch mean in the running_mean update only.  A Linear's
  * bias cancels inside a training-mode BatchNorm (it shifts z and its batch mean alike), so the caller may run the
  * contraction WITHOUT the bias, pass the bias here, and get the same y, gradients and running statistics.
- * Backward: dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
+ * Backward: dY NULL means a rank-1 upstream gradient dY[m,n] = gvec[m]*wvec[n] — the backward of a following
+ * 1-output Linear (the tail's last layer), computed on the fly instead of being written and read back twice.
+ * dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
  * dZ = gamma*rstd*(dyh - dbeta/M - zh*dgamma/M) in training.
  */
 MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N,
@@ -374,7 +376,7 @@ MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, 
                                   const uint8_t *keep, float p, const float *gamma,
                                   const float *beta, const float *save_mean,
                                   const float *save_rstd, float *dgamma_dbeta, float *dZ,
-                                  void *stream);
+                                  const float *gvec, const float *wvec, void *stream);
 
 /* ---- §8f rank 1: fused row-sparse optimizer steps on row-form gradients -------------------
  * Reference: get_optimizers' sparse branch (src/models/deepfm.py:163-184): torch.optim.SparseAdam

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_relu_drop_fwd(BnArgs a) {
 }
 
 struct BnBwdArgs {
-  const float *dY, *Z;
+  const float *dY, *Z;           // dY NULL: the upstream gradient is rank-1, dY[m,n] = gvec[m] * wvec[n]
+  const float *gvec, *wvec;      // (the backward of a following 1-output Linear, never materialised)
   int ld;
   int M, N;
   int has_bn, training;
@@ -263,7 +264,7 @@ __device__ __forceinline__ float bwd_dyh(const BnBwdArgs &a, int64_t e, int n, f
   }
   zh = (z - mean) * rstd;
   const float pre = g * zh + b;
-  float d = a.dY[e];
+  float d = a.dY ? a.dY[e] : a.gvec[e / a.N] * a.wvec[n];
   if (a.keep) d = a.keep[e] ? d * (1.f / (1.f - a.p)) : 0.f;
   return pre > 0.f ? d : 0.f;
 }
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
       if (a.beta) { const float4 t = ld4(a.beta + n0); bt[0] = t.x; bt[1] = t.y; bt[2] = t.z; bt[3] = t.w; }
     }
     const float ks = a.keep ? 1.f / (1.f - a.p) : 1.f;
+    const float4 w4 = a.dY ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.wvec + n0);
     const int stride = gridDim.y * 4;
     float accb[4] = {0.f, 0.f, 0.f, 0.f}, accg[4] = {0.f, 0.f, 0.f, 0.f};
     for (int m = blockIdx.y * 4 + w; m < a.M; m += 2 * stride) {
@@ -295,7 +297,12 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
         ok[u] = mm < a.M;
         const int mr = ok[u] ? mm : m;
         z[u] = ld4(a.Z + (int64_t)mr * a.ld + n0);
-        dy[u] = ld4(a.dY + (int64_t)mr * a.N + n0);
+        if (a.dY) {
+          dy[u] = ld4(a.dY + (int64_t)mr * a.N + n0);
+        } else {
+          const float gm = a.gvec[mr];
+          dy[u] = make_float4(gm * w4.x, gm * w4.y, gm * w4.z, gm * w4.w);
+        }
         k4[u] = a.keep ? *reinterpret_cast<const uchar4 *>(a.keep + (int64_t)mr * a.N + n0) : make_uchar4(1, 1, 1, 1);
       }
 #pragma unroll
@@ -377,7 +384,15 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(BnBwdArgs a) {
     const int m = (int)(ev / nv), n0 = (int)(ev % nv) * VEC;
     const int64_t e0 = (int64_t)m * a.N + n0;
     const Vec<VEC> z = ldv<VEC>(a.Z + (int64_t)m * a.ld + n0);
-    const Vec<VEC> dy = ldv<VEC>(a.dY + e0);
+    Vec<VEC> dy;
+    if (a.dY) {
+      dy = ldv<VEC>(a.dY + e0);
+    } else {
+      const float gm = a.gvec[m];
+      const Vec<VEC> wv = ldv<VEC>(a.wvec + n0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dy.v[j] = gm * wv.v[j];
+    }
     uint8_t kv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) kv[j] = 1;
@@ -487,24 +502,24 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
 int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M, int32_t N, int32_t has_bn,
                            int32_t training, const uint8_t *keep, float p, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_rstd, float *dgamma_dbeta /*[2,N] zeroed*/,
-                           float *dZ, void *stream) {
+                           float *dZ, const float *gvec, const float *wvec, void *stream) {
   if (M < 0 || N < 0 || p < 0.f || p >= 1.f) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
-  if (!dY || !Z || !dZ) return MI_ERR_INVALID_ARG;
+  if (!Z || !dZ || (!dY && (!gvec || !wvec))) return MI_ERR_INVALID_ARG;
   if (has_bn && (!save_mean || !save_rstd || !dgamma_dbeta)) return MI_ERR_INVALID_ARG;
   BnBwdArgs a;
-  a.dY = dY; a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = has_bn; a.training = training;
+  a.dY = dY; a.gvec = dY ? nullptr : gvec; a.wvec = dY ? nullptr : wvec; a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = has_bn; a.training = training;
   a.keep = keep; a.p = p; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_rstd = save_rstd;
   a.dgamma = dgamma_dbeta; a.dbeta = dgamma_dbeta ? dgamma_dbeta + N : nullptr;
   a.dZ = dZ;
   if (has_bn) {
-    const bool v4r = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dY) && (!keep || ((uintptr_t)keep & 3) == 0) &&
+    const bool v4r = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && (dY ? aligned16(dY) : aligned16(wvec)) && (!keep || ((uintptr_t)keep & 3) == 0) &&
                      aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta) && (!gamma || aligned16(gamma)) &&
                      (!beta || aligned16(beta));
     if (v4r) MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce_v4, col_grid_v4(M, N), kBlock, stream, a);
     else MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce, col_grid(M, N), kBlock, stream, a);
   }
-  const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dZ) && aligned16(dY) &&
+  const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dZ) && (dY ? aligned16(dY) : aligned16(wvec)) &&
                   (!keep || ((uintptr_t)keep & 3) == 0) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
                   (!has_bn || (aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta)));
   if (v4) MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply<4>, grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);

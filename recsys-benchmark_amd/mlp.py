@@ -149,7 +149,10 @@ class _Linear1Fn(torch.autograd.Function):
 class _BNReLUDropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, nbt, has_bn, training, momentum, eps, p, seed, salt,
-                bump_seed, stats, dgb, mean_offset=None):
+                bump_seed, stats, dgb, mean_offset=None, lin1_W=None, lin1_b=None, lin1_add=None, lin1_red=None):
+        """lin1_* (optional): the tail's final 1-output Linear (weight [1, N], bias, row-wise addend, N+1 zeroed floats)
+        rides in the same autograd node: the node returns that layer's [M, 1] output, and its backward feeds the
+        rank-1 gradient g[m] * W[n] to the BatchNorm backward kernels directly instead of writing it out."""
         dev = _lib.require_gpu(z)
         z = _kernels._f32c(z)
         M, N = z.shape
@@ -170,29 +173,62 @@ class _BNReLUDropFn(torch.autograd.Function):
                 save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None, _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_fwd",
         )
-        ctx.save_for_backward(z, gamma, beta, keep, save, dgb)
         ctx.meta = (M, N, bool(has_bn), bool(training), float(p if drop else 0.0))
-        return y
+        ctx.lin1 = lin1_W is not None
+        if not ctx.lin1:
+            ctx.save_for_backward(z, gamma, beta, keep, save, dgb)
+            return y
+        out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+        add = None if lin1_add is None else _kernels._f32c(lin1_add)
+        _lib.check(_lib.load().mi_rowdot(y.data_ptr(), N, lin1_W.data_ptr(), _lib.ptr(lin1_b), _lib.ptr(add),
+                                         out.data_ptr(), M, N, _lib.stream_ptr(dev)), "mi_rowdot")
+        ctx.save_for_backward(z, gamma, beta, keep, save, dgb, y, lin1_W, lin1_red)
+        ctx.lin1_meta = (lin1_b is not None, None if lin1_add is None else tuple(lin1_add.shape))
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        z, gamma, beta, keep, save, dgb = ctx.saved_tensors
         M, N, has_bn, training, p = ctx.meta
-        dev = z.device
-        dy = _kernels._f32c(dy)
+        lib = _lib.load()
+        dW1 = db1 = dadd = gvec = W1 = None
+        if ctx.lin1:
+            z, gamma, beta, keep, save, dgb, y, W1, red = ctx.saved_tensors
+            dev = z.device
+            s = _lib.stream_ptr(dev)
+            has_b1, add_shape = ctx.lin1_meta
+            gvec = _kernels._f32c(dy).view(M)
+            if red is None:
+                red = torch.zeros((N + 1,), dtype=torch.float32, device=dev)
+            want_db1 = has_b1 and ctx.needs_input_grad[18]
+            if ctx.needs_input_grad[17]:
+                _lib.check(lib.mi_colsum(y.data_ptr(), N, gvec.data_ptr(), 1, red.data_ptr(),
+                                         red[N:].data_ptr() if want_db1 else None, M, N, s), "mi_colsum")
+                dW1 = red[:N].view(1, N)
+            elif want_db1:
+                _lib.check(lib.mi_colsum(gvec.data_ptr(), 1, None, 0, red[N:].data_ptr(), None, M, 1, s), "mi_colsum")
+            if want_db1:
+                db1 = red[N:]
+            if add_shape is not None and ctx.needs_input_grad[19]:
+                dadd = gvec.view(add_shape)
+            dy_ptr = None
+        else:
+            z, gamma, beta, keep, save, dgb = ctx.saved_tensors
+            dev = z.device
+            dy = _kernels._f32c(dy)
+            dy_ptr = dy.data_ptr()
         dz = torch.empty_like(z)
         if has_bn and dgb is None:
             dgb = torch.zeros((2 * N,), dtype=torch.float32, device=dev)
         _lib.check(
-            _lib.load().mi_bn_relu_dropout_bwd(
-                dy.data_ptr(), z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(keep), p, _lib.ptr(gamma),
+            lib.mi_bn_relu_dropout_bwd(
+                dy_ptr, z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(keep), p, _lib.ptr(gamma),
                 _lib.ptr(beta), save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None,
-                _lib.ptr(dgb), dz.data_ptr(), _lib.stream_ptr(dev)),
+                _lib.ptr(dgb), dz.data_ptr(), _lib.ptr(gvec), _lib.ptr(W1), _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_bwd",
         )
         dgamma = dgb[:N] if (has_bn and gamma is not None and ctx.needs_input_grad[1]) else None
         dbeta = dgb[N:2 * N] if (has_bn and beta is not None and ctx.needs_input_grad[2]) else None
-        return (dz, dgamma, dbeta) + (None,) * 14
+        return (dz, dgamma, dbeta) + (None,) * 14 + (dW1, db1, dadd, None)
 
 
 def _groups(seq: nn.Sequential) -> List[List]:
@@ -247,7 +283,11 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         return t
 
     need_bump = True
+    skip_next = False
     for k, grp in enumerate(groups):
+        if skip_next:                       # the final 1-output Linear already ran inside the previous group's node
+            skip_next = False
+            continue
         if grp[0] == "plain":
             m = grp[1]
             if isinstance(m, nn.Linear) and m.out_features == 1 and x.dim() == 2:
@@ -275,13 +315,26 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
             else:
                 seed.add_(1)               # no statistics launch to ride on
             need_bump = False
-        x = _BNReLUDropFn.apply(
+        # the tail's final Linear(., 1) directly behind this group: same autograd node (its rank-1 input gradient is
+        # consumed by the BatchNorm backward kernels without ever being written out)
+        lin1 = None
+        if k + 2 == len(groups) and groups[k + 1][0] == "plain" and torch.is_grad_enabled():
+            nxt = groups[k + 1][1]
+            if isinstance(nxt, nn.Linear) and nxt.out_features == 1 and nxt.in_features == N and z.dim() == 2:
+                lin1 = nxt
+        fn_args = (
             z, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
             bn.running_mean if bn is not None else None, bn.running_var if bn is not None else None,
             bn.num_batches_tracked if bn is not None else None,
             bn is not None, bool(p > 0.0) if bn is None else bool(bn.training),
             bn.momentum if bn is not None else 0.0, bn.eps if bn is not None else 0.0, p, seed, 7919 * (k + 1),
             bump_in_kernel, stats, dgb, lin.bias if skip_bias else None)
+        if lin1 is not None:
+            x = _BNReLUDropFn.apply(*fn_args, lin1.weight, lin1.bias, last_add, take(N + 1))
+            last_add = None
+            skip_next = True
+        else:
+            x = _BNReLUDropFn.apply(*fn_args)
     if last_add is not None:
         x = x + last_add.view(-1, *([1] * (x.dim() - 1)))
     return x
