@@ -269,6 +269,8 @@ __device__ __forceinline__ float bwd_dyh(const BnBwdArgs &a, int64_t e, int n, f
   return pre > 0.f ? d : 0.f;
 }
 
+// RANK1: the upstream gradient is gvec[m] * wvec[n] (compile-time, so that no branch sits between the loads)
+template <bool RANK1>
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
   __shared__ float4 p1[4][64], p2[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -284,7 +286,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
       if (a.beta) { const float4 t = ld4(a.beta + n0); bt[0] = t.x; bt[1] = t.y; bt[2] = t.z; bt[3] = t.w; }
     }
     const float ks = a.keep ? 1.f / (1.f - a.p) : 1.f;
-    const float4 w4 = a.dY ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.wvec + n0);
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RANK1) w4 = ld4(a.wvec + n0);
     const int stride = gridDim.y * 4;
     float accb[4] = {0.f, 0.f, 0.f, 0.f}, accg[4] = {0.f, 0.f, 0.f, 0.f};
     for (int m = blockIdx.y * 4 + w; m < a.M; m += 2 * stride) {
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce_v4(BnBwdArgs a) {
         ok[u] = mm < a.M;
         const int mr = ok[u] ? mm : m;
         z[u] = ld4(a.Z + (int64_t)mr * a.ld + n0);
-        if (a.dY) {
+        if constexpr (!RANK1) {
           dy[u] = ld4(a.dY + (int64_t)mr * a.N + n0);
         } else {
           const float gm = a.gvec[mr];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_reduce(BnBwdArgs a) {
   }
 }
 
-template <int VEC>
+template <int VEC, bool RANK1>
 __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(BnBwdArgs a) {
   const int nv = a.N / VEC;
   const int64_t total = (int64_t)a.M * nv;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(BnBwdArgs a) {
     const int64_t e0 = (int64_t)m * a.N + n0;
     const Vec<VEC> z = ldv<VEC>(a.Z + (int64_t)m * a.ld + n0);
     Vec<VEC> dy;
-    if (a.dY) {
+    if constexpr (!RANK1) {
       dy = ldv<VEC>(a.dY + e0);
     } else {
       const float gm = a.gvec[m];
@@ -516,14 +519,17 @@ int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t
     const bool v4r = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && (dY ? aligned16(dY) : aligned16(wvec)) && (!keep || ((uintptr_t)keep & 3) == 0) &&
                      aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta) && (!gamma || aligned16(gamma)) &&
                      (!beta || aligned16(beta));
-    if (v4r) MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce_v4, col_grid_v4(M, N), kBlock, stream, a);
+    if (v4r && dY) MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce_v4<false>, col_grid_v4(M, N), kBlock, stream, a);
+    else if (v4r) MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce_v4<true>, col_grid_v4(M, N), kBlock, stream, a);
     else MI_LAUNCH("bn_bwd_reduce", k_bn_bwd_reduce, col_grid(M, N), kBlock, stream, a);
   }
   const bool v4 = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && aligned16(dZ) && (dY ? aligned16(dY) : aligned16(wvec)) &&
                   (!keep || ((uintptr_t)keep & 3) == 0) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
                   (!has_bn || (aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta)));
-  if (v4) MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply<4>, grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);
-  else MI_LAUNCH("bn_relu_dropout_bwd", k_bn_bwd_apply<1>, grid_for_elems((int64_t)M * N), kBlock, stream, a);
+  if (v4 && dY) MI_LAUNCH("bn_relu_dropout_bwd", (k_bn_bwd_apply<4, false>), grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);
+  else if (v4) MI_LAUNCH("bn_relu_dropout_bwd", (k_bn_bwd_apply<4, true>), grid_for_elems((int64_t)M * N / 4), kBlock, stream, a);
+  else if (dY) MI_LAUNCH("bn_relu_dropout_bwd", (k_bn_bwd_apply<1, false>), grid_for_elems((int64_t)M * N), kBlock, stream, a);
+  else MI_LAUNCH("bn_relu_dropout_bwd", (k_bn_bwd_apply<1, true>), grid_for_elems((int64_t)M * N), kBlock, stream, a);
   return launch_status();
 }
 
