@@ -64,6 +64,14 @@ constexpr int KQ = BK / 4;               // float4 per tile row (k contiguous)
 
 // Stage a [64 rows][32 k] tile of an operand into LDS (row = output index, k contiguous).
 // trans == 0: global is [row][k] (k contiguous);  trans == 1: global is [k][row].
+// LDS tiles are [row][k] with rows of LDSS = 36 floats and the eight 4-float chunks of a row XOR-swizzled by
+// (row >> 3) & 7.  The pad makes the fragment reads (8 consecutive rows, same chunk) conflict-free; the swizzle is
+// constant inside every aligned group of 8 rows, so it keeps that property, and it spreads the SCALAR stores of a
+// transposed operand (a thread owns 4 consecutive rows at one k) over all 32 banks: without it they fall on 8 banks
+// (8-way conflicts; SQ_LDS_BANK_CONFLICT was 78 % of the LDS cycles of a weight-gradient GEMM), with it 2-way — the
+// minimum for 64 lanes.
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 3) & 7)) << 2; }
+
 template <int ROWS>
 struct Staged {
   float4 v[ROWS * BK / 4 / 256];   // float4 loads per thread for a [ROWS][BK] operand tile
@@ -175,14 +183,16 @@ __device__ __forceinline__ void stage_store(float (*T)[LDSS], const Staged<ROWS>
   for (int i = 0; i < NLD; ++i) {
     const int f = t + i * 256;
     if constexpr (!TRANS) {
-      const int row = f / KQ, kq = (f % KQ) * 4;
-      *reinterpret_cast<float4 *>(&T[row][kq]) = s.v[i];
+      const int row = f / KQ;
+      *reinterpret_cast<float4 *>(&T[row][swz(row, f % KQ)]) = s.v[i];
     } else {
       const int kk = f / RQ, mq = (f % RQ) * 4;
-      T[mq + 0][kk] = s.v[i].x;
-      T[mq + 1][kk] = s.v[i].y;
-      T[mq + 2][kk] = s.v[i].z;
-      T[mq + 3][kk] = s.v[i].w;
+      // (mq .. mq+3 share row >> 3: one swizzled column for the four rows)
+      const int col = swz(mq, kk >> 2) + (kk & 3);
+      T[mq + 0][col] = s.v[i].x;
+      T[mq + 1][col] = s.v[i].y;
+      T[mq + 2][col] = s.v[i].z;
+      T[mq + 3][col] = s.v[i].w;
     }
   }
 }
@@ -192,10 +202,10 @@ template <int RB>
 __device__ __forceinline__ void mma_tile(floatx16 (&acc)[RB], float (*As)[LDSS], float (*Bs)[LDSS], int ar, int br, int kh) {
 #pragma unroll
   for (int c = 0; c < BK / 8; ++c) {
-    const float4 bv = *reinterpret_cast<const float4 *>(&Bs[br][c * 8 + kh * 4]);
+    const float4 bv = *reinterpret_cast<const float4 *>(&Bs[br][swz(br, c * 2 + kh)]);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const float4 av = *reinterpret_cast<const float4 *>(&As[ar + rb * 32][c * 8 + kh * 4]);
+      const float4 av = *reinterpret_cast<const float4 *>(&As[ar + rb * 32][swz(ar + rb * 32, c * 2 + kh)]);
       acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[rb], 0, 0, 0);
       acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[rb], 0, 0, 0);
       acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[rb], 0, 0, 0);
