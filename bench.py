@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--ring", type=int, default=16, help="distinct pre-generated id batches rotated through, one per step")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded model even on 1 GPU (exercises the N>1 path)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--c4", action="store_true", help="BASELINE config 4: the same 26 fields with the largest one scaled so that "
+                    "the table has 1e9 rows (64 GB fp32); row-sharded model (implies --sharded)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.sharded
+    sharded = world > 1 or args.sharded or args.c4
     if sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
@@ -143,7 +145,10 @@ def main():
     # (searched once, during the warm-up steps)
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
 
-    dims, D, hidden, p_drop = CRITEO_KAGGLE_26, 16, [400, 400, 400], 0.5
+    dims, D, hidden, p_drop = list(CRITEO_KAGGLE_26), 16, [400, 400, 400], 0.5
+    if args.c4:
+        big = max(range(len(dims)), key=lambda i: dims[i])
+        dims[big] += 1_000_000_000 - sum(dims)
     F, B = len(dims), args.batch
     torch.manual_seed(2023)
     sparse = not args.dense_grads
@@ -305,7 +310,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "launch": "hipGraph replay" if use_graph else ("eager RCCL collectives + one hipGraph for the local compute"
                                                            if (sharded and graphed_local) else "eager"),
-            "config": {"workload": f"C2 DeepFM Criteo-26field full embedding: F={F}, D={D}, N={sum(dims)} rows, "
+            "config": {"workload": f"{'C4' if args.c4 else 'C2'} DeepFM Criteo-26field full embedding: F={F}, D={D}, N={sum(dims)} rows, "
                                    f"MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(ring)} distinct uniform-id batches "
                                    f"rotated (fresh ids every step), "
                                    f"{'row-form (COO)' if sparse else 'dense'} table grads",

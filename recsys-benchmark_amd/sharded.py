@@ -139,8 +139,9 @@ class ShardedDeepFM(nn.Module):
         self.num_local_rows = local_num_rows(N, self.rank, self.world)
         # xavier-uniform over the GLOBAL [N, D] matrix (src/models/embeddings/base.py:66-67); sink row zero
         bound = (6.0 / (N + num_factor)) ** 0.5
-        W = (torch.rand(self.num_local_rows + 1, num_factor, device=device) * 2 - 1) * bound
-        w1 = torch.randn(self.num_local_rows + 1, 1, device=device)                # N(0,1) like nn.EmbeddingBag
+        # (in place: a 1e9-row table is 64 GB, temporaries of that size must not pile up)
+        W = torch.empty(self.num_local_rows + 1, num_factor, device=device).uniform_(-bound, bound)
+        w1 = torch.empty(self.num_local_rows + 1, 1, device=device).normal_()      # N(0,1) like nn.EmbeddingBag
         W[-1].zero_()
         w1[-1].zero_()
         self.embedding_shard = nn.Parameter(W)
