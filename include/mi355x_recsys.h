@@ -378,6 +378,25 @@ MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, 
                                   const float *save_rstd, float *dgamma_dbeta, float *dZ,
                                   const float *gvec, const float *wvec, void *stream);
 
+/* ---- §8f rank 3: the contrastive loss of the LightGCN step ------------------------------------
+ * Reference: info_nce (src/losses.py:25-47) as called by the trainer (src/trainer/lightgcn.py:215-229).
+ * mi_rownorm_fwd: Y[r,:] = X[r,:] * inv[r], inv[r] = 1/max(|X[r,:]|_2, eps)  (F.normalize(dim=1), eps 1e-12).
+ * mi_rownorm_bwd: dX = inv * (dY - Y <Y,dY>)  (dX = inv * dY for a row clamped at eps).
+ * mi_lse_diag_fwd: S fp32 [n,n] (row stride ld) raw scores; lse[i] = logsumexp_j(S[i,j]*inv_t);
+ *   loss[0] = mean_i (lse[i] - S[i,i]*inv_t).  workspace: mi_lse_diag_workspace_elems(n) floats.
+ * mi_lse_diag_bwd: S[i,j] <- g[0]/n * inv_t * (exp(S[i,j]*inv_t - lse[i]) - [i==j])  (in place: the gradient
+ *   with respect to the raw scores; the two GEMMs that follow are mi_gemm_f32 calls).
+ */
+MI_API int mi_rownorm_fwd(const float *X, int64_t n, int32_t D, float eps, float *Y, float *inv,
+                          void *stream);
+MI_API int mi_rownorm_bwd(const float *Y, const float *inv, const float *dY, int64_t n, int32_t D,
+                          float eps, float *dX, void *stream);
+MI_API int64_t mi_lse_diag_workspace_elems(int32_t n);
+MI_API int mi_lse_diag_fwd(const float *S, int64_t ld, int32_t n, float inv_t, float *lse,
+                           float *workspace, float *loss, void *stream);
+MI_API int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const float *lse,
+                           const float *g, void *stream);
+
 /* ---- §8f rank 1: fused row-sparse optimizer steps on row-form gradients -------------------
  * Reference: get_optimizers' sparse branch (src/models/deepfm.py:163-184): torch.optim.SparseAdam
  * on the embedding (no weight decay) / SGD with weight_decay=0 on it.
@@ -385,13 +404,15 @@ MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, 
  *   vals fp32[n,D]); duplicates are summed (== grad.coalesce()), then for each touched row
  *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); W -= step_size * m/(sqrt(v)+eps),
  *   step_size = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host (torch/optim/sparse_adam.py).
+ *   acc fp32[n,D] is workspace that must be all zero on entry and is all zero again on exit
+ *   (rows repeated more often than one wave pass covers are summed there with float atomics).
  * mi_scatter_axpy_rows: W[idx[i],:] += alpha*g[i,:] (row-sparse SGD, alpha = -lr; float atomics).
  */
 MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm,
                                  const float *vals, float *W, float *exp_avg,
-                                 float *exp_avg_sq, int64_t n, int32_t D, int64_t N,
-                                 float step_size, float beta1, float beta2, float eps,
-                                 void *stream);
+                                 float *exp_avg_sq, float *acc, int64_t n, int32_t D,
+                                 int64_t N, float step_size, float beta1, float beta2,
+                                 float eps, void *stream);
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 

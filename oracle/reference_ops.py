@@ -227,6 +227,24 @@ def bpr_loss(user_embs, pos_embs, neg_embs) -> torch.Tensor:
     return -F.logsigmoid(y_pos - y_neg).mean()
 
 
+def info_nce(view1: torch.Tensor, view2: torch.Tensor, temperature: float = 1, b_cos: bool = True) -> torch.Tensor:
+    """src/losses.py:25-47: -mean_i log softmax_j(<v1_i, v2_j> / T)[i, i]; with b_cos the rows are first scaled to unit
+    length the way F.normalize does it (x / max(|x|_2, 1e-12))."""
+    if b_cos:
+        # vector_norm, not sqrt(sum(x^2)): its backward is 0 (not NaN) at an all-zero row, as in F.normalize
+        view1 = view1 / torch.linalg.vector_norm(view1, 2, 1, keepdim=True).clamp_min(1e-12)
+        view2 = view2 / torch.linalg.vector_norm(view2, 2, 1, keepdim=True).clamp_min(1e-12)
+    scores = view1 @ view2.T / temperature
+    return (torch.logsumexp(scores, 1) - scores.diagonal()).mean()
+
+
+def bpr_loss_multi(user_embs, pos_embs, neg_embs) -> torch.Tensor:
+    """src/losses.py:50-68: K negatives per positive; summed over the negatives, averaged over the N samples."""
+    y_pos = (user_embs * pos_embs).sum(1, keepdim=True)                 # [N, 1]
+    y_neg = (user_embs.unsqueeze(1) * neg_embs).sum(2)                  # [N, K]
+    return F.softplus(y_neg - y_pos).sum() / user_embs.shape[0]
+
+
 def l2_reg_loss(user_rows, pos_rows, neg_rows) -> torch.Tensor:
     """LightGCN.get_reg_loss — src/models/lightgcn.py:90-100."""
     return (user_rows.norm(2).pow(2) + pos_rows.norm(2).pow(2) + neg_rows.norm(2).pow(2)) / (2 * len(user_rows))

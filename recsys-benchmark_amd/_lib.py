@@ -54,8 +54,8 @@ SIGNATURES = {
                                ctypes.c_float, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p],
     "mi_bn_relu_dropout_bwd": [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p, _p,
                                _p],
-    "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                              ctypes.c_float, _p],
+    "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, ctypes.c_float,
+                              ctypes.c_float, ctypes.c_float, _p],
     "mi_scatter_axpy_rows": [_p, _p, ctypes.c_float, _p, _i64, _i32, _i64, _p],
     "mi_tt_digits": [_p, _i64, _i64, _p, _i32, _p, _p, _p, _p],
     "mi_move_chunks": [_p, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _i32, _p],
@@ -71,6 +71,11 @@ SIGNATURES = {
     "mi_bpr_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p],
     "mi_bpr_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p],
     "mi_mask_topk_rows": [_p, _i64, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p],
+    "mi_rownorm_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p],
+    "mi_rownorm_bwd": [_p, _p, _p, _i64, _i32, ctypes.c_float, _p, _p],
+    "mi_lse_diag_workspace_elems": [_i32],
+    "mi_lse_diag_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p, _p],
+    "mi_lse_diag_bwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p],
     "mi_qat_gather_fwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _i64, _i32, _i64, _p, _p],
     "mi_qat_gather_bwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_optembed_fwd": [_p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i64, _p, _p],
@@ -85,7 +90,7 @@ SIGNATURES = {
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
 _RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
-             "mi_bpr_workspace_elems": ctypes.c_int64}
+             "mi_bpr_workspace_elems": ctypes.c_int64, "mi_lse_diag_workspace_elems": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()

@@ -31,7 +31,7 @@ inline int grid_for_waves(int64_t n_wave_items) {
   return (int)g;
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -60,6 +60,19 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// "last workgroup sums the partials" without agent-scope fences (on gfx950 a __threadfence() is an L2 write-back +
+// invalidate per workgroup: the loss kernels took 13 us with it): the partial travels as a device-scope (sc1) atomic
+// store, a workgroup-scope release drains it (s_waitcnt) before the ticket is taken, and the last workgroup reads the
+// partials with sc1 atomic loads — everything meets at the coherence point behind the per-XCD L2s.
+__device__ __forceinline__ void publish_partial(float *part, unsigned *ticket, float s, bool &last) {
+  __hip_atomic_store(part + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+}
+__device__ __forceinline__ float read_partial(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 }  // namespace mi
 

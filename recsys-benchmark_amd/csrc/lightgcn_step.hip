@@ -15,19 +15,6 @@
 namespace {
 using namespace mi;
 
-// "last workgroup sums the partials" without agent-scope fences (on gfx950 a __threadfence() is an L2 write-back +
-// invalidate per workgroup: the loss kernels took 13 us with it): the partial travels as a device-scope (sc1) atomic
-// store, a workgroup-scope release drains it (s_waitcnt) before the ticket is taken, and the last workgroup reads the
-// partials with sc1 atomic loads — everything meets at the coherence point behind the per-XCD L2s.
-__device__ __forceinline__ void publish_partial(float *part, unsigned *ticket, float s, bool &last) {
-  __hip_atomic_store(part + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-}
-__device__ __forceinline__ float read_partial(const float *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __device__ __forceinline__ float softplus(float x) {   // log(1 + e^x), stable
   return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }

@@ -133,3 +133,88 @@ class _RowSqFn(torch.autograd.Function):
 def reg_loss_rows(user_table, item_table, users, pos_items, neg_items):
     """LightGCN.get_reg_loss on plain [N, D] tables in one launch each way."""
     return _RowSqFn.apply(user_table, item_table, item_table, users, pos_items, neg_items)
+
+
+def bpr_loss_multi(user_embs, pos_embs, neg_embs):
+    """src/losses.py:50-68 — K negatives per positive ([N, K, D]): the BPR kernel over the N*K (user, positive, negative)
+    triples, summed over the negatives and averaged over the N samples."""
+    if neg_embs.dim() != 3 or neg_embs.shape[0] != user_embs.shape[0]:
+        raise ValueError("bpr_loss_multi: negatives must be [N, K, D]")
+    n, k = neg_embs.shape[:2]
+    rep = torch.arange(n, device=user_embs.device).repeat_interleave(k)
+    return _BPRFn.apply(user_embs, pos_embs, neg_embs.reshape(n * k, -1), rep, rep, None) * k
+
+
+_NORMALIZE_EPS = 1e-12      # F.normalize's default
+
+
+def _unit_rows(x):
+    y, inv = torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi_rownorm_fwd(x.data_ptr(), x.shape[0], x.shape[1], _NORMALIZE_EPS, y.data_ptr(), inv.data_ptr(),
+                                          _lib.stream_ptr(x.device)), "mi_rownorm_fwd")
+    return y, inv
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """-mean_i log_softmax(v1 v2^T / T)[i, i], rows optionally scaled to unit length first.  The n x n score matrix is
+    kept for the backward, which overwrites it with the gradient of the scores (single use)."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, temperature, b_cos):
+        dev = _lib.require_gpu(v1, v2)
+        lib = _lib.load()
+        if v1.dim() != 2 or v1.shape != v2.shape or v1.shape[0] == 0:
+            raise ValueError("info_nce: the two views must be non-empty [N, D] matrices of the same shape")
+        same = v1.data_ptr() == v2.data_ptr() and v1.stride() == v2.stride()
+        v1 = _kernels._f32c(v1)
+        v2 = v1 if same else _kernels._f32c(v2)
+        n, D = v1.shape
+        inv1 = inv2 = None
+        if b_cos:
+            v1, inv1 = _unit_rows(v1)
+            v2, inv2 = (v1, inv1) if same else _unit_rows(v2)
+        S = torch.empty(n, n, dtype=torch.float32, device=dev)
+        _kernels.gemm(v1, v2, S, n, n, D, D, D, n, transB=True)
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.mi_lse_diag_workspace_elems(n)), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        inv_t = 1.0 / float(temperature)
+        _lib.check(lib.mi_lse_diag_fwd(S.data_ptr(), n, n, inv_t, lse.data_ptr(), ws.data_ptr(), loss.data_ptr(),
+                                       _lib.stream_ptr(dev)), "mi_lse_diag_fwd")
+        ctx.save_for_backward(v1, v2, S, lse, *([inv1, inv2] if b_cos else []))
+        ctx.meta = (n, D, inv_t, bool(b_cos))
+        ctx.spent = False
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.spent:
+            raise RuntimeError("info_nce: the saved score matrix was consumed by an earlier backward")
+        ctx.spent = True
+        v1, v2, S, lse, *invs = ctx.saved_tensors
+        n, D, inv_t, b_cos = ctx.meta
+        lib = _lib.load()
+        dev = S.device
+        g = _kernels._f32c(g).view(1)
+        _lib.check(lib.mi_lse_diag_bwd(S.data_ptr(), n, n, inv_t, lse.data_ptr(), g.data_ptr(), _lib.stream_ptr(dev)),
+                   "mi_lse_diag_bwd")
+        grads = [None, None]
+        for k, (need, other, trans) in enumerate(((ctx.needs_input_grad[0], v2, False), (ctx.needs_input_grad[1], v1, True))):
+            if not need:
+                continue
+            d = torch.empty(n, D, dtype=torch.float32, device=dev)
+            _kernels.gemm(S, other, d, n, D, n, n, D, D, transA=trans)         # dS v2   /   dS^T v1
+            if b_cos:
+                y = (v1, v2)[k]
+                dx = torch.empty_like(d)
+                _lib.check(lib.mi_rownorm_bwd(y.data_ptr(), invs[k].data_ptr(), d.data_ptr(), n, D, _NORMALIZE_EPS,
+                                              dx.data_ptr(), _lib.stream_ptr(dev)), "mi_rownorm_bwd")
+                d = dx
+            grads[k] = d
+        return grads[0], grads[1], None, None
+
+
+def info_nce(view1: torch.Tensor, view2: torch.Tensor, temperature: float = 1, b_cos: bool = True) -> torch.Tensor:
+    """src/losses.py:25-47.  Row normalisation, the score GEMM (mi_gemm_f32), and one kernel for log-softmax + diagonal +
+    mean; the trainer passes the same matrix twice (src/trainer/lightgcn.py:227), which is normalised once."""
+    return _InfoNCEFn.apply(view1, view2, temperature, b_cos)

@@ -31,6 +31,7 @@ class SparseAdam(torch.optim.Optimizer):
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError(f"Invalid betas: {betas}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._workspace = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -54,10 +55,13 @@ class SparseAdam(torch.optim.Optimizer):
                 N = p.shape[0]
                 D = p.numel() // N
                 rows_sorted, perm = torch.sort(rows)
+                acc = self._workspace.get(p)           # not optimizer state: all zero between steps
+                if acc is None or acc.numel() < vals.numel():
+                    acc = self._workspace[p] = torch.zeros(vals.numel(), dtype=torch.float32, device=dev)
                 _lib.check(
                     lib.mi_sparse_adam_sorted(rows_sorted.data_ptr(), perm.data_ptr(), vals.data_ptr(), p.data_ptr(),
                                               state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                              rows.numel(), D, N, step_size, beta1, beta2, group["eps"],
+                                              acc.data_ptr(), rows.numel(), D, N, step_size, beta1, beta2, group["eps"],
                                               _lib.stream_ptr(dev)),
                     "mi_sparse_adam_sorted",
                 )

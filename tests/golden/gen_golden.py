@@ -479,9 +479,36 @@ def gen_csr_pruned():
          out2=torch.nn.functional.embedding(ids2, dense))
 
 
+# ------------------------------------------------------------------ G9: the two losses around the BPR loss
+def gen_losses():
+    gen = torch.Generator().manual_seed(31)
+    n, D, K = 37, 16, 5
+    arrays = {}
+    for tag, b_cos, temp in (("cos_t02", True, 0.2), ("cos_t1", True, 1.0), ("dot_t05", False, 0.5)):
+        v1 = torch.randn(n, D, generator=gen).requires_grad_(True)
+        v2 = torch.randn(n, D, generator=gen).requires_grad_(True)
+        loss = ref_losses.info_nce(v1, v2, temp, b_cos)
+        loss.backward()
+        arrays.update({f"{tag}/v1": v1, f"{tag}/v2": v2, f"{tag}/temperature": np.array(temp), f"{tag}/b_cos": np.array(b_cos),
+                       f"{tag}/loss": loss, f"{tag}/grad_v1": v1.grad, f"{tag}/grad_v2": v2.grad})
+    # the trainer's call: both views are the same matrix (src/trainer/lightgcn.py:219-227)
+    v = torch.randn(n, D, generator=gen).requires_grad_(True)
+    loss = ref_losses.info_nce(v, v, 0.2)
+    loss.backward()
+    arrays.update({"self/v": v, "self/loss": loss, "self/grad_v": v.grad})
+    u = torch.randn(n, D, generator=gen).requires_grad_(True)
+    p = torch.randn(n, D, generator=gen).requires_grad_(True)
+    ng = torch.randn(n, K, D, generator=gen).requires_grad_(True)
+    loss = ref_losses.bpr_loss_multi(u, p, ng)
+    loss.backward()
+    arrays.update({"multi/u": u, "multi/p": p, "multi/n": ng, "multi/loss": loss, "multi/grad_u": u.grad,
+                   "multi/grad_p": p.grad, "multi/grad_n": ng.grad})
+    save("losses", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned", "losses"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("N,D,n", [(1000, 16, 4096), (50, 16, 2000), (300, 7, 500), (100000, 64, 3000), (64, 1, 700)])
+@pytest.mark.parametrize("N,D,n", [(1000, 16, 4096), (50, 16, 2000), (300, 7, 500), (100000, 64, 3000), (64, 1, 700),
+                                   (40, 4, 5000), (200, 256, 900), (3, 16, 4096), (5, 8, 1)])
 def test_sparse_adam_matches_torch(N, D, n):
     gen = torch.Generator().manual_seed(N + D)
     W0 = torch.randn(N, D, generator=gen)
@@ -35,6 +36,8 @@ def test_sparse_adam_matches_torch(N, D, n):
     untouched = torch.ones(N, dtype=torch.bool)
     untouched[rows] = False
     assert omine.state[mine]["step"] == 3
+    # the long-segment workspace is handed back all zero (the next step relies on it)
+    assert not omine._workspace[mine].any()
 
 
 def test_sparse_sgd_and_factory_end_to_end():
