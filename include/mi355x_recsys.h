@@ -404,15 +404,19 @@ MI_API int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const f
  *   vals fp32[n,D]); duplicates are summed (== grad.coalesce()), then for each touched row
  *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); W -= step_size * m/(sqrt(v)+eps),
  *   step_size = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host (torch/optim/sparse_adam.py).
- *   acc fp32[n,D] is workspace that must be all zero on entry and is all zero again on exit
- *   (rows repeated more often than one wave pass covers are summed there with float atomics).
- * mi_scatter_axpy_rows: W[idx[i],:] += alpha*g[i,:] (row-sparse SGD, alpha = -lr; float atomics).
+ *   step_size_dev (nullable): read the step size from device memory instead — mi_adam_tick(step, step_size, lr, b1, b2)
+ *   does step[0] += 1 and writes it there, so a captured training step needs no host-side counter.
+ *   acc fp32[n,D] is scratch (contents irrelevant before and after): a row repeated more often than one wave pass
+ *   covers leaves a partial sum per pass there, which a second kernel adds in a fixed order (no atomics: the step is
+ *   deterministic).
  */
 MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm,
                                  const float *vals, float *W, float *exp_avg,
                                  float *exp_avg_sq, float *acc, int64_t n, int32_t D,
-                                 int64_t N, float step_size, float beta1, float beta2,
-                                 float eps, void *stream);
+                                 int64_t N, float step_size, const float *step_size_dev,
+                                 float beta1, float beta2, float eps, void *stream);
+MI_API int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2,
+                        void *stream);
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 

@@ -96,27 +96,37 @@ class GatherFM(torch.autograd.Function):
                 "mi_gather_fm_bwd_rows",
             )
             gb_done = True
-            if sparse_W and need_W:
-                gW = _coo(rows, gvals, Wshape)
-            if sparse_w1 and need_w1:
-                gw1 = _coo(rows, g1vals.view((-1,) + (1,) * (len(w1shape) - 1)), w1shape)
-        if dense_form:
+            # a table that wants a dense gradient next to one in row form (the reference's sparse config keeps the
+            # first-order table dense): scatter-add the values just computed — never a second pass over a zeroed [N, D]
+            if need_W:
+                gW = _coo(rows, gvals, Wshape) if sparse_W else _scatter_rows(rows, gvals, N, D, stream).view(Wshape)
+            if need_w1:
+                gw1 = (_coo(rows, g1vals.view((-1,) + (1,) * (len(w1shape) - 1)), w1shape) if sparse_w1
+                       else _scatter_rows(rows, g1vals, N, 1, stream).view(w1shape))
+        elif dense_form:
             gWd = torch.zeros((N, D), dtype=torch.float32, device=dev)
             gw1d = torch.zeros((N,), dtype=torch.float32, device=dev)
             _lib.check(
                 lib.mi_gather_fm_bwd_dense(rows.data_ptr(), emb.data_ptr(), g_y.data_ptr(),
                                            _lib.ptr(g_emb), gWd.data_ptr(), gw1d.data_ptr(),
-                                           None if gb_done else _lib.ptr(gb), B, F, D, N, stream),
+                                           _lib.ptr(gb), B, F, D, N, stream),
                 "mi_gather_fm_bwd_dense",
             )
             gb_done = True
-            if need_W and not sparse_W:
+            if need_W:
                 gW = gWd.view(Wshape)
-            if need_w1 and not sparse_w1:
+            if need_w1:
                 gw1 = gw1d.view(w1shape)
         if gb is not None and not gb_done:          # neither table needs a gradient: nothing was launched
             gb = g_y.sum().view(1)
         return None, None, gW, gw1, gb, None, None
+
+
+def _scatter_rows(rows, vals, N, D, stream):
+    out = torch.zeros((N, D), dtype=torch.float32, device=vals.device)
+    _lib.check(_lib.load().mi_scatter_axpy_rows(rows.data_ptr(), vals.data_ptr(), 1.0, out.data_ptr(), rows.numel(), D, N,
+                                                stream), "mi_scatter_axpy_rows")
+    return out
 
 
 def gather_fm(idx, offsets, W, w1, bias, sparse_W=False, sparse_w1=False):

@@ -25,12 +25,16 @@ def _coo_parts(grad: torch.Tensor):
 
 
 class SparseAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.SparseAdam's arguments plus `capturable`: the step count and the bias-corrected step size live on the
+    device (state["step"] becomes a 0-dim float tensor, as in torch's capturable Adam) and are advanced by a one-thread
+    kernel, so step() has no host-side state and can be captured into a hipGraph (trainer.GraphedTrainStep)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if not 0.0 < lr:
             raise ValueError(f"Invalid learning rate: {lr}")
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError(f"Invalid betas: {betas}")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, capturable=bool(capturable)))
         self._workspace = {}
 
     @torch.no_grad()
@@ -39,6 +43,7 @@ class SparseAdam(torch.optim.Optimizer):
         lib = _lib.load()
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
+            capturable = group.get("capturable", False)
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -46,23 +51,32 @@ class SparseAdam(torch.optim.Optimizer):
                 rows, vals = _coo_parts(p.grad)
                 state = self.state[p]
                 if not state:
-                    state["step"] = 0
+                    state["step"] = torch.zeros((), dtype=torch.float32, device=dev) if capturable else 0
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
-                t = state["step"]
-                step_size = group["lr"] * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+                stream = _lib.stream_ptr(dev)
+                if capturable:
+                    ss = self._workspace.get((p, "step_size"))
+                    if ss is None:
+                        ss = self._workspace[(p, "step_size")] = torch.zeros(1, dtype=torch.float32, device=dev)
+                    _lib.check(lib.mi_adam_tick(state["step"].data_ptr(), ss.data_ptr(), group["lr"], beta1, beta2, stream),
+                               "mi_adam_tick")
+                    step_size, step_size_dev = 0.0, ss.data_ptr()
+                else:
+                    state["step"] += 1
+                    t = state["step"]
+                    step_size, step_size_dev = group["lr"] * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t), None
                 N = p.shape[0]
                 D = p.numel() // N
                 rows_sorted, perm = torch.sort(rows)
-                acc = self._workspace.get(p)           # not optimizer state: all zero between steps
+                acc = self._workspace.get(p)           # scratch, not optimizer state
                 if acc is None or acc.numel() < vals.numel():
-                    acc = self._workspace[p] = torch.zeros(vals.numel(), dtype=torch.float32, device=dev)
+                    acc = self._workspace[p] = torch.empty(vals.numel(), dtype=torch.float32, device=dev)
                 _lib.check(
                     lib.mi_sparse_adam_sorted(rows_sorted.data_ptr(), perm.data_ptr(), vals.data_ptr(), p.data_ptr(),
                                               state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                              acc.data_ptr(), rows.numel(), D, N, step_size, beta1, beta2, group["eps"],
-                                              _lib.stream_ptr(dev)),
+                                              acc.data_ptr(), rows.numel(), D, N, step_size, step_size_dev, beta1, beta2,
+                                              group["eps"], stream),
                     "mi_sparse_adam_sorted",
                 )
         return loss
@@ -92,19 +106,35 @@ class SparseSGD(torch.optim.Optimizer):
         return loss
 
 
+def _dense_adam(params, lr, weight_decay):
+    """torch.optim.Adam with the reference's arguments.  For parameters on the GPU it is torch's single-pass multi-tensor
+    implementation (`fused=True`: same update, one read and one write of p, m, v per step instead of the default
+    implementation's several passes — 11.6 -> 3.8 ms over the 574 M parameters of the headline model) with a device-side
+    step count (`capturable=True`), so that a whole training step can be replayed as a hipGraph."""
+    on_gpu = len(params) > 0 and all(p.is_cuda and p.is_floating_point() for p in params)
+    if on_gpu:
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+
+
 def get_optimizers(model, config: Dict) -> List[torch.optim.Optimizer]:
     """src/models/deepfm.py:155-219 with the sparse branches on the fused row-sparse steps."""
     sparse: bool = config.get("sparse", False)
     optimizer_name: str = config.get("optimizer", "adam")
     lr_emb = config.get("learning_rate_emb", config["learning_rate"])
     if sparse:
-        decay_param = [p for name, p in model.named_parameters() if "embedding." not in name]
-        no_decay_param = list(model.embedding.parameters())
+        # extension (off unless DeepFM(fc_sparse=True)): a first-order table that emits row-form gradients joins the
+        # row-sparse group, since torch's dense Adam/SGD reject sparse gradients
+        fc = getattr(model, "fc", None)
+        fc_rows = list(fc.parameters()) if getattr(fc, "sparse", False) else []
+        decay_param = [p for name, p in model.named_parameters()
+                       if "embedding." not in name and not any(p is q for q in fc_rows)]
+        no_decay_param = list(model.embedding.parameters()) + fc_rows
     if sparse and optimizer_name == "adam":
-        return [SparseAdam(no_decay_param, lr=lr_emb),
-                torch.optim.Adam(decay_param, lr=config["learning_rate"], weight_decay=config["weight_decay"])]
+        return [SparseAdam(no_decay_param, lr=lr_emb, capturable=all(p.is_cuda for p in no_decay_param)),
+                _dense_adam(decay_param, lr=config["learning_rate"], weight_decay=config["weight_decay"])]
     if optimizer_name == "adam":
-        return [torch.optim.Adam(model.parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"])]
+        return [_dense_adam(list(model.parameters()), lr=config["learning_rate"], weight_decay=config["weight_decay"])]
     elif optimizer_name == "sgd":
         if not sparse:
             return [torch.optim.SGD(model.parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"])]

@@ -169,3 +169,19 @@ def test_registry_forced_arguments_and_field_name():
     import recsys_benchmark_amd.embeddings as E
     emb = E.get_embedding(cfg, [5, 7], 8)
     assert cfg == {"name": "qr", "divider": 3} and type(emb).__name__ == "QRHashingEmbedding"
+
+
+def test_binary_auc_is_sklearns_roc_auc_with_ties():
+    from sklearn.metrics import roc_auc_score
+
+    from recsys_benchmark_amd.trainer import binary_auc
+
+    gen = torch.Generator().manual_seed(0)
+    for n, levels in ((1000, 0), (500, 7), (64, 2)):
+        score = torch.rand(n, generator=gen)
+        if levels:
+            score = (score * levels).floor() / levels          # many tied scores
+        true = (torch.rand(n, generator=gen) < 0.4).float()
+        assert abs(binary_auc(true, score) - roc_auc_score(true.tolist(), score.tolist())) < 1e-12
+    with pytest.raises(ValueError):
+        binary_auc(torch.ones(5), torch.rand(5))

@@ -36,8 +36,27 @@ def test_sparse_adam_matches_torch(N, D, n):
     untouched = torch.ones(N, dtype=torch.bool)
     untouched[rows] = False
     assert omine.state[mine]["step"] == 3
-    # the long-segment workspace is handed back all zero (the next step relies on it)
-    assert not omine._workspace[mine].any()
+
+
+def test_sparse_adam_is_deterministic_and_capturable_mode_agrees():
+    gen = torch.Generator().manual_seed(9)
+    N, D, n = 40, 16, 6000                                  # every row repeated ~150 times: all on the multi-pass route
+    W0 = torch.randn(N, D, generator=gen).to(DEV)
+    runs = []
+    for capturable in (False, False, True):
+        p = torch.nn.Parameter(W0.clone())
+        opt = SparseAdam([p], lr=0.01, capturable=capturable)
+        g2 = torch.Generator().manual_seed(10)
+        for _ in range(4):
+            rows = torch.randint(0, N, (n,), generator=g2).to(DEV)
+            vals = torch.randn(n, D, generator=g2).to(DEV)
+            p.grad = torch.sparse_coo_tensor(rows.view(1, -1), vals, (N, D), check_invariants=False)
+            opt.step()
+        runs.append((p.detach().clone(), opt.state[p]["exp_avg_sq"].clone(), opt.state[p]["step"]))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "two identical runs differ"
+    # device-side step size: double arithmetic rounded to fp32, the host path's value
+    assert torch.equal(runs[0][0], runs[2][0]), "capturable mode differs from the host-side step count"
+    assert float(runs[2][2]) == 4.0 and runs[0][2] == 4
 
 
 def test_sparse_sgd_and_factory_end_to_end():

@@ -1,0 +1,107 @@
+"""GPU: the CTR training loop around the path (reference: src/trainer/deepfm.py:17-139).  A hipGraph-replayed training step
+must leave the model and both optimizers exactly where the same steps launched eagerly leave them (same kernels, same
+order; the only run-to-run freedom is the order of float atomics in the dense first-order-table gradient)."""
+import copy
+
+import pytest
+import torch
+
+from conftest import assert_close
+
+import recsys_benchmark_amd as pkg
+from recsys_benchmark_amd import trainer
+from recsys_benchmark_amd.optim import get_optimizers
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+DIMS = [50, 3, 1000, 7, 200]
+
+
+def _batches(n, B, seed):
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in DIMS], 1)
+        out.append((x, (torch.rand(B, generator=gen) < 0.3).float()))
+    return out
+
+
+def _model(sparse, fc_sparse=False):
+    torch.manual_seed(3)
+    return pkg.DeepFM(DIMS, 16, [64, 32], p_dropout=0.0, use_batchnorm=True,
+                      embedding_config={"name": "vanilla", "sparse": sparse}, fc_sparse=fc_sparse).to(DEV)
+
+
+@pytest.mark.parametrize("sparse,fc_sparse", [(True, False), (True, True), (False, False)])
+def test_graphed_step_equals_eager_steps(sparse, fc_sparse):
+    cfg = {"sparse": sparse, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    ref_model = _model(sparse, fc_sparse)
+    model = copy.deepcopy(ref_model)
+    ref_step = trainer.GraphedTrainStep(ref_model, get_optimizers(ref_model, cfg), use_graph=False)
+    step = trainer.GraphedTrainStep(model, get_optimizers(model, cfg), warmup=2)
+    data = _batches(9, 256, 11)
+    for x, y in data:
+        ref_step(x.to(DEV), y.to(DEV))
+        step(x.to(DEV), y.to(DEV))
+    assert step._graph is not None, "the step was never captured"
+    assert_close(step.loss_sum, ref_step.loss_sum, 1e-6, 1e-6, "accumulated loss")
+    # Adam divides by sqrt(v): where a gradient is almost zero, the last-bit freedom of the float atomics (dense table
+    # gradients, column sums of the MLP backward) comes out amplified in a handful of elements — 2e-5 absolute is
+    # 0.2 % of one lr-sized step; a stale buffer or a wrong step count would be off by whole steps (1e-2)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
+        assert_close(a, b, 1e-3, 2e-5, k)
+    for oa, ob in zip(step.optimizers, ref_step.optimizers):
+        for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+            if not oa.state[pa] and not ob.state[pb]:
+                continue                                   # never received a gradient (DeepFM.linear_layer is unused)
+            for key in ("step", "exp_avg", "exp_avg_sq"):
+                assert_close(torch.as_tensor(oa.state[pa][key]).float(), torch.as_tensor(ob.state[pb][key]).float(), 1e-3, 1e-7,
+                             key)
+    # a batch of another shape runs eagerly and the graph stays valid for the next full batch
+    x, y = _batches(1, 100, 5)[0]
+    for s in (ref_step, step):
+        s(x.to(DEV), y.to(DEV))
+        s(data[0][0].to(DEV), data[0][1].to(DEV))
+    assert_close(step.loss_sum, ref_step.loss_sum, 1e-6, 1e-6, "accumulated loss after a ragged batch")
+    assert_close(model.embedding.get_weight(), ref_model.embedding.get_weight(), 1e-3, 2e-5, "table after a ragged batch")
+
+
+def test_train_epoch_matches_a_hand_written_loop_and_learns():
+    cfg = {"sparse": True, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    model = _model(True)
+    ref = copy.deepcopy(model)
+    data = _batches(6, 128, 2) + _batches(1, 40, 3)          # ragged last batch
+    opts = get_optimizers(model, cfg)
+    step = trainer.GraphedTrainStep(model, opts)
+    first = trainer.train_epoch(data, model, opts, device=DEV, log_step=3, step=step)
+    # the reference's loop, spelled out with stock criterion on the same kernels
+    ropts = get_optimizers(ref, cfg)
+    crit = torch.nn.BCEWithLogitsLoss()
+    total = 0.0
+    ref.train()
+    for x, y in data:
+        out = ref(x.to(DEV))
+        loss = crit(out, y.to(DEV).float())
+        for o in ropts:
+            o.zero_grad()
+        loss.backward()
+        for o in ropts:
+            o.step()
+        total += loss.item()
+    assert abs(first["loss"] - total / len(data)) < 1e-5
+    later = [trainer.train_epoch(data, model, opts, device=DEV, log_step=0, step=step)["loss"] for _ in range(15)][-1]
+    assert later < first["loss"] * 0.8, (first, later)
+
+
+def test_validate_epoch_matches_sklearn():
+    from sklearn.metrics import log_loss, roc_auc_score
+
+    model = _model(False)
+    data = _batches(5, 200, 8) + _batches(1, 33, 9)
+    res = trainer.validate_epoch(data, model, device=DEV)
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([torch.sigmoid(model(x.to(DEV))).cpu() for x, _ in data]).double()
+    true = torch.cat([y for _, y in data])
+    assert abs(res["auc"] - roc_auc_score(true.tolist(), pred.tolist())) < 1e-9
+    assert abs(res["log_loss"] - log_loss(true.numpy(), pred.numpy())) < 1e-5
