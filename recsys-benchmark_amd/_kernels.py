@@ -5,6 +5,8 @@ arithmetic step of the hot path runs in libmi355x_recsys.so.
 """
 from typing import Optional, Tuple
 
+import collections
+
 import torch
 
 from . import _lib
@@ -26,6 +28,36 @@ def _i64c(t: torch.Tensor) -> torch.Tensor:
 
 def _coo(rows: torch.Tensor, vals: torch.Tensor, shape) -> torch.Tensor:
     return torch.sparse_coo_tensor(rows.view(1, -1), vals, shape, check_invariants=False)
+
+
+# Row ids that came from a multi-field lookup (rows[b, f] = x[b, f] + offsets[f]) and may later head a row-form
+# gradient: the optimizer can sort them field by field in LDS (mi_sort_field_rows) instead of generically.  The entry
+# holds the ids tensor itself, so its storage — and with it the pointer used as the key — cannot be recycled while the
+# entry lives; only the last few lookups are kept.
+_field_layouts: "collections.OrderedDict[int, tuple]" = collections.OrderedDict()
+
+
+def _note_field_layout(rows: torch.Tensor, offsets: torch.Tensor, N: int) -> None:
+    _field_layouts[rows.data_ptr()] = (rows, offsets, N)
+    _field_layouts.move_to_end(rows.data_ptr())
+    while len(_field_layouts) > 4:
+        _field_layouts.popitem(last=False)
+
+
+def sort_field_rows(rows_flat: torch.Tensor, N: int):
+    """(sorted ids, permutation) of a flat view of ids noted by a multi-field lookup, or None when the ids are not known
+    to have that layout (or exceed the LDS sort's limits) and the caller has to sort them generically."""
+    entry = _field_layouts.get(rows_flat.data_ptr())
+    if entry is None:
+        return None
+    rows, offsets, n_rows = entry
+    B, F = rows.shape
+    if rows_flat.numel() != B * F or n_rows != N or B > 8192 or N >= 2**32 - 2 or B == 0:
+        return None
+    rows_sorted, perm = torch.empty_like(rows_flat), torch.empty_like(rows_flat)
+    _lib.check(_lib.load().mi_sort_field_rows(rows.data_ptr(), offsets.data_ptr(), N, B, F, rows_sorted.data_ptr(),
+                                              perm.data_ptr(), _lib.stream_ptr(rows.device)), "mi_sort_field_rows")
+    return rows_sorted, perm
 
 
 class GatherFM(torch.autograd.Function):
@@ -60,6 +92,8 @@ class GatherFM(torch.autograd.Function):
             ),
             "mi_gather_fm_fwd",
         )
+        if sparse_W or sparse_w1:
+            _note_field_layout(rows, offsets, N)
         ctx.save_for_backward(emb, rows)
         ctx.shapes = (B, F, D, N, tuple(W.shape), tuple(w1.shape))
         ctx.sparse = (sparse_W, sparse_w1)

@@ -12,7 +12,7 @@ from typing import Dict, List
 
 import torch
 
-from . import _lib
+from . import _kernels, _lib
 
 
 def _coo_parts(grad: torch.Tensor):
@@ -22,6 +22,15 @@ def _coo_parts(grad: torch.Tensor):
     rows = grad._indices()[0].contiguous()
     vals = grad._values().contiguous()
     return rows, vals.view(vals.shape[0], -1)
+
+
+def sort_rows(rows: torch.Tensor, N: int):
+    """(sorted row ids, permutation) of a row-form gradient's ids.  Ids produced by a multi-field lookup are sorted
+    field by field in LDS (one launch, ≈4x faster than a generic sort at the headline shape); anything else by
+    torch.sort (stable is not needed for correctness, only the grouping is)."""
+    _lib.require_gpu(rows)
+    found = _kernels.sort_field_rows(rows, N)
+    return found if found is not None else tuple(torch.sort(rows))
 
 
 class SparseAdam(torch.optim.Optimizer):
@@ -41,6 +50,7 @@ class SparseAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib = _lib.load()
+        sorted_ids = {}      # both DeepFM tables receive gradients over the same ids: sort them once per step
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             capturable = group.get("capturable", False)
@@ -68,7 +78,10 @@ class SparseAdam(torch.optim.Optimizer):
                     step_size, step_size_dev = group["lr"] * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t), None
                 N = p.shape[0]
                 D = p.numel() // N
-                rows_sorted, perm = torch.sort(rows)
+                key = (rows.data_ptr(), rows.numel(), N)
+                if key not in sorted_ids:
+                    sorted_ids[key] = sort_rows(rows, N) if rows.numel() else (rows, rows)
+                rows_sorted, perm = sorted_ids[key]
                 acc = self._workspace.get(p)           # scratch, not optimizer state
                 if acc is None or acc.numel() < vals.numel():
                     acc = self._workspace[p] = torch.empty(vals.numel(), dtype=torch.float32, device=dev)

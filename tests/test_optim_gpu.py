@@ -7,7 +7,7 @@ import torch
 from conftest import assert_close
 
 import recsys_benchmark_amd as pkg
-from recsys_benchmark_amd.optim import SparseAdam, SparseSGD, get_optimizers
+from recsys_benchmark_amd.optim import SparseAdam, SparseSGD, get_optimizers, sort_rows
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -36,6 +36,41 @@ def test_sparse_adam_matches_torch(N, D, n):
     untouched = torch.ones(N, dtype=torch.bool)
     untouched[rows] = False
     assert omine.state[mine]["step"] == 3
+
+
+@pytest.mark.parametrize("B,dims", [(1, [7]), (5, [3, 1, 9]), (1000, [2, 50, 100000]), (4096, [1460, 583, 10131227, 3, 24]),
+                                    (8192, [40, 5]), (4097, [1, 1, 300])])
+def test_field_sort_is_a_stable_sort_of_the_batch_ids(B, dims):
+    from recsys_benchmark_amd import _kernels
+
+    gen = torch.Generator().manual_seed(B)
+    F, N = len(dims), sum(dims)
+    offsets = torch.tensor([0] + dims[:-1]).cumsum(0)
+    rows = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1) + offsets
+    if B > 8:                                   # ids outside their field's range come back as N behind the field's ids
+        rows[1, 0], rows[5, F - 1], rows[B - 1, 0] = -1, N + 12345, dims[0] if F > 1 else N
+    drows = rows.to(DEV)
+    _kernels._note_field_layout(drows, offsets.to(DEV), N)
+    got_rows, got_perm = sort_rows(drows.view(-1), N)
+    lo, hi = offsets, torch.cat([offsets[1:], torch.tensor([N])])
+    bad = (rows < lo) | (rows >= hi)
+    # expected: each column stably sorted with its bad ids last, columns laid end to end
+    want_rows, want_perm = [], []
+    for f in range(F):
+        key = torch.where(bad[:, f], torch.full((B,), 2**62), rows[:, f])
+        k, order = torch.sort(key, stable=True)
+        want_rows.append(torch.where(k == 2**62, torch.full_like(k, N), k))
+        want_perm.append(order * F + f)
+    assert torch.equal(got_rows.cpu(), torch.cat(want_rows))            # integer work: bit-exact
+    assert torch.equal(got_perm.cpu(), torch.cat(want_perm))
+    if not bad.any():
+        assert torch.equal(got_rows.cpu(), torch.sort(rows.view(-1))[0])
+
+
+def test_ids_without_a_noted_layout_are_sorted_generically():
+    rows = torch.randint(0, 1000, (20000,)).to(DEV)
+    got_rows, got_perm = sort_rows(rows, 1000)
+    assert torch.equal(got_rows, torch.sort(rows)[0]) and torch.equal(rows[got_perm], got_rows)
 
 
 def test_sparse_adam_is_deterministic_and_capturable_mode_agrees():

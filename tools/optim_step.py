@@ -40,7 +40,8 @@ def main():
     N = sum(dims)
     x, _ = synth_batch(dims, a.batch, 1, dev)
     offs = torch.tensor([0] + dims[:-1], device=dev).cumsum(0)
-    rows = (x + offs).reshape(-1)
+    rows2d = x + offs
+    rows = rows2d.reshape(-1)
     vals = torch.randn(rows.numel(), D, device=dev) * 1e-3
 
     def grad():
@@ -57,6 +58,13 @@ def main():
         del opt, p
         torch.cuda.empty_cache()
     out["torch.sort(rows) alone"] = timeit(lambda: torch.sort(rows), a.iters)
+    from recsys_benchmark_amd import _kernels
+    _kernels._note_field_layout(rows2d, offs, N)           # what the multi-field lookup does for its ids
+    out["field sort (LDS) alone"] = timeit(lambda: rbo.sort_rows(rows, N), a.iters)
+    p = torch.nn.Parameter(torch.zeros(N, D, device=dev))
+    opt = rbo.SparseAdam([p], lr=1e-3)
+    p.grad = grad()
+    out["optim.SparseAdam, field sort"] = timeit(opt.step, a.iters)
     uniq = torch.unique(rows).numel()
     print(f"n={rows.numel()} rows, {uniq} distinct, D={D}, table {N} rows")
     for k, v in out.items():
