@@ -37,7 +37,11 @@ def _coo(rows: torch.Tensor, vals: torch.Tensor, shape) -> torch.Tensor:
 _field_layouts: "collections.OrderedDict[int, tuple]" = collections.OrderedDict()
 
 
-def _note_field_layout(rows: torch.Tensor, offsets: torch.Tensor, N: int) -> None:
+def note_field_layout(rows: torch.Tensor, offsets: torch.Tensor, N: int) -> None:
+    """rows int64[B, F] = x + offsets (offsets ascending, field f's ids in [offsets[f], offsets[f+1]), the last below N)."""
+    if rows.dim() != 2 or not rows.is_contiguous() or rows.dtype != torch.int64 or not rows.is_cuda:
+        return
+    offsets = offsets.reshape(-1)
     _field_layouts[rows.data_ptr()] = (rows, offsets, N)
     _field_layouts.move_to_end(rows.data_ptr())
     while len(_field_layouts) > 4:
@@ -93,7 +97,7 @@ class GatherFM(torch.autograd.Function):
             "mi_gather_fm_fwd",
         )
         if sparse_W or sparse_w1:
-            _note_field_layout(rows, offsets, N)
+            note_field_layout(rows, offsets, N)
         ctx.save_for_backward(emb, rows)
         ctx.shapes = (B, F, D, N, tuple(W.shape), tuple(w1.shape))
         ctx.sparse = (sparse_W, sparse_w1)

@@ -43,10 +43,12 @@ class DCN_Mix(nn.Module):
         layers.append(nn.Linear(inp_size, 1))
         self._dnn = nn.Sequential(*layers)
         self.register_buffer("offsets", _offsets(field_dims))
+        self._num_rows = int(sum(field_dims))
 
     def forward(self, x):
         """x: int [B, F] -> logits [B]."""
         x = x + self.offsets
+        _kernels.note_field_layout(x, self.offsets, self._num_rows)     # lets the sparse optimizer sort field by field
         emb = self.embedding(x)
         bs = x.shape[0]
         cross_logit = self.cross_head(emb.reshape(bs, -1))
@@ -86,9 +88,11 @@ class DCNv2(nn.Module):
             self._last_fc = nn.Linear(inp_size + dnn_out, 1)
         self._dnn = nn.Sequential(*layers)
         self.register_buffer("offsets", _offsets(field_dims))
+        self._num_rows = int(sum(field_dims))
 
     def forward(self, x):
         x = x + self.offsets
+        _kernels.note_field_layout(x, self.offsets, self._num_rows)     # lets the sparse optimizer sort field by field
         emb = self.embedding(x)
         bs = x.shape[0]
         emb = emb.reshape(bs, -1)

@@ -83,6 +83,7 @@ class DeepFM(nn.Module):
                 sparse_W=emb_mod.sparse_grad, sparse_w1=bool(self.fc.sparse),
             )
         rows = x + self.offsets
+        _kernels.note_field_layout(rows, self.offsets, self.fc.weight.shape[0])   # lets the sparse optimizer sort by field
         emb = emb_mod(rows)
         return _kernels.fm_first_order(emb, rows, self.fc.weight, self._bias,
                                        sparse_w1=bool(self.fc.sparse))

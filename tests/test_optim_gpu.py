@@ -50,7 +50,7 @@ def test_field_sort_is_a_stable_sort_of_the_batch_ids(B, dims):
     if B > 8:                                   # ids outside their field's range come back as N behind the field's ids
         rows[1, 0], rows[5, F - 1], rows[B - 1, 0] = -1, N + 12345, dims[0] if F > 1 else N
     drows = rows.to(DEV)
-    _kernels._note_field_layout(drows, offsets.to(DEV), N)
+    _kernels.note_field_layout(drows, offsets.to(DEV), N)
     got_rows, got_perm = sort_rows(drows.view(-1), N)
     lo, hi = offsets, torch.cat([offsets[1:], torch.tensor([N])])
     bad = (rows < lo) | (rows >= hi)

@@ -58,6 +58,14 @@ def run(name, model):
     t_graph = wall(graph.replay)
     print(f"[{name}] eager {t_eager:.0f} us/step, hipGraph replay {t_graph:.0f} us/step = {B / t_graph:.2f} M samples/s "
           f"(loss {float(loss):.4f})")
+    # the whole training step (+ zero_grad and the optimizers of get_optimizers) as trainer.GraphedTrainStep replays it
+    from recsys_benchmark_amd import optim, trainer
+    sparse = bool(getattr(model.embedding, "sparse_grad", False))
+    opts = optim.get_optimizers(model, {"optimizer": "adam", "learning_rate": 1e-3, "weight_decay": 1e-6, "sparse": sparse})
+    tstep = trainer.GraphedTrainStep(model, opts, lossf)
+    t_train = wall(lambda: tstep(x, y))
+    print(f"    + optimizers ({'SparseAdam + Adam' if sparse else 'Adam'}), one hipGraph: {t_train:.0f} us/step = "
+          f"{B / t_train:.2f} M samples/s{'' if tstep._graph is not None else '  [NOT captured]'}")
     pkg.check_index_errors()
 
 
@@ -69,6 +77,8 @@ def main():
                                     embedding_config=emb, p_dropout=0.5))
     run("DCN-Mix  vanilla", DCN_Mix(AVAZU_22, 16, [400, 400, 400], num_layers=3, num_experts=4, rank=64,
                                     embedding_config={"name": "vanilla"}, p_dropout=0.5))
+    run("DCN-Mix  vanilla, row-form grads", DCN_Mix(AVAZU_22, 16, [400, 400, 400], num_layers=3, num_experts=4, rank=64,
+                                                    embedding_config={"name": "vanilla", "sparse": True}, p_dropout=0.5))
     run("DCNv2 stacked   ", DCNv2(AVAZU_22, 16, [400, 400, 400], num_layers=3, embedding_config={"name": "vanilla"}))
 
 

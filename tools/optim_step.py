@@ -59,7 +59,7 @@ def main():
         torch.cuda.empty_cache()
     out["torch.sort(rows) alone"] = timeit(lambda: torch.sort(rows), a.iters)
     from recsys_benchmark_amd import _kernels
-    _kernels._note_field_layout(rows2d, offs, N)           # what the multi-field lookup does for its ids
+    _kernels.note_field_layout(rows2d, offs, N)           # what the multi-field lookup does for its ids
     out["field sort (LDS) alone"] = timeit(lambda: rbo.sort_rows(rows, N), a.iters)
     p = torch.nn.Parameter(torch.zeros(N, D, device=dev))
     opt = rbo.SparseAdam([p], lr=1e-3)
