@@ -414,7 +414,7 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
                                  const float *vals, float *W, float *exp_avg,
                                  float *exp_avg_sq, float *acc, int64_t n, int32_t D,
                                  int64_t N, float step_size, const float *step_size_dev,
-                                 float beta1, float beta2, float eps, void *stream);
+                                 double beta1, double beta2, float eps, void *stream);
 /* mi_sort_field_rows: rows int64[B,F] with rows[b,f] in [offsets[f], offsets[f+1]) (offsets ascending, offsets[F] := N —
  *   the ids DeepFM forms at src/models/deepfm.py:88).  rows_sorted[B*F] ascending and perm[i] = flat position b*F+f of
  *   the i-th smallest, equal ids in ascending b (a stable sort); an id outside its field's range comes back as N behind
@@ -425,6 +425,17 @@ MI_API int mi_sort_field_rows(const int64_t *rows, const int64_t *offsets, int64
                               int32_t F, int64_t *rows_sorted, int64_t *perm, void *stream);
 MI_API int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2,
                         void *stream);
+/* mi_adam_dense_multi: torch.optim.Adam (L2 weight decay, no amsgrad) over `count` dense fp32 tensors in as few launches as
+ *   possible — get_optimizers' dense groups (src/models/deepfm.py:178-193).  The five pointer arrays and numels live in
+ *   HOST memory; steps[i] points at tensor i's device-side step count (a float, torch's capturable layout), read as
+ *   t = step + 1 and advanced by one after the update:
+ *   g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ *   The betas are doubles: 1 - beta is formed in double and then rounded (1.f - 0.999f is off by 1.3e-5).
+ */
+MI_API int mi_adam_dense_multi(float *const *params, const float *const *grads, float *const *exp_avgs,
+                               float *const *exp_avg_sqs, float *const *steps, const int64_t *numels,
+                               int32_t count, float lr, double beta1, double beta2, float eps,
+                               float weight_decay, void *stream);
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 

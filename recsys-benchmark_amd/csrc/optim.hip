@@ -20,7 +20,7 @@ struct AdamArgs {
   float *W, *M, *V;      // [N, D]
   float *acc;            // [n, D] scratch: per-pass pieces of the segments longer than one pass
   int64_t n, N;
-  float step_size, beta1, beta2, eps;
+  float step_size, omb1, omb2, eps;   // omb = 1 - beta, formed in double by the host (1.f - 0.999f is off by 1.3e-5)
   const float *step_size_dev;   // when given: the step size lives on the device (mi_adam_tick), hipGraph replays
 };
 
@@ -32,8 +32,8 @@ __global__ void k_adam_tick(float *step, float *step_size, double lr, double bet
 }
 
 __device__ __forceinline__ float adam1(const AdamArgs &a, float g, float &m, float &v) {
-  m += (1.f - a.beta1) * (g - m);
-  v += (1.f - a.beta2) * (g * g - v);
+  m += a.omb1 * (g - m);
+  v += a.omb2 * (g * g - v);
   return a.step_size * (m / (sqrtf(v) + a.eps));
 }
 __device__ __forceinline__ void resolve_step_size(AdamArgs &a) {
@@ -177,6 +177,80 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam_anyD(AdamArgs a, int D) 
   }
 }
 
+// ---- dense Adam over a list of tensors (torch.optim.Adam, L2 weight decay) --------------------------------------
+// One launch updates up to kAdamTensors tensors: workgroup c owns one 4096-element chunk of one tensor (chunk counts are
+// prefix-summed in the table), every thread four float4 groups with all loads issued before the arithmetic — 7 streams
+// (p, g, m, v in; p, m, v out), HBM-bound for the big tables and one launch instead of a 40 us multi_tensor_apply for the
+// MLP's 0.5 M parameters.  The step count is a device float per tensor (torch's capturable layout): this kernel reads
+// t = step + 1, k_adam_steps_inc advances the counters afterwards.
+constexpr int kAdamTensors = 12;
+constexpr int kAdamChunk = kBlock * 16;
+struct AdamDenseTable {
+  float *p[kAdamTensors];
+  const float *g[kAdamTensors];
+  float *m[kAdamTensors];
+  float *v[kAdamTensors];
+  float *step[kAdamTensors];
+  int64_t numel[kAdamTensors];
+  int64_t chunk_end[kAdamTensors];   // prefix sum of ceil(numel / kAdamChunk)
+  int32_t count;
+  uint32_t vec_ok;                   // bit k: all four pointers of tensor k are 16-byte aligned
+};
+
+__device__ __forceinline__ void adam_dense1(float &p, float g, float &m, float &v, float omb1, float b2, float omb2, float wd,
+                                            float step_size, float inv_bc2s, float eps) {
+  g += wd * p;
+  m += omb1 * (g - m);                             // m.lerp_(g, 1 - b1)
+  v = b2 * v + omb2 * g * g;
+  p -= step_size * (m / (sqrtf(v) * inv_bc2s + eps));
+}
+
+__global__ __launch_bounds__(kBlock) void k_adam_dense(AdamDenseTable t, float lr, double beta1, double beta2, float eps,
+                                                       float wd) {
+  __shared__ float s_step_size, s_inv_bc2s;
+  int k = 0;
+  while (k + 1 < t.count && (int64_t)blockIdx.x >= t.chunk_end[k]) ++k;
+  const int64_t chunk = (int64_t)blockIdx.x - (k ? t.chunk_end[k - 1] : 0);
+  if (threadIdx.x == 0) {
+    const double tt = (double)t.step[k][0] + 1.0;
+    s_step_size = (float)((double)lr / (1.0 - pow(beta1, tt)));
+    s_inv_bc2s = (float)(1.0 / sqrt(1.0 - pow(beta2, tt)));
+  }
+  __syncthreads();
+  const float step_size = s_step_size, inv_bc2s = s_inv_bc2s;
+  const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
+  float *P = t.p[k], *M = t.m[k], *V = t.v[k];
+  const float *G = t.g[k];
+  const int64_t n = t.numel[k], base = chunk * kAdamChunk;
+  if (((t.vec_ok >> k) & 1u) && base + kAdamChunk <= n) {
+    float4 p[4], g[4], m[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t e = base + (int64_t)(u * kBlock + threadIdx.x) * 4;
+      p[u] = ld4(P + e); g[u] = ld4(G + e); m[u] = ld4(M + e); v[u] = ld4(V + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      adam_dense1(p[u].x, g[u].x, m[u].x, v[u].x, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
+      adam_dense1(p[u].y, g[u].y, m[u].y, v[u].y, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
+      adam_dense1(p[u].z, g[u].z, m[u].z, v[u].z, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
+      adam_dense1(p[u].w, g[u].w, m[u].w, v[u].w, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
+      const int64_t e = base + (int64_t)(u * kBlock + threadIdx.x) * 4;
+      st4(P + e, p[u]); st4(M + e, m[u]); st4(V + e, v[u]);
+    }
+  } else {                                         // a tensor's last chunk, or unaligned views
+    for (int64_t e = base + threadIdx.x; e < n && e < base + kAdamChunk; e += kBlock) {
+      float p = P[e], m = M[e], v = V[e];
+      adam_dense1(p, G[e], m, v, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+}
+
+__global__ void k_adam_steps_inc(AdamDenseTable t) {
+  if ((int)threadIdx.x < t.count) t.step[threadIdx.x][0] += 1.f;
+}
+
 // W[idx[i], :] += alpha * g[i, :]   (row-sparse SGD: linear, so duplicates need no coalescing)
 __global__ __launch_bounds__(kBlock) void k_scatter_axpy(const int64_t *__restrict__ idx, const float *__restrict__ g,
                                                          float alpha, float *__restrict__ W, int64_t n, int D,
@@ -196,12 +270,13 @@ extern "C" {
 
 int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *W,
                           float *exp_avg, float *exp_avg_sq, float *acc, int64_t n, int32_t D, int64_t N,
-                          float step_size, const float *step_size_dev, float beta1, float beta2, float eps,
+                          float step_size, const float *step_size_dev, double beta1, double beta2, float eps,
                           void *stream) {
   if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
   if (!rows_sorted || !perm || !vals || !W || !exp_avg || !exp_avg_sq || !acc) return MI_ERR_INVALID_ARG;
-  AdamArgs a{rows_sorted, perm, vals, W, exp_avg, exp_avg_sq, acc, n, N, step_size, beta1, beta2, eps, step_size_dev};
+  AdamArgs a{rows_sorted, perm, vals, W, exp_avg, exp_avg_sq, acc, n, N, step_size, (float)(1.0 - beta1), (float)(1.0 - beta2),
+             eps, step_size_dev};
 #define CALL(LPR, VW)                                                                        \
   do {                                                                                       \
     const int grid = grid_for_waves((n + (kWave / LPR) - 1) / (kWave / LPR));                \
@@ -233,6 +308,35 @@ int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const
 int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2, void *stream) {
   if (!step || !step_size) return MI_ERR_INVALID_ARG;
   MI_LAUNCH("adam_tick", k_adam_tick, 1, 1, stream, step, step_size, lr, beta1, beta2);
+  return launch_status();
+}
+
+int mi_adam_dense_multi(float *const *params, const float *const *grads, float *const *exp_avgs,
+                        float *const *exp_avg_sqs, float *const *steps, const int64_t *numels, int32_t count, float lr,
+                        double beta1, double beta2, float eps, float weight_decay, void *stream) {
+  if (count < 0) return MI_ERR_INVALID_ARG;
+  if (count == 0) return MI_OK;
+  if (!params || !grads || !exp_avgs || !exp_avg_sqs || !steps || !numels) return MI_ERR_INVALID_ARG;
+  for (int32_t first = 0; first < count; first += kAdamTensors) {
+    AdamDenseTable t{};
+    int64_t chunks = 0;
+    for (int32_t i = first; i < count && t.count < kAdamTensors; ++i) {
+      if (numels[i] < 0) return MI_ERR_INVALID_ARG;
+      if (numels[i] == 0) continue;
+      if (!params[i] || !grads[i] || !exp_avgs[i] || !exp_avg_sqs[i] || !steps[i]) return MI_ERR_INVALID_ARG;
+      const int k = t.count++;
+      t.p[k] = params[i]; t.g[k] = grads[i]; t.m[k] = exp_avgs[i]; t.v[k] = exp_avg_sqs[i]; t.step[k] = steps[i];
+      t.numel[k] = numels[i];
+      chunks += (numels[i] + kAdamChunk - 1) / kAdamChunk;
+      t.chunk_end[k] = chunks;
+      if (aligned16(params[i]) && aligned16(grads[i]) && aligned16(exp_avgs[i]) && aligned16(exp_avg_sqs[i]))
+        t.vec_ok |= 1u << k;
+    }
+    if (t.count == 0) continue;
+    if (chunks > 0x7fffffff) return MI_ERR_UNSUPPORTED;
+    MI_LAUNCH("adam_dense", k_adam_dense, (int)chunks, kBlock, stream, t, lr, beta1, beta2, eps, weight_decay);
+    MI_LAUNCH("adam_steps_inc", k_adam_steps_inc, 1, kWave, stream, t);
+  }
   return launch_status();
 }
 

@@ -7,6 +7,7 @@ lookup kernels emit directly: one torch.sort of the row ids (no host sync) + ONE
 `p[rows] -= lr * g` as float-atomic adds (linear, so duplicates need no coalescing).
 `get_optimizers(model, config)` mirrors src/models/deepfm.py:155-219.
 """
+import ctypes
 import math
 from typing import Dict, List
 
@@ -119,14 +120,61 @@ class SparseSGD(torch.optim.Optimizer):
         return loss
 
 
+class Adam(torch.optim.Adam):
+    """torch.optim.Adam (same constructor, param_groups and state_dict: it IS a torch.optim.Adam with `capturable=True`,
+    i.e. device-side step counts) whose step over fp32 GPU parameters is mi_adam_dense_multi: one launch per 12 tensors,
+    one read and one write of p, m, v.  At the headline model: the 574 M-parameter dense config 12.5 ms (torch's default
+    multi-pass implementation) / 3.8 ms (torch `fused=True`) -> see DESIGN.md §5; the MLP's 0.5 M parameters 42 us
+    (torch fused, 8 workgroups) -> one 5 us launch.  Options the kernel does not implement (amsgrad, maximize, decoupled
+    weight decay, gradient scaling, non-fp32 or CPU parameters) take torch's own step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kwargs):
+        kwargs.setdefault("capturable", True)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
+
+    def _kernel_ok(self, group) -> bool:
+        if group["amsgrad"] or group["maximize"] or group.get("decoupled_weight_decay", False) or group["differentiable"]:
+            return False
+        if not group["capturable"] or getattr(self, "grad_scale", None) is not None:
+            return False
+        if isinstance(group["lr"], torch.Tensor) or any(isinstance(b, torch.Tensor) for b in group["betas"]):
+            return False
+        return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in group["params"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not all(self._kernel_ok(g) for g in self.param_groups):
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
+            self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)   # torch's own state layout
+            if not params:
+                continue
+            dev = _lib.require_gpu(*params)
+            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+            n = len(params)
+            arr = ctypes.c_void_p * n
+            beta1, beta2 = group["betas"]
+            _lib.check(lib.mi_adam_dense_multi(arr(*[t.data_ptr() for t in params]), arr(*[t.data_ptr() for t in grads]),
+                                               arr(*[t.data_ptr() for t in exp_avgs]),
+                                               arr(*[t.data_ptr() for t in exp_avg_sqs]),
+                                               arr(*[t.data_ptr() for t in steps]),
+                                               (ctypes.c_int64 * n)(*[t.numel() for t in params]), n, group["lr"], beta1,
+                                               beta2, group["eps"], group["weight_decay"], _lib.stream_ptr(dev)),
+                       "mi_adam_dense_multi")
+        return loss
+
+
 def _dense_adam(params, lr, weight_decay):
-    """torch.optim.Adam with the reference's arguments.  For parameters on the GPU it is torch's single-pass multi-tensor
-    implementation (`fused=True`: same update, one read and one write of p, m, v per step instead of the default
-    implementation's several passes — 11.6 -> 3.8 ms over the 574 M parameters of the headline model) with a device-side
-    step count (`capturable=True`), so that a whole training step can be replayed as a hipGraph."""
-    on_gpu = len(params) > 0 and all(p.is_cuda and p.is_floating_point() for p in params)
-    if on_gpu:
-        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
+    """The reference's `torch.optim.Adam(params, lr=..., weight_decay=...)`: on the GPU the subclass above (device-side
+    step counts, so that a whole training step can be replayed as a hipGraph), otherwise torch's own."""
+    if len(params) > 0 and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        return Adam(params, lr=lr, weight_decay=weight_decay)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
 
 

@@ -7,7 +7,7 @@ import torch
 from conftest import assert_close
 
 import recsys_benchmark_amd as pkg
-from recsys_benchmark_amd.optim import SparseAdam, SparseSGD, get_optimizers, sort_rows
+from recsys_benchmark_amd.optim import Adam, SparseAdam, SparseSGD, get_optimizers, sort_rows
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -124,3 +124,44 @@ def test_sparse_sgd_and_factory_end_to_end():
     assert_close(W, W0 - 0.1 * W.grad.to_dense(), 1e-5, 1e-5)
     cfg2 = {"sparse": True, "optimizer": "sgd", "learning_rate": 1e-2, "weight_decay": 0.0}
     assert isinstance(get_optimizers(model, cfg2)[0], SparseSGD)
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 1e-3])
+def test_dense_adam_matches_torch_adam(weight_decay):
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(1,), (5,), (4096,), (4097,), (400, 416), (16, 3, 7), (100003,)] + [(33,)] * 9       # 16 tensors: two launches
+    ref = [torch.nn.Parameter(torch.randn(*sh, generator=gen)) for sh in shapes]
+    flat = torch.zeros(50, device=DEV)
+    mine = [torch.nn.Parameter(t.detach().clone().to(DEV)) for t in ref]
+    oref = torch.optim.Adam(ref, lr=1e-2, weight_decay=weight_decay)
+    omine = Adam(mine, lr=1e-2, weight_decay=weight_decay)
+    assert isinstance(omine, torch.optim.Adam) and omine.state_dict()["param_groups"][0].keys() == \
+        torch.optim.Adam(mine, capturable=True).state_dict()["param_groups"][0].keys()
+    for step in range(5):
+        for a, b in zip(ref, mine):
+            g = torch.randn(a.shape, generator=gen) * (10.0 ** (step - 2))
+            a.grad = g
+            b.grad = g.to(DEV) if step != 3 or a.numel() != 5 else None     # a parameter may sit a step out
+            if b.grad is None:
+                a.grad = None
+        oref.step()
+        omine.step()
+    # same arithmetic in fp32; torch divides where the kernel multiplies by a reciprocal: 1 ulp
+    for a, b in zip(ref, mine):
+        assert_close(b, a, 2e-6, 1e-7, f"param {tuple(a.shape)}")
+        assert_close(omine.state[b]["exp_avg_sq"], oref.state[a]["exp_avg_sq"], 2e-6, 1e-12, "exp_avg_sq")
+        assert float(omine.state[b]["step"]) == float(oref.state[a]["step"])
+    # unaligned views (the sharded model's flat gradient buffer) take the scalar route
+    p = torch.nn.Parameter(torch.randn(1001, generator=gen).to(DEV))
+    q = torch.nn.Parameter(p.detach().clone().cpu())
+    o1, o2 = Adam([p], lr=1e-3), torch.optim.Adam([q], lr=1e-3)
+    buf = torch.randn(1002, generator=gen)
+    p.grad, q.grad = buf.to(DEV)[1:], buf[1:].clone()
+    o1.step(), o2.step()
+    assert_close(p, q, 2e-6, 1e-7, "unaligned gradient view")
+    # options outside the kernel fall through to torch's implementation
+    r = torch.nn.Parameter(torch.ones(10, device=DEV))
+    o3 = Adam([r], lr=1e-1, amsgrad=True)
+    r.grad = torch.ones(10, device=DEV)
+    o3.step()
+    assert_close(r, torch.full((10,), 0.9), 1e-5, 1e-6, "amsgrad fallback")

@@ -88,7 +88,9 @@ def test_train_epoch_matches_a_hand_written_loop_and_learns():
         for o in ropts:
             o.step()
         total += loss.item()
-    assert abs(first["loss"] - total / len(data)) < 1e-5
+    # seven Adam steps apart the two runs differ by the float-atomics noise Adam amplifies (see the test above): 2e-4 on a
+    # mean loss of ~0.7; a skipped, repeated or stale batch would move it by 1e-2
+    assert abs(first["loss"] - total / len(data)) < 2e-4
     later = [trainer.train_epoch(data, model, opts, device=DEV, log_step=0, step=step)["loss"] for _ in range(15)][-1]
     assert later < first["loss"] * 0.8, (first, later)
 
