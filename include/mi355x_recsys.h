@@ -418,11 +418,14 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
 /* mi_sort_field_rows: rows int64[B,F] with rows[b,f] in [offsets[f], offsets[f+1]) (offsets ascending, offsets[F] := N —
  *   the ids DeepFM forms at src/models/deepfm.py:88).  rows_sorted[B*F] ascending and perm[i] = flat position b*F+f of
  *   the i-th smallest, equal ids in ascending b (a stable sort); an id outside its field's range comes back as N behind
- *   its field's valid ids.  One workgroup per field sorts its column in LDS.  B <= 8192, N < 2^32-2, else
+ *   its field's valid ids.  Every column is cut into runs of 1024 ids sorted by one workgroup each, then merged by
+ *   rank; workspace: mi_sort_field_rows_workspace_bytes(B, F) bytes (0 when B <= 1024).  B <= 65536, N < 2^32-2, else
  *   MI_ERR_UNSUPPORTED (the caller sorts generically).
  */
+MI_API int64_t mi_sort_field_rows_workspace_bytes(int64_t B, int32_t F);
 MI_API int mi_sort_field_rows(const int64_t *rows, const int64_t *offsets, int64_t N, int64_t B,
-                              int32_t F, int64_t *rows_sorted, int64_t *perm, void *stream);
+                              int32_t F, int64_t *rows_sorted, int64_t *perm, void *workspace,
+                              void *stream);
 MI_API int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2,
                         void *stream);
 /* mi_adam_dense_multi: torch.optim.Adam (L2 weight decay, no amsgrad) over `count` dense fp32 tensors in as few launches as

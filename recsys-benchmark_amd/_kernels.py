@@ -56,11 +56,14 @@ def sort_field_rows(rows_flat: torch.Tensor, N: int):
         return None
     rows, offsets, n_rows = entry
     B, F = rows.shape
-    if rows_flat.numel() != B * F or n_rows != N or B > 8192 or N >= 2**32 - 2 or B == 0:
+    if rows_flat.numel() != B * F or n_rows != N or B > 65536 or N >= 2**32 - 2 or B == 0:
         return None
+    lib = _lib.load()
     rows_sorted, perm = torch.empty_like(rows_flat), torch.empty_like(rows_flat)
-    _lib.check(_lib.load().mi_sort_field_rows(rows.data_ptr(), offsets.data_ptr(), N, B, F, rows_sorted.data_ptr(),
-                                              perm.data_ptr(), _lib.stream_ptr(rows.device)), "mi_sort_field_rows")
+    nbytes = int(lib.mi_sort_field_rows_workspace_bytes(B, F))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=rows.device) if nbytes else None
+    _lib.check(lib.mi_sort_field_rows(rows.data_ptr(), offsets.data_ptr(), N, B, F, rows_sorted.data_ptr(),
+                                      perm.data_ptr(), _lib.ptr(ws), _lib.stream_ptr(rows.device)), "mi_sort_field_rows")
     return rows_sorted, perm
 
 

@@ -56,7 +56,8 @@ SIGNATURES = {
                                _p],
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
                               ctypes.c_double, ctypes.c_float, _p],
-    "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p],
+    "mi_sort_field_rows_workspace_bytes": [_i64, _i32],
+    "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p],
     "mi_adam_dense_multi": [_p, _p, _p, _p, _p, _p, _i32, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_float,
                             ctypes.c_float, _p],
     "mi_adam_tick": [_p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p],
@@ -94,7 +95,8 @@ SIGNATURES = {
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
 _RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
-             "mi_bpr_workspace_elems": ctypes.c_int64, "mi_lse_diag_workspace_elems": ctypes.c_int64}
+             "mi_bpr_workspace_elems": ctypes.c_int64, "mi_lse_diag_workspace_elems": ctypes.c_int64,
+             "mi_sort_field_rows_workspace_bytes": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()

@@ -39,7 +39,7 @@ def test_sparse_adam_matches_torch(N, D, n):
 
 
 @pytest.mark.parametrize("B,dims", [(1, [7]), (5, [3, 1, 9]), (1000, [2, 50, 100000]), (4096, [1460, 583, 10131227, 3, 24]),
-                                    (8192, [40, 5]), (4097, [1, 1, 300])])
+                                    (8192, [40, 5]), (4097, [1, 1, 300]), (1024, [9, 2000]), (1025, [9, 2000]), (20000, [5, 100000])])
 def test_field_sort_is_a_stable_sort_of_the_batch_ids(B, dims):
     from recsys_benchmark_amd import _kernels
 
