@@ -423,3 +423,20 @@ def optembed_weight(weight, t_param, field_dims, mode_threshold_e: str, mask_d_i
         m = mask_d_idx if mode_threshold_d == "feature" else torch.repeat_interleave(mask_d_idx, fd, dim=0, output_size=N)
         emb = emb * F.embedding(m, torch.tril(torch.ones((D, D), dtype=torch.bool))).to(weight)
     return emb
+
+
+def ndcg_recall(y_pred, y_true, k: int = 20):
+    """src/metrics.py:70-108 (get_ndcg_recall; get_ndcg :9-43 is its first component): per user, hits among the first k
+    recommendations weighted 1/log2(rank+1) over the ideal DCG of min(len(true), k) hits; recall over the same count."""
+    import math
+
+    ndcg = recall = 0.0
+    for pred_user, true_user in zip(y_pred, y_true):
+        true_user = set(int(t) for t in true_user)
+        hits = [1.0 if int(p) in true_user else 0.0 for p in list(pred_user)[:k]]
+        dcg = sum(h / math.log2(r + 2) for r, h in enumerate(hits))
+        length = min(len(true_user), k)
+        idcg = sum(1.0 / math.log2(r + 2) for r in range(length))
+        ndcg += dcg / idcg
+        recall += sum(hits) / length
+    return ndcg / len(y_pred), recall / len(y_pred)

@@ -1,10 +1,11 @@
-"""The CTR training / validation loops around the hot path (reference: src/trainer/deepfm.py:17-139), with the per-batch
-work — forward, BCE-with-logits, backward, every optimizer step — replayed as ONE hipGraph.
+"""The training / validation loops around the hot path — CTR (reference: src/trainer/deepfm.py:17-139) and LightGCN
+(src/trainer/lightgcn.py:14-165, 378-421) — with the per-batch work — forward, loss, backward, every optimizer step —
+replayed as ONE hipGraph.
 
 At the headline shape the eager step is bound by the host (≈0.85 ms of Python / autograd / launch work around ≈0.45 ms of
 kernels); a captured step has no host work beyond two input copies and one graph launch.  What makes the whole step
 capturable: the lookup kernels emit row-form gradients without host syncs, `optim.SparseAdam(capturable=True)` keeps its
-step count on the device, torch's Adam runs fused + capturable (`optim.get_optimizers` builds both that way on a GPU),
+step count on the device, `optim.Adam` steps from device-side counts too (`optim.get_optimizers` builds both on a GPU),
 dropout seeds and BatchNorm counters advance inside kernels.
 
 `train_epoch` / `validate_epoch` keep the reference's signatures and return values; the loss is accumulated on the device
@@ -13,11 +14,12 @@ and read back at the logging steps only (the reference calls `.item()` every bat
 import datetime
 import logging
 import warnings
-from typing import Dict, List, Optional, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 
 from . import losses
+from .lightgcn import score_topk, train_items_csr
 
 logger = logging.getLogger("recsys_benchmark_amd.trainer")
 now = datetime.datetime.now
@@ -164,3 +166,146 @@ def validate_epoch(val_loader, model, device="cuda") -> Dict[str, float]:
         y_pred.append(torch.sigmoid(outputs).reshape(-1))
     y_true, y_pred = torch.cat(y_true), torch.cat(y_pred)
     return {"auc": binary_auc(y_true, y_pred), "log_loss": float(log_loss) / y_pred.numel()}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# collaborative filtering (LightGCN): reference src/trainer/lightgcn.py:14-165, 378-421
+class GraphedCFTrainStep:
+    """step(users, pos_items, neg_items): one LightGCN optimisation step as the reference's `_train_step` does it —
+    propagate, BPR over the batch rows, `weight_decay * get_reg_loss`, optional InfoNCE on the batch's distinct rows,
+    zero_grad, backward, optimizer step — replayed as one hipGraph for the batch size seen first (other sizes, and
+    `info_nce_weight > 0`, whose `torch.unique` has a data-dependent shape, run eagerly on the same kernels).
+
+    `sums` (device tensor [4]) accumulates loss, rec_loss, reg_loss, cl_loss; `steps` counts the calls."""
+
+    def __init__(self, model, adj, optimizer, weight_decay: float = 0, info_nce_weight: float = 0, warmup: int = 2,
+                 use_graph: bool = True):
+        self.model, self.adj, self.optimizer = model, adj, optimizer
+        self.weight_decay, self.info_nce_weight = weight_decay, info_nce_weight
+        self.warmup = warmup
+        self.use_graph = use_graph and not info_nce_weight
+        self.steps = 0
+        self.sums: Optional[torch.Tensor] = None
+        self._graph, self._static, self._shape, self._seen = None, None, None, 0
+
+    def _body(self, users, pos_items, neg_items):
+        all_user_emb, all_item_emb = self.model(self.adj)
+        rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items)
+        zero = torch.zeros((), device=rec_loss.device)
+        reg_loss = self.model.get_reg_loss(users, pos_items, neg_items) if self.weight_decay > 0 else zero
+        cl_loss = zero
+        if self.info_nce_weight > 0:           # SGL without augmentation (src/trainer/lightgcn.py:405-417)
+            view = torch.cat([torch.index_select(all_user_emb, 0, torch.unique(users)),
+                              torch.index_select(all_item_emb, 0, torch.unique(pos_items))], 0)
+            cl_loss = losses.info_nce(view, view, 0.2) * self.info_nce_weight
+        loss = rec_loss + self.weight_decay * reg_loss + cl_loss
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        parts = torch.stack([loss.detach(), rec_loss.detach(), reg_loss.detach(), cl_loss.detach()])
+        self.sums += parts
+        return parts
+
+    def __call__(self, users, pos_items, neg_items) -> torch.Tensor:
+        if self.sums is None:
+            self.sums = torch.zeros(4, dtype=torch.float32, device=users.device)
+        self.steps += 1
+        shape = (tuple(users.shape), users.dtype)
+        if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:
+            try:
+                static = (users.clone(), pos_items.clone(), neg_items.clone())
+                self.optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    parts = self._body(*static)
+                self._graph, self._static = graph, static + (parts,)
+            except Exception as exc:
+                warnings.warn(f"hipGraph capture of the LightGCN step failed ({exc!r}); continuing with eager steps")
+                torch.cuda.synchronize()
+                self.use_graph, self._graph = False, None
+        if self._graph is not None and self._shape == shape:
+            for dst, src in zip(self._static[:3], (users, pos_items, neg_items)):
+                dst.copy_(src, non_blocking=True)
+            self._graph.replay()
+            return self._static[3]
+        if self._graph is None:
+            if self._shape != shape:
+                self._shape, self._seen = shape, 0
+            self._seen += 1
+        return self._body(users, pos_items, neg_items)
+
+
+def train_epoch_cf(dataloader, model, optimizer, device="cuda", log_step=10, weight_decay=0, profiler=None,
+                   info_nce_weight=0, step: Optional[GraphedCFTrainStep] = None) -> Dict[str, float]:
+    """src/trainer/lightgcn.py:14-77 (`train_epoch`): {"loss", "reg_loss", "rec_loss", "cl_loss"} averaged over the
+    batches.  `dataloader.dataset.get_norm_adj()` supplies the normalised adjacency, as in the reference."""
+    model.train()
+    model.to(device)
+    if step is None:
+        adj = dataloader.dataset.get_norm_adj().to(device)
+        step = GraphedCFTrainStep(model, adj, optimizer, weight_decay, info_nce_weight)
+    first_steps = step.steps
+    first = step.sums.clone() if step.sums is not None else None
+    idx = -1
+    for idx, (users, pos_items, neg_items) in enumerate(dataloader):
+        step(users.to(device, non_blocking=True), pos_items.to(device, non_blocking=True),
+             neg_items.to(device, non_blocking=True))
+        if log_step and idx % log_step == 0:
+            done = (step.sums - first if first is not None else step.sums) / (idx + 1)
+            logger.info("Idx: %d - loss: %.2g - rec_loss: %.2g", idx, float(done[0]), float(done[1]))
+        if profiler:
+            profiler.step()
+    n = step.steps - first_steps
+    total = (step.sums - first if first is not None else step.sums) if n else torch.zeros(4)
+    avg = (total / max(n, 1)).tolist()
+    return {"loss": avg[0], "rec_loss": avg[1], "reg_loss": avg[2], "cl_loss": avg[3]}
+
+
+def ndcg_recall_at_k(y_pred: torch.Tensor, y_true: Sequence[Union[Sequence[int], set]], k: int = 20) -> Tuple[float, float]:
+    """src/metrics.py:9-43, 70-108 (`get_ndcg`, `get_ndcg_recall`) for a [users, >=k] tensor of recommended item ids:
+    the relevance test is one broadcast comparison against the padded true-item lists on y_pred's device, float64."""
+    dev = y_pred.device
+    n = len(y_true)
+    if n == 0 or y_pred.shape[0] != n:
+        raise ValueError("y_pred must hold one row of recommendations per entry of y_true")
+    lens = torch.tensor([len(t) for t in y_true], dtype=torch.int64)
+    width = max(int(lens.max()), 1)
+    padded = torch.full((n, width), -1, dtype=torch.int64)
+    for i, t in enumerate(y_true):
+        if len(t):
+            padded[i, :len(t)] = torch.as_tensor(sorted(t) if isinstance(t, (set, frozenset)) else list(t), dtype=torch.int64)
+    padded, lens = padded.to(dev), lens.to(dev)
+    pred = y_pred[:, :k]
+    relevant = (pred.unsqueeze(2) == padded.unsqueeze(1)).any(2).to(torch.float64)          # [n, k]
+    weight = 1.0 / torch.log2(torch.arange(2, pred.shape[1] + 2, dtype=torch.float64, device=dev))
+    dcg = (relevant * weight).sum(1)
+    length = torch.clamp(lens, max=k)
+    ideal = torch.cumsum(1.0 / torch.log2(torch.arange(2, k + 2, dtype=torch.float64, device=dev)), 0)
+    idcg = ideal[(length - 1).clamp(min=0)]
+    ndcg = (dcg / idcg).mean()
+    recall = (relevant.sum(1) / length.to(torch.float64)).mean()
+    return float(ndcg), float(recall)
+
+
+@torch.no_grad()
+def validate_epoch_cf(train_dataset, val_loader, model, device="cuda", k=20, filter_item_on_train=True, profiler=None,
+                      metrics: Optional[List[str]] = None) -> Dict[str, float]:
+    """src/trainer/lightgcn.py:80-165 (`validate_epoch`): {"ndcg"} or {"ndcg", "recall"}.  Scores, the train-item mask
+    (a CSR of `train_dataset.get_graph()` built once, not a Python loop per batch) and the top-k run in `score_topk`;
+    the recommendations stay on the device until the metric."""
+    adj = train_dataset.get_norm_adj().to(device)
+    graph = train_dataset.get_graph()
+    model.eval()
+    model = model.to(device)
+    user_embs, item_embs = model(adj)
+    csr = train_items_csr(graph, user_embs.shape[0], device) if filter_item_on_train else None
+    preds, truths = [], []
+    for users, pos_items in val_loader:
+        preds.append(score_topk(user_embs, item_embs, torch.as_tensor(users).to(device), k, csr))
+        truths.extend(pos_items)
+        if profiler:
+            profiler.step()
+    ndcg, recall = ndcg_recall_at_k(torch.cat(preds), truths, k)
+    if metrics is not None and "ndcg" in metrics and "recall" in metrics:
+        return {"ndcg": ndcg, "recall": recall}
+    return {"ndcg": ndcg}

@@ -506,9 +506,29 @@ def gen_losses():
     save("losses", **arrays)
 
 
+# ------------------------------------------------------------------ G10: ranking metrics of the LightGCN validation
+def gen_metrics():
+    from src import metrics as ref_metrics
+
+    gen = torch.Generator().manual_seed(37)
+    n, k, num_item = 50, 20, 400
+    pred = torch.stack([torch.randperm(num_item, generator=gen)[:k] for _ in range(n)])
+    lens = torch.randint(1, 45, (n,), generator=gen)
+    true = [torch.randperm(num_item, generator=gen)[:int(m)].tolist() for m in lens]
+    true[3] = pred[3, :5].tolist()                      # a user whose whole test set is recommended
+    true_pad = torch.full((n, int(lens.max())), -1, dtype=torch.int64)
+    for i, t in enumerate(true):
+        true_pad[i, :len(t)] = torch.tensor(t)
+    ndcg, recall = ref_metrics.get_ndcg_recall(pred.tolist(), [set(t) for t in true], k)
+    ndcg_only = ref_metrics.get_ndcg(pred.tolist(), true, k)
+    ndcg10, recall10 = ref_metrics.get_ndcg_recall(pred.tolist(), true, 10)
+    save("metrics", pred=pred, true_pad=true_pad, k=np.array(k), ndcg=np.array(ndcg), recall=np.array(recall),
+         ndcg_only=np.array(ndcg_only), ndcg10=np.array(ndcg10), recall10=np.array(recall10))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned", "losses"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned", "losses", "metrics"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

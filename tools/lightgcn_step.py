@@ -65,6 +65,15 @@ def main():
     print(f"[product] eager {t_eager:.0f} us/step, hipGraph replay {t_graph:.0f} us/step ({B / t_graph:.2f} M triples/s); "
           f"loss {float(loss):.4f}, |grad|_1 {gn:.3e}")
 
+    # the whole _train_step (zero_grad + Adam included) as trainer.GraphedCFTrainStep replays it
+    from recsys_benchmark_amd import optim, trainer
+    for nce in (0.0, 0.1):
+        m2 = LightGCN(U, I, num_layers=L, hidden_size=D).to(dev).train()
+        tstep = trainer.GraphedCFTrainStep(m2, adj, optim.Adam(m2.parameters(), lr=1e-3), weight_decay=1e-4, info_nce_weight=nce)
+        t_train = wall(lambda: tstep(users, pos, neg))
+        print(f"[product, whole step with Adam, info_nce_weight={nce}] {t_train:.0f} us/step = {B / t_train:.2f} M triples/s "
+              f"({'one hipGraph' if tstep._graph is not None else 'eager: torch.unique has a data-dependent shape'})")
+
     # the same step in stock torch ops (reference op sequence on the GPU)
     Eu = model.user_emb_table.get_weight().detach().clone().requires_grad_(True)
     Ei = model.item_emb_table.get_weight().detach().clone().requires_grad_(True)
