@@ -185,6 +185,24 @@ class ShardedDeepFM(nn.Module):
             flat /= self.world
         torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
+    def get_optimizers(self, config):
+        """The optimizers `get_optimizers` (src/models/deepfm.py:155-219) builds for its `sparse: True` configs, for this
+        model: the row-sparse step on the two table shards (their gradients arrive in row form, already averaged over
+        the global batch), the dense step on the replicated tail (whose gradients are all-reduced, so every rank takes
+        the same step and the replicas stay identical)."""
+        from . import optim
+
+        name = config.get("optimizer", "adam")
+        lr_emb = config.get("learning_rate_emb", config["learning_rate"])
+        shards = [self.embedding_shard, self.fc_shard]
+        if name == "adam":
+            return [optim.SparseAdam(shards, lr=lr_emb, capturable=True),
+                    optim.Adam(self.dense_parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"])]
+        if name == "sgd":
+            return [optim.SparseSGD(shards, lr=lr_emb),
+                    torch.optim.SGD(self.dense_parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"])]
+        raise ValueError(f"optimizer_name={name!r} is not recognized")
+
     def check_overflow(self):
         """Synchronise; raise if any fixed-capacity bucket overflowed since the last check."""
         if bool(self.bucket_overflow.item()):

@@ -57,6 +57,51 @@ def test_sharded_world1_equals_unsharded(one_rank_group):
     pkg.check_index_errors()
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphed):
+    """Same batches, same optimizers: after several steps the shards hold the unsharded model's tables."""
+    from recsys_benchmark_amd.optim import get_optimizers
+
+    torch.manual_seed(4)
+    dims, D, B = [50, 7, 1000, 3], 16, 64
+    dev = torch.device("cuda", 0)
+    ref = pkg.DeepFM(dims, D, [32, 16], p_dropout=0.0, use_batchnorm=True,
+                     embedding_config={"name": "vanilla", "sparse": True}, fc_sparse=True).to(dev)
+    sh = ShardedDeepFM(dims, D, [32, 16], p_dropout=0.0, use_batchnorm=True, device=dev)
+    sh.load_full_tables(ref.embedding.get_weight().data, ref.fc.weight.data)
+    sh._deep_branch.load_state_dict(ref._deep_branch.state_dict())
+    cfg = {"sparse": True, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    ropts, sopts = get_optimizers(ref, cfg), sh.get_optimizers(cfg)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    gstep = sh.make_graphed_step(lossf, B) if graphed else None
+    gen = torch.Generator().manual_seed(5)
+    for _ in range(6):
+        x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1).to(dev)
+        y = (torch.rand(B, generator=gen) < 0.3).float().to(dev)
+        for o in ropts:
+            o.zero_grad()
+        lossf(ref(x), y).backward()
+        for o in ropts:
+            o.step()
+        if graphed:
+            gstep(x, y)
+        else:
+            for o in sopts:
+                o.zero_grad()
+            lossf(sh(x), y).backward()
+            sh.allreduce_dense_grads()
+        for o in sopts:
+            o.step()
+    N = sum(dims)
+    # six Adam steps apart: the usual amplification of last-bit differences where a gradient is almost zero
+    assert_close(sh.embedding_shard[:N], ref.embedding.get_weight(), 1e-3, 2e-5, "table")
+    assert_close(sh.fc_shard[:N], ref.fc.weight, 1e-3, 2e-5, "first-order table")
+    assert not sh.embedding_shard[N].any() and not sh.fc_shard[N].any(), "the sink row moved"
+    for (k, p), (_, q) in zip(sh._deep_branch.named_parameters(), ref._deep_branch.named_parameters()):
+        assert_close(p, q, 1e-3, 2e-5, k)
+    pkg.check_index_errors()
+
+
 def test_graphed_local_compute_matches_eager():
     """Isolated child process (see tests/_graphed_sharded_check.py for why)."""
     import subprocess
