@@ -88,14 +88,13 @@ class CerpEmbedding(IEmbedding):
         assert bool(((pattern >= 0) & (pattern <= 1)).all())
         return nn.Parameter(init * pattern)
 
+    def _pruned_tables(self):
+        soft = lambda w, t: torch.sign(w) * torch.relu(torch.abs(w) - torch.sigmoid(t))   # noqa: E731
+        return soft(self.q_weight, self.q_threshold), soft(self.p_weight, self.p_threshold)
+
     def apply_pruning(self):
         """Materialised pruned tables, for the bookkeeping helpers only (the lookup fuses this)."""
-        self.sparse_q_weight = torch.sign(self.q_weight) * torch.relu(
-            torch.abs(self.q_weight) - torch.sigmoid(self.q_threshold)
-        )
-        self.sparse_p_weight = torch.sign(self.p_weight) * torch.relu(
-            torch.abs(self.p_weight) - torch.sigmoid(self.p_threshold)
-        )
+        self.sparse_q_weight, self.sparse_p_weight = self._pruned_tables()
 
     def forward(self, x):
         emb = _kernels.dual_gather(
@@ -125,9 +124,11 @@ class CerpEmbedding(IEmbedding):
         return n_params
 
     def get_prune_loss(self, K=100):
-        self.apply_pruning()
-        emb = self.sparse_p_weight + self.sparse_q_weight
-        return -torch.tanh(emb * K).norm(2) ** 2
+        # same value as the reference's (cerp_embedding.py get_prune_loss); the pruned tables are NOT stashed on the module
+        # here: a tensor with autograd history that outlives a hipGraph capture on a module attribute crashes torch's
+        # capture_end, and this loss is part of the captured training step (trainer.train_epoch_cerp)
+        q, p = self._pruned_tables()
+        return -torch.tanh((p + q) * K).norm(2) ** 2
 
 
 class RetrainCerpEmbedding(IEmbedding):

@@ -25,6 +25,13 @@ logger = logging.getLogger("recsys_benchmark_amd.trainer")
 now = datetime.datetime.now
 
 
+def _capturable(optimizers) -> bool:
+    """False when an optimizer keeps its step count on the host (torch's Adam family without `capturable=True`): its
+    step() refuses to run under capture, and a capture abandoned half-way is not something to recover from — so this
+    is checked up front.  `optim.get_optimizers` / `optim.Adam` / `optim.SparseAdam(capturable=True)` all qualify."""
+    return all(group.get("capturable", True) for opt in optimizers for group in opt.param_groups)
+
+
 class GraphedTrainStep:
     """step(inputs, labels): one optimisation step of `model` on the batch, in the reference's order (forward, loss,
     zero_grad, backward, optimizer steps).  The first `warmup` calls run eagerly (they are ordinary training steps and
@@ -35,14 +42,23 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model: torch.nn.Module, optimizers, criterion: Optional[torch.nn.Module] = None, warmup: int = 2,
-                 use_graph: bool = True, clip_grad: float = 0):
+                 use_graph: bool = True, clip_grad: float = 0, extra_loss=None, extra_weight: float = 1.0):
+        """extra_loss: optional callable returning a scalar tensor; `extra_weight` times it is added to the criterion
+        before the backward (the CERP trainer's `prune_loss_weight * model.embedding.get_prune_loss()`); `extra_sum`
+        accumulates the unweighted values."""
         self.model = model
+        self.extra_loss, self.extra_weight = extra_loss, extra_weight
+        self.extra_sum: Optional[torch.Tensor] = None
         self.optimizers: List[torch.optim.Optimizer] = optimizers if isinstance(optimizers, list) else [optimizers]
         self.criterion = criterion if criterion is not None else losses.BCEWithLogitsLoss()
         self.warmup = warmup
         self.clip_grad = clip_grad
         # clip_grad_norm_ reads the norm back on some paths and row-form gradients have no dense norm: eager only
         self.use_graph = use_graph and not clip_grad
+        if self.use_graph and not _capturable(self.optimizers):
+            warnings.warn("an optimizer keeps its step count on the host (capturable=False): the training step runs "
+                          "eagerly; build the optimizers with recsys_benchmark_amd.optim.get_optimizers / optim.Adam")
+            self.use_graph = False
         self.steps = 0
         self.loss_sum: Optional[torch.Tensor] = None
         self.last_loss: Optional[torch.Tensor] = None
@@ -54,9 +70,14 @@ class GraphedTrainStep:
     def _body(self, inputs, labels):
         outputs = self.model(inputs)
         loss = self.criterion(outputs, labels.float())
+        total = loss
+        if self.extra_loss is not None:
+            extra = self.extra_loss()
+            total = loss + self.extra_weight * extra
+            self.extra_sum += extra.detach()
         for opt in self.optimizers:
             opt.zero_grad(set_to_none=True)
-        loss.backward()
+        total.backward()
         if self.clip_grad:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
         for opt in self.optimizers:
@@ -79,6 +100,7 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep runs on the GPU: move the batch to the model's device first")
         if self.loss_sum is None:
             self.loss_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
+            self.extra_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
         self.steps += 1
         shape = (tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype)
         if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:
@@ -135,6 +157,40 @@ def train_epoch(dataloader, model, optimizers: Union[List[torch.optim.Optimizer]
     return loss_dict
 
 
+def train_epoch_cerp(dataloader, model, optimizer, device="cuda", log_step=10, profiler=None, clip_grad=0,
+                     target_sparsity=0.8, prune_loss_weight=0, step: Optional[GraphedTrainStep] = None) -> Dict[str, float]:
+    """src/trainer/deepfm.py:142-248: `train_epoch` plus `prune_loss_weight * model.embedding.get_prune_loss()` in the
+    loss, the table's sparsity checked at the logging steps, and an early return (running sums, as in the reference) once
+    it reaches `target_sparsity`.  Returns {"loss", "prune_loss", "log_loss", "sparsity", "num_params"}."""
+    model.train()
+    model.to(device)
+    if step is None:
+        step = GraphedTrainStep(model, optimizer, clip_grad=clip_grad, extra_loss=lambda: model.embedding.get_prune_loss(),
+                                extra_weight=prune_loss_weight)
+    first_steps = step.steps
+    first = (float(step.loss_sum), float(step.extra_sum)) if step.loss_sum is not None else (0.0, 0.0)
+
+    def sums():
+        log_loss, prune = float(step.loss_sum) - first[0], float(step.extra_sum) - first[1]
+        return {"loss": log_loss + prune_loss_weight * prune, "prune_loss": prune, "log_loss": log_loss}
+
+    idx = -1
+    for idx, (inputs, labels) in enumerate(dataloader):
+        step(inputs.to(device, non_blocking=True), labels.to(device, non_blocking=True))
+        if log_step and idx % log_step == 0:
+            sparsity, num_params = model.embedding.get_sparsity(get_n_params=True)
+            running = sums()
+            logger.info("Idx: %d - loss: %.4g - sparsity: %.4g - num_params: %d", idx, running["loss"] / (idx + 1), sparsity,
+                        num_params)
+            if sparsity >= target_sparsity:
+                return dict(running, sparsity=sparsity, num_params=num_params)
+        if profiler:
+            profiler.step()
+    n = max(step.steps - first_steps, 1)
+    sparsity, num_params = model.embedding.get_sparsity(get_n_params=True)
+    return dict({k: v / n for k, v in sums().items()}, sparsity=sparsity, num_params=num_params)
+
+
 def binary_auc(y_true: torch.Tensor, y_score: torch.Tensor) -> float:
     """Area under the ROC curve as sklearn.metrics.roc_auc_score computes it for binary labels (ties share their average
     rank: the Mann-Whitney statistic), on the device in float64."""
@@ -184,6 +240,10 @@ class GraphedCFTrainStep:
         self.weight_decay, self.info_nce_weight = weight_decay, info_nce_weight
         self.warmup = warmup
         self.use_graph = use_graph and not info_nce_weight
+        if self.use_graph and not _capturable([optimizer]):
+            warnings.warn("the optimizer keeps its step count on the host (capturable=False): the LightGCN step runs "
+                          "eagerly; use recsys_benchmark_amd.optim.Adam")
+            self.use_graph = False
         self.steps = 0
         self.sums: Optional[torch.Tensor] = None
         self._graph, self._static, self._shape, self._seen = None, None, None, 0

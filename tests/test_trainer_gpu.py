@@ -207,3 +207,63 @@ def test_cf_validate_epoch_matches_reference_procedure():
     ndcg, recall = ro.ndcg_recall(preds, truths, k)
     assert abs(got["ndcg"] - ndcg) < 1e-9 and abs(got["recall"] - recall) < 1e-9
     assert set(trainer.validate_epoch_cf(ds, val, model, device=DEV, k=k)) == {"ndcg"}
+
+
+def test_train_epoch_cerp_adds_the_prune_loss_and_reports_sparsity():
+    """src/trainer/deepfm.py:142-248 on a CERP table: one-graph steps equal eager steps, the loss is log-loss +
+    weight * prune loss, and the early return fires once the target sparsity is reached."""
+    torch.manual_seed(5)
+    cfg = {"name": "cerp", "bucket_size": 40}
+    model = pkg.DeepFM(DIMS, 16, [32], p_dropout=0.0, use_batchnorm=True, embedding_config=cfg).to(DEV)
+    eager = copy.deepcopy(model)
+    data = _batches(8, 128, 21)
+    w = 1e-4
+    from recsys_benchmark_amd.optim import Adam
+
+    gstep = trainer.GraphedTrainStep(model, Adam(model.parameters(), lr=1e-2), extra_loss=lambda: model.embedding.get_prune_loss(),
+                                     extra_weight=w)
+    got = trainer.train_epoch_cerp(data, model, None, device=DEV, log_step=0, prune_loss_weight=w, step=gstep)
+    assert gstep._graph is not None, "the CERP step was never captured"
+    estep = trainer.GraphedTrainStep(eager, Adam(eager.parameters(), lr=1e-2), use_graph=False,
+                                     extra_loss=lambda: eager.embedding.get_prune_loss(), extra_weight=w)
+    want = trainer.train_epoch_cerp(data, eager, None, device=DEV, log_step=0, prune_loss_weight=w, step=estep)
+    assert set(got) == {"loss", "prune_loss", "log_loss", "sparsity", "num_params"}
+    for key in ("loss", "prune_loss", "log_loss"):
+        assert abs(got[key] - want[key]) < 2e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])
+    assert abs(got["loss"] - (got["log_loss"] + w * got["prune_loss"])) < 1e-5 and got["prune_loss"] < 0
+    assert got["num_params"] == want["num_params"] and 0.0 <= got["sparsity"] < 1.0
+    # target sparsity already met: returns at the first logging step with running sums
+    # (a stock torch optimizer keeps its step count on the host: such a step is never captured, it runs eagerly)
+    with pytest.warns(UserWarning, match="capturable=False"):
+        early = trainer.train_epoch_cerp(data, model, torch.optim.Adam(model.parameters(), lr=1e-2), device=DEV, log_step=1,
+                                         prune_loss_weight=w, target_sparsity=-1.0)
+    assert early["sparsity"] >= -1.0 and early["log_loss"] > 0
+
+
+@pytest.mark.parametrize("emb_cfg", [
+    {"name": "qr", "divider": 5, "operation": "mult"}, {"name": "qr", "divider": 3, "operation": "cat"},
+    {"name": "cerp", "bucket_size": 40}, {"name": "pep", "threshold_type": "feature_dim"}, {"name": "qat", "n_bits": 8},
+    {"name": "tt_emb_torch", "tt_ranks": [4, 4]}, {"name": "dhe", "inp_size": 64, "hidden_sizes": [32]},
+    {"name": "deepfm_optembed", "t_init": 0.0},
+], ids=lambda c: c["name"] + str(c.get("operation", "")))
+def test_every_table_kind_trains_inside_one_graph(emb_cfg, tmp_path):
+    """The step with each compressed table is captured (no host sync, no data-dependent shape anywhere on the path) and
+    replays to the same losses as eager launches of the same kernels."""
+    from recsys_benchmark_amd.optim import Adam
+
+    cfg = dict(emb_cfg)
+    if cfg["name"] == "pep":
+        cfg["checkpoint_weight_dir"] = str(tmp_path)
+    torch.manual_seed(9)
+    model = pkg.DeepFM(DIMS, 16, [32], p_dropout=0.0, use_batchnorm=True, embedding_config=cfg).to(DEV)
+    eager = copy.deepcopy(model)
+    gstep = trainer.GraphedTrainStep(model, Adam(model.parameters(), lr=1e-2))
+    estep = trainer.GraphedTrainStep(eager, Adam(eager.parameters(), lr=1e-2), use_graph=False)
+    draws = cfg["name"] in ("qat", "deepfm_optembed")          # stochastic rounding / sampled masks: own random streams
+    for x, y in _batches(6, 128, 31):
+        gstep(x.to(DEV), y.to(DEV))
+        estep(x.to(DEV), y.to(DEV))
+    assert gstep._graph is not None, "never captured"
+    assert torch.isfinite(gstep.loss_sum)
+    if not draws:
+        assert_close(gstep.loss_sum, estep.loss_sum, 2e-4, 1e-5, "accumulated loss, graph vs eager")
