@@ -386,16 +386,22 @@ MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, 
  *   loss[0] = mean_i (lse[i] - S[i,i]*inv_t).  workspace: mi_lse_diag_workspace_elems(n) floats.
  * mi_lse_diag_bwd: S[i,j] <- g[0]/n * inv_t * (exp(S[i,j]*inv_t - lse[i]) - [i==j])  (in place: the gradient
  *   with respect to the raw scores; the two GEMMs that follow are mi_gemm_f32 calls).
+ *   symmetric != 0 (both views are one matrix): writes dS + dS^T instead, so that the gradient is one product (dS+dS^T) v.
+ *   valid uint8[n] + count fp32[1] (both or neither): rows/columns with valid == 0 are treated as absent and the mean runs
+ *   over count[0] rows — the fixed-shape form of the trainer's torch.unique (src/trainer/lightgcn.py:407-413): the batch's
+ *   rows as they come with repeated ids masked out, so the step has no data-dependent shape and can be captured.
  */
 MI_API int mi_rownorm_fwd(const float *X, int64_t n, int32_t D, float eps, float *Y, float *inv,
                           void *stream);
 MI_API int mi_rownorm_bwd(const float *Y, const float *inv, const float *dY, int64_t n, int32_t D,
                           float eps, float *dX, void *stream);
 MI_API int64_t mi_lse_diag_workspace_elems(int32_t n);
-MI_API int mi_lse_diag_fwd(const float *S, int64_t ld, int32_t n, float inv_t, float *lse,
-                           float *workspace, float *loss, void *stream);
-MI_API int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const float *lse,
-                           const float *g, void *stream);
+MI_API int mi_lse_diag_fwd(const float *S, int64_t ld, int32_t n, float inv_t, const uint8_t *valid,
+                           const float *count, float *lse, float *workspace, float *loss,
+                           void *stream);
+MI_API int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const uint8_t *valid,
+                           const float *count, const float *lse, const float *g, int32_t symmetric,
+                           void *stream);
 
 /* ---- §8f rank 1: fused row-sparse optimizer steps on row-form gradients -------------------
  * Reference: get_optimizers' sparse branch (src/models/deepfm.py:163-184): torch.optim.SparseAdam

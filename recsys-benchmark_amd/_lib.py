@@ -79,8 +79,8 @@ SIGNATURES = {
     "mi_rownorm_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p],
     "mi_rownorm_bwd": [_p, _p, _p, _i64, _i32, ctypes.c_float, _p, _p],
     "mi_lse_diag_workspace_elems": [_i32],
-    "mi_lse_diag_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p, _p],
-    "mi_lse_diag_bwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p],
+    "mi_lse_diag_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p, _p, _p, _p],
+    "mi_lse_diag_bwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p, _p, _i32, _p],
     "mi_qat_gather_fwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _i64, _i32, _i64, _p, _p],
     "mi_qat_gather_bwd": [_p, _p, _p, _i32, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_optembed_fwd": [_p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i64, _p, _p],

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(kBlock) void k_rownorm_bwd(const float *__restrict_
 // running (max, sum of exp(v - max)) pair and its merge
 struct MaxSum { float mx, sum; };
 __device__ __forceinline__ void ms_push(MaxSum &a, float v) {
+  if (v == -INFINITY) return;                      // a masked column
   if (v > a.mx) { a.sum = a.sum * expf(a.mx - v) + 1.f; a.mx = v; }
   else a.sum += expf(v - a.mx);
 }
@@ -57,7 +58,10 @@ __device__ __forceinline__ MaxSum ms_merge(MaxSum a, MaxSum b) {
   return a;
 }
 
+// valid (nullable): rows and columns with valid[i] == 0 do not exist — the fixed-shape stand-in for torch.unique: the
+// batch's rows as they come, duplicates masked out, count[0] = number of valid rows
 __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict__ S, int64_t ld, int n, float inv_t,
+                                                         const uint8_t *__restrict__ valid, const float *__restrict__ count,
                                                          float *__restrict__ lse, float *__restrict__ part,
                                                          unsigned *ticket, float *__restrict__ loss) {
   __shared__ MaxSum red[kWavesPerBlock];
@@ -67,6 +71,10 @@ __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict
   float term = 0.f;                            // thread 0: this workgroup's sum of (lse_i - s_ii)
   // a few hundred workgroups walk the rows: one ticket per workgroup, not per row (same-address atomics serialise)
   for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+    if (valid && !valid[row]) {                  // workgroup-uniform
+      if (threadIdx.x == 0) lse[row] = 0.f;
+      continue;
+    }
     const float *s = S + row * ld;
     MaxSum a{-INFINITY, 0.f};
     if ((ld & 3) == 0 && aligned16(S)) {
@@ -78,6 +86,13 @@ __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict
         for (int u = 0; u < 4; ++u) {
           const int j = j0 + u * kBlock;
           v[u] = j < n4 ? ld4(s + 4 * j) : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          if (valid && j < n4) {
+            const uchar4 ok = *reinterpret_cast<const uchar4 *>(valid + 4 * j);
+            if (!ok.x) v[u].x = -INFINITY;
+            if (!ok.y) v[u].y = -INFINITY;
+            if (!ok.z) v[u].z = -INFINITY;
+            if (!ok.w) v[u].w = -INFINITY;
+          }
         }
         float mx = a.mx;
 #pragma unroll
@@ -85,15 +100,16 @@ __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict
           v[u].x *= inv_t; v[u].y *= inv_t; v[u].z *= inv_t; v[u].w *= inv_t;
           mx = fmaxf(fmaxf(fmaxf(mx, v[u].x), fmaxf(v[u].y, v[u].z)), v[u].w);
         }
+        if (mx == -INFINITY) continue;              // nothing valid so far
         float sum = a.mx > -INFINITY ? a.sum * expf(a.mx - mx) : 0.f;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           sum += expf(v[u].x - mx) + expf(v[u].y - mx) + expf(v[u].z - mx) + expf(v[u].w - mx);
         a = MaxSum{mx, sum};
       }
-      for (int j = (n4 << 2) + threadIdx.x; j < n; j += kBlock) ms_push(a, s[j] * inv_t);
+      for (int j = (n4 << 2) + threadIdx.x; j < n; j += kBlock) ms_push(a, (!valid || valid[j]) ? s[j] * inv_t : -INFINITY);
     } else {
-      for (int j = threadIdx.x; j < n; j += kBlock) ms_push(a, s[j] * inv_t);
+      for (int j = threadIdx.x; j < n; j += kBlock) ms_push(a, (!valid || valid[j]) ? s[j] * inv_t : -INFINITY);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict
     if (threadIdx.x == 0) {
       float u = 0.f;
       for (int j = 0; j < kWavesPerBlock; ++j) u += redf[j];
-      loss[0] = u / (float)n;
+      loss[0] = u / (count ? count[0] : (float)n);
       *ticket = 0;
     }
   }
@@ -130,13 +146,20 @@ __global__ __launch_bounds__(kBlock) void k_lse_diag_fwd(const float *__restrict
 
 // S[i, j] <- g/n/T * (exp(S[i, j]/T - lse_i) - [i == j])
 __global__ __launch_bounds__(kBlock) void k_lse_diag_bwd(float *__restrict__ S, int64_t ld, int n, float inv_t,
-                                                         const float *__restrict__ lse, const float *__restrict__ g) {
-  const float c = g[0] * inv_t / (float)n;
+                                                         const uint8_t *__restrict__ valid, const float *__restrict__ count,
+                                                         const float *__restrict__ lse, const float *__restrict__ g,
+                                                         int symmetric) {
+  const float c = g[0] * inv_t / (count ? count[0] : (float)n);
   const int64_t total = (int64_t)n * n;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
     const int i = (int)(e / n), j = (int)(e - (int64_t)i * n);
     float *p = S + i * ld + j;
-    *p = c * (expf(*p * inv_t - lse[i]) - (i == j ? 1.f : 0.f));
+    const bool live = !valid || (valid[i] && valid[j]);
+    // symmetric (both views are one matrix, S = S^T): dS + dS^T in one pass, so that dv = (dS + dS^T) v is ONE product
+    const float s = *p * inv_t, d = i == j ? 1.f : 0.f;
+    float val = expf(s - lse[i]) - d;
+    if (symmetric) val += expf(s - lse[j]) - d;
+    *p = live ? c * val : 0.f;
   }
 }
 }  // namespace
@@ -163,23 +186,25 @@ int mi_rownorm_bwd(const float *Y, const float *inv, const float *dY, int64_t n,
 constexpr int kLseGrid = 1024;
 int64_t mi_lse_diag_workspace_elems(int32_t) { return kLseGrid + 1; }
 
-int mi_lse_diag_fwd(const float *S, int64_t ld, int32_t n, float inv_t, float *lse, float *workspace, float *loss,
-                    void *stream) {
+int mi_lse_diag_fwd(const float *S, int64_t ld, int32_t n, float inv_t, const uint8_t *valid, const float *count, float *lse,
+                    float *workspace, float *loss, void *stream) {
   if (n <= 0 || ld < n) return MI_ERR_INVALID_ARG;
-  if (!S || !lse || !workspace || !loss) return MI_ERR_INVALID_ARG;
+  if (!S || !lse || !workspace || !loss || (valid != nullptr) != (count != nullptr)) return MI_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(valid) & 3u) return MI_ERR_INVALID_ARG;       // read four flags at a time
   const int grid = n < kLseGrid ? n : kLseGrid;
   if (hipMemsetAsync(workspace + kLseGrid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return MI_ERR_LAUNCH;
-  MI_LAUNCH("lse_diag_fwd", k_lse_diag_fwd, grid, kBlock, stream, S, ld, n, inv_t, lse, workspace,
+  MI_LAUNCH("lse_diag_fwd", k_lse_diag_fwd, grid, kBlock, stream, S, ld, n, inv_t, valid, count, lse, workspace,
             reinterpret_cast<unsigned *>(workspace + kLseGrid), loss);
   return launch_status();
 }
 
-int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const float *lse, const float *g, void *stream) {
+int mi_lse_diag_bwd(float *S, int64_t ld, int32_t n, float inv_t, const uint8_t *valid, const float *count, const float *lse,
+                    const float *g, int32_t symmetric, void *stream) {
   if (n <= 0 || ld < n) return MI_ERR_INVALID_ARG;
-  if (!S || !lse || !g) return MI_ERR_INVALID_ARG;
+  if (!S || !lse || !g || (valid != nullptr) != (count != nullptr)) return MI_ERR_INVALID_ARG;
   int64_t grid = ((int64_t)n * n + kBlock - 1) / kBlock;
   if (grid > kMaxGrid) grid = kMaxGrid;
-  MI_LAUNCH("lse_diag_bwd", k_lse_diag_bwd, (int)grid, kBlock, stream, S, ld, n, inv_t, lse, g);
+  MI_LAUNCH("lse_diag_bwd", k_lse_diag_bwd, (int)grid, kBlock, stream, S, ld, n, inv_t, valid, count, lse, g, symmetric);
   return launch_status();
 }
 

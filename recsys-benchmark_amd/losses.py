@@ -3,6 +3,8 @@
 each way instead of ~8 elementwise/reduction launches — at B=4096 every launch is microseconds.
 `bpr_loss` / `bpr_loss_rows` are src/losses.py:6-22 (optionally fused with the trainer's three index_selects)
 as one HIP launch each way."""
+from typing import Optional
+
 import torch
 from torch import nn
 
@@ -160,7 +162,7 @@ class _InfoNCEFn(torch.autograd.Function):
     kept for the backward, which overwrites it with the gradient of the scores (single use)."""
 
     @staticmethod
-    def forward(ctx, v1, v2, temperature, b_cos):
+    def forward(ctx, v1, v2, temperature, b_cos, valid=None):
         dev = _lib.require_gpu(v1, v2)
         lib = _lib.load()
         if v1.dim() != 2 or v1.shape != v2.shape or v1.shape[0] == 0:
@@ -179,9 +181,16 @@ class _InfoNCEFn(torch.autograd.Function):
         ws = torch.empty(int(lib.mi_lse_diag_workspace_elems(n)), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         inv_t = 1.0 / float(temperature)
-        _lib.check(lib.mi_lse_diag_fwd(S.data_ptr(), n, n, inv_t, lse.data_ptr(), ws.data_ptr(), loss.data_ptr(),
-                                       _lib.stream_ptr(dev)), "mi_lse_diag_fwd")
+        count = None
+        if valid is not None:
+            if valid.numel() != n:
+                raise ValueError("info_nce: `valid` must flag each of the N rows")
+            valid = valid.reshape(-1).to(device=dev, dtype=torch.uint8).contiguous()
+            count = valid.sum(dtype=torch.float32).view(1)
+        _lib.check(lib.mi_lse_diag_fwd(S.data_ptr(), n, n, inv_t, _lib.ptr(valid), _lib.ptr(count), lse.data_ptr(),
+                                       ws.data_ptr(), loss.data_ptr(), _lib.stream_ptr(dev)), "mi_lse_diag_fwd")
         ctx.save_for_backward(v1, v2, S, lse, *([inv1, inv2] if b_cos else []))
+        ctx.mask = (valid, count)
         ctx.meta = (n, D, inv_t, bool(b_cos))
         ctx.spent = False
         return loss.view(())
@@ -196,11 +205,13 @@ class _InfoNCEFn(torch.autograd.Function):
         lib = _lib.load()
         dev = S.device
         g = _kernels._f32c(g).view(1)
-        _lib.check(lib.mi_lse_diag_bwd(S.data_ptr(), n, n, inv_t, lse.data_ptr(), g.data_ptr(), _lib.stream_ptr(dev)),
-                   "mi_lse_diag_bwd")
+        valid, count = ctx.mask
+        same = v1.data_ptr() == v2.data_ptr()          # one matrix for both views: dS + dS^T formed in place, one product
+        _lib.check(lib.mi_lse_diag_bwd(S.data_ptr(), n, n, inv_t, _lib.ptr(valid), _lib.ptr(count), lse.data_ptr(),
+                                       g.data_ptr(), int(same), _lib.stream_ptr(dev)), "mi_lse_diag_bwd")
         grads = [None, None]
         for k, (need, other, trans) in enumerate(((ctx.needs_input_grad[0], v2, False), (ctx.needs_input_grad[1], v1, True))):
-            if not need:
+            if not need or (same and k == 1):
                 continue
             d = torch.empty(n, D, dtype=torch.float32, device=dev)
             _kernels.gemm(S, other, d, n, D, n, n, D, D, transA=trans)         # dS v2   /   dS^T v1
@@ -211,10 +222,25 @@ class _InfoNCEFn(torch.autograd.Function):
                                               dx.data_ptr(), _lib.stream_ptr(dev)), "mi_rownorm_bwd")
                 d = dx
             grads[k] = d
-        return grads[0], grads[1], None, None
+        if same and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]:
+            raise RuntimeError("info_nce(v, v): the gradient is delivered through the first argument")
+        return grads[0], grads[1], None, None, None
 
 
-def info_nce(view1: torch.Tensor, view2: torch.Tensor, temperature: float = 1, b_cos: bool = True) -> torch.Tensor:
+def info_nce(view1: torch.Tensor, view2: torch.Tensor, temperature: float = 1, b_cos: bool = True,
+             valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """src/losses.py:25-47.  Row normalisation, the score GEMM (mi_gemm_f32), and one kernel for log-softmax + diagonal +
-    mean; the trainer passes the same matrix twice (src/trainer/lightgcn.py:227), which is normalised once."""
-    return _InfoNCEFn.apply(view1, view2, temperature, b_cos)
+    mean; the trainer passes the same matrix twice (src/trainer/lightgcn.py:227), which is normalised once.
+    valid (extension, [N] bool): rows flagged False are treated as absent — info_nce(v, v, valid=m) == info_nce(v[m], v[m])
+    without the data-dependent shape (see first_occurrence)."""
+    return _InfoNCEFn.apply(view1, view2, temperature, b_cos, valid)
+
+
+def first_occurrence(ids: torch.Tensor, num_ids: int) -> torch.Tensor:
+    """[B] bool: True where ids[i] appears for the first time in the batch — a fixed-shape stand-in for torch.unique
+    (selecting these entries yields each distinct id once).  Two launches, no host sync."""
+    ids = ids.reshape(-1)
+    pos = torch.arange(ids.numel(), device=ids.device)
+    owner = torch.full((num_ids,), ids.numel(), dtype=torch.int64, device=ids.device)
+    owner.scatter_reduce_(0, ids, pos, reduce="amin", include_self=True)
+    return owner[ids] == pos

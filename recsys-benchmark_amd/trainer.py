@@ -229,8 +229,8 @@ def validate_epoch(val_loader, model, device="cuda") -> Dict[str, float]:
 class GraphedCFTrainStep:
     """step(users, pos_items, neg_items): one LightGCN optimisation step as the reference's `_train_step` does it —
     propagate, BPR over the batch rows, `weight_decay * get_reg_loss`, optional InfoNCE on the batch's distinct rows,
-    zero_grad, backward, optimizer step — replayed as one hipGraph for the batch size seen first (other sizes, and
-    `info_nce_weight > 0`, whose `torch.unique` has a data-dependent shape, run eagerly on the same kernels).
+    zero_grad, backward, optimizer step — replayed as one hipGraph for the batch size seen first (other sizes run eagerly
+    on the same kernels).  The reference's `torch.unique` (a data-dependent shape) is replaced by a first-occurrence mask.
 
     `sums` (device tensor [4]) accumulates loss, rec_loss, reg_loss, cl_loss; `steps` counts the calls."""
 
@@ -239,7 +239,7 @@ class GraphedCFTrainStep:
         self.model, self.adj, self.optimizer = model, adj, optimizer
         self.weight_decay, self.info_nce_weight = weight_decay, info_nce_weight
         self.warmup = warmup
-        self.use_graph = use_graph and not info_nce_weight
+        self.use_graph = use_graph
         if self.use_graph and not _capturable([optimizer]):
             warnings.warn("the optimizer keeps its step count on the host (capturable=False): the LightGCN step runs "
                           "eagerly; use recsys_benchmark_amd.optim.Adam")
@@ -255,9 +255,12 @@ class GraphedCFTrainStep:
         reg_loss = self.model.get_reg_loss(users, pos_items, neg_items) if self.weight_decay > 0 else zero
         cl_loss = zero
         if self.info_nce_weight > 0:           # SGL without augmentation (src/trainer/lightgcn.py:405-417)
-            view = torch.cat([torch.index_select(all_user_emb, 0, torch.unique(users)),
-                              torch.index_select(all_item_emb, 0, torch.unique(pos_items))], 0)
-            cl_loss = losses.info_nce(view, view, 0.2) * self.info_nce_weight
+            # view1 = rows of the batch's DISTINCT users and positives; here: all batch rows, repeats masked out (the loss is
+            # a mean over rows of a softmax over columns: the order of the rows is immaterial), so no shape depends on data
+            view = torch.cat([torch.index_select(all_user_emb, 0, users), torch.index_select(all_item_emb, 0, pos_items)], 0)
+            valid = torch.cat([losses.first_occurrence(users, all_user_emb.shape[0]),
+                               losses.first_occurrence(pos_items, all_item_emb.shape[0])])
+            cl_loss = losses.info_nce(view, view, 0.2, valid=valid) * self.info_nce_weight
         loss = rec_loss + self.weight_decay * reg_loss + cl_loss
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()

@@ -9,7 +9,7 @@ from conftest import assert_close, load_golden
 from oracle import reference_ops as ro
 from recsys_benchmark_amd import _lib
 from recsys_benchmark_amd.lightgcn import score_topk, train_items_csr
-from recsys_benchmark_amd.losses import bpr_loss, bpr_loss_multi, bpr_loss_rows, info_nce
+from recsys_benchmark_amd.losses import bpr_loss, bpr_loss_multi, bpr_loss_rows, first_occurrence, info_nce
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
@@ -203,3 +203,31 @@ def test_info_nce_same_view_and_degenerate_rows():
     assert_close(h.grad[7] * 1e-12, v.grad[7] * 1e-12, 1e-3, 1e-6, "grad of the clamped row")
     with pytest.raises(ValueError):
         info_nce(h, h[:10], 0.2)
+
+
+@pytest.mark.parametrize("n,D", [(9, 8), (517, 64), (4096, 64)])
+def test_masked_info_nce_equals_info_nce_of_the_selected_rows(n, D):
+    gen = torch.Generator().manual_seed(n)
+    v = torch.randn(n, D, generator=gen)
+    m = torch.rand(n, generator=gen) < 0.7
+    m[0] = True
+    sel = v[m].clone().requires_grad_(True)
+    ref = ro.info_nce(sel, sel, 0.2)
+    ref.backward()
+    h = v.to(DEV).requires_grad_(True)
+    out = info_nce(h, h, 0.2, valid=m.to(DEV))
+    out.backward()
+    assert_close(out, ref, 1e-5, 1e-5, "loss")
+    assert_close(h.grad[m.to(DEV)], sel.grad, 1e-4, 1e-6 / max(1.0, n / 100), "grad of the kept rows")
+    assert not h.grad[~m.to(DEV)].any(), "a masked row received a gradient"
+
+
+def test_first_occurrence_selects_each_id_once():
+    gen = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 300, (2048,), generator=gen).to(DEV)
+    first = first_occurrence(ids, 300)
+    assert torch.equal(torch.sort(ids[first])[0], torch.unique(ids))
+    # and it is the FIRST position of each id
+    pos = torch.arange(2048, device=DEV)[first]
+    for i in pos[:50].tolist():
+        assert not (ids[:i] == ids[i]).any()
