@@ -65,6 +65,25 @@ def run(name, model, opts, x, y, iters):
           f"{'' if gstep._graph is not None else '  [NOT captured]'}")
 
 
+def eval_forward(x, iters):
+    """validate_epoch's forward (eval mode: running statistics, no dropout), eager vs replayed"""
+    dims = list(CRITEO_KAGGLE_26)
+    torch.manual_seed(0)
+    model = rb.DeepFM(dims, 16, [400, 400, 400], p_dropout=0.5, use_batchnorm=True).to(x.device).eval()
+    out = {}
+    for name, fwd in (("eager", trainer.GraphedForward(model, use_graph=False)), ("hipGraph", trainer.GraphedForward(model))):
+        for _ in range(5):
+            fwd(x)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(iters):
+            fwd(x)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t) / iters * 1e3
+    print(f"eval forward: eager {out['eager']:.3f} ms = {x.shape[0] / out['eager'] / 1e3:.1f} M samples/s;  one hipGraph "
+          f"{out['hipGraph']:.3f} ms = {x.shape[0] / out['hipGraph'] / 1e3:.1f} M samples/s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
@@ -85,6 +104,8 @@ def main():
         run(name, model, opts, x, y, a.iters)
         del model, opts
         torch.cuda.empty_cache()
+    if not a.only:
+        eval_forward(x, a.iters)
 
 
 if __name__ == "__main__":
