@@ -3,9 +3,8 @@
 PyTorch is plumbing here: it owns the device buffers and the stream; every
 arithmetic step of the hot path runs in libmi355x_recsys.so.
 """
-from typing import Optional, Tuple
-
 import collections
+from typing import Optional, Tuple
 
 import torch
 

@@ -13,7 +13,7 @@ from oracle import int_ops
 from oracle import reference_ops as ro
 
 import recsys_benchmark_amd as pkg
-from recsys_benchmark_amd import _kernels, _lib
+from recsys_benchmark_amd import _lib
 from recsys_benchmark_amd.embeddings import (CerpEmbedding, DHEmbedding, PrunedEmbedding, QRHashingEmbedding,
                                              RetrainCerpEmbedding, get_embedding)
 

@@ -1,13 +1,11 @@
 """GPU parity of the LightGCN propagation (fused CSR SpMM kernels) vs the reference goldens and
 the oracle.  fp32; only the per-row summation order differs: rtol 1e-5 / atol 1e-6."""
-import numpy as np
 import pytest
 import torch
 
 from conftest import assert_close, golden_names, load_golden
 from oracle import reference_ops as ro
 
-import recsys_benchmark_amd as pkg
 from recsys_benchmark_amd import _kernels, _lib
 from recsys_benchmark_amd.graph_utils import calculate_sparse_graph_adj_norm
 from recsys_benchmark_amd.lightgcn import LightGCN, SingleLightGCN
