@@ -129,7 +129,10 @@ class Adam(torch.optim.Adam):
     weight decay, gradient scaling, non-fp32 or CPU parameters) take torch's own step."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kwargs):
-        kwargs.setdefault("capturable", True)
+        params = list(params)
+        tensors = [t for g in params for t in (g["params"] if isinstance(g, dict) else [g[1] if isinstance(g, tuple) else g])]
+        # device-side step counts only where they are supported (torch rejects capturable=True for CPU parameters)
+        kwargs.setdefault("capturable", bool(tensors) and all(t.is_cuda for t in tensors))
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
 
     def _kernel_ok(self, group) -> bool:

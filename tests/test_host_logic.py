@@ -185,3 +185,21 @@ def test_binary_auc_is_sklearns_roc_auc_with_ties():
         assert abs(binary_auc(true, score) - roc_auc_score(true.tolist(), score.tolist())) < 1e-12
     with pytest.raises(ValueError):
         binary_auc(torch.ones(5), torch.rand(5))
+
+
+def test_adam_subclass_on_cpu_parameters_is_plain_torch_adam():
+    """optim.Adam only switches to the HIP kernel (and device-side step counts) for GPU parameters."""
+    from recsys_benchmark_amd.optim import Adam
+
+    torch.manual_seed(0)
+    p, q = torch.nn.Parameter(torch.randn(7, 3)), None
+    q = torch.nn.Parameter(p.detach().clone())
+    a, b = Adam([p], lr=1e-2, weight_decay=1e-3), torch.optim.Adam([q], lr=1e-2, weight_decay=1e-3)
+    assert a.param_groups[0]["capturable"] is False
+    for _ in range(3):
+        g = torch.randn(7, 3)
+        p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+    assert torch.equal(p, q)
+    assert Adam([{"params": [torch.nn.Parameter(torch.zeros(2))], "lr": 0.1}]).param_groups[0]["lr"] == 0.1
