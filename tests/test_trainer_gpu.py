@@ -267,3 +267,33 @@ def test_every_table_kind_trains_inside_one_graph(emb_cfg, tmp_path):
     assert torch.isfinite(gstep.loss_sum)
     if not draws:
         assert_close(gstep.loss_sum, estep.loss_sum, 2e-4, 1e-5, "accumulated loss, graph vs eager")
+
+
+def test_end_to_end_training_learns_a_planted_signal():
+    """train_epoch + validate_epoch on synthetic clicks drawn from a planted first-order model: the validation AUC of the
+    trained DeepFM (row-form table gradients, SparseAdam + Adam, one-graph steps) climbs well above chance."""
+    gen = torch.Generator().manual_seed(13)
+    dims = [30, 8, 200, 5, 60]
+    planted = [torch.randn(d, generator=gen) for d in dims]
+
+    def draw(n, B):
+        out = []
+        for _ in range(n):
+            x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+            logit = sum(w[x[:, f]] for f, w in enumerate(planted)) * 0.8
+            out.append((x, (torch.rand(B, generator=gen) < torch.sigmoid(logit)).float()))
+        return out
+
+    train, val = draw(40, 256), draw(8, 256)
+    torch.manual_seed(1)
+    model = pkg.DeepFM(dims, 8, [32, 16], p_dropout=0.1, use_batchnorm=True,
+                       embedding_config={"name": "vanilla", "sparse": True}, fc_sparse=True).to(DEV)
+    opts = get_optimizers(model, {"sparse": True, "optimizer": "adam", "learning_rate": 5e-3, "weight_decay": 1e-6})
+    step = trainer.GraphedTrainStep(model, opts)
+    before = trainer.validate_epoch(val, model, device=DEV)
+    losses_seen = [trainer.train_epoch(train, model, opts, device=DEV, log_step=0, step=step)["loss"] for _ in range(6)]
+    after = trainer.validate_epoch(val, model, device=DEV)
+    assert step._graph is not None
+    assert losses_seen[-1] < losses_seen[0] - 0.05, losses_seen
+    assert after["auc"] > 0.75 > before["auc"] - 0.2 and after["log_loss"] < before["log_loss"], (before, after)
+    pkg.check_index_errors()
