@@ -361,6 +361,37 @@ def train_epoch_cf(dataloader, model, optimizer, device="cuda", log_step=10, wei
     return {"loss": avg[0], "rec_loss": avg[1], "reg_loss": avg[2], "cl_loss": avg[3]}
 
 
+def train_epoch_pep(dataloader, model, optimizer, device="cuda", log_step=10, weight_decay=0, profiler=None,
+                    info_nce_weight=0, target_sparsity=0, step: Optional[GraphedCFTrainStep] = None) -> Dict[str, float]:
+    """src/trainer/lightgcn.py:294-375: `train_epoch` for a LightGCN on PEP tables — the tables' sparsity is read at the
+    logging steps (`get_sparsity_and_param`) and the epoch ends early once it exceeds `target_sparsity`.  Returns the
+    four averaged losses plus "sparsity" / "num_params" of the last check."""
+    from .lightgcn import get_sparsity_and_param
+
+    model.train()
+    model.to(device)
+    if step is None:
+        step = GraphedCFTrainStep(model, dataloader.dataset.get_norm_adj().to(device), optimizer, weight_decay, info_nce_weight)
+    first_steps = step.steps
+    first = step.sums.clone() if step.sums is not None else None
+    extra = {}
+    for idx, (users, pos_items, neg_items) in enumerate(dataloader):
+        step(users.to(device, non_blocking=True), pos_items.to(device, non_blocking=True),
+             neg_items.to(device, non_blocking=True))
+        if log_step and idx % log_step == 0:
+            sparsity, num_params = get_sparsity_and_param(model)
+            extra = {"sparsity": sparsity, "num_params": num_params}
+            logger.info("Idx: %d - sparsity: %.2f - num_params: %d", idx, sparsity, num_params)
+            if sparsity > target_sparsity:
+                logger.info("Found target sparsity")
+                break
+        if profiler:
+            profiler.step()
+    n = max(step.steps - first_steps, 1)
+    avg = ((step.sums - first if first is not None else step.sums) / n).tolist() if step.sums is not None else [0.0] * 4
+    return dict({"loss": avg[0], "rec_loss": avg[1], "reg_loss": avg[2], "cl_loss": avg[3]}, **extra)
+
+
 def ndcg_recall_at_k(y_pred: torch.Tensor, y_true: Sequence[Union[Sequence[int], set]], k: int = 20) -> Tuple[float, float]:
     """src/metrics.py:9-43, 70-108 (`get_ndcg`, `get_ndcg_recall`) for a [users, >=k] tensor of recommended item ids:
     the relevance test is one broadcast comparison against the padded true-item lists on y_pred's device, float64."""

@@ -297,3 +297,22 @@ def test_end_to_end_training_learns_a_planted_signal():
     assert losses_seen[-1] < losses_seen[0] - 0.05, losses_seen
     assert after["auc"] > 0.75 > before["auc"] - 0.2 and after["log_loss"] < before["log_loss"], (before, after)
     pkg.check_index_errors()
+
+
+def test_train_epoch_pep_reports_sparsity_and_stops_at_the_target(tmp_path):
+    from recsys_benchmark_amd.optim import Adam
+
+    ds = _ToyCF(seed=3)
+    torch.manual_seed(4)
+    cfg = {"name": "pep", "threshold_type": "feature_dim", "checkpoint_weight_dir": str(tmp_path)}
+    model = pkg.LightGCN(ds.num_user, ds.num_item, num_layers=2, hidden_size=16, embedding_config=cfg).to(DEV)
+    data = _Loader(ds.triples(6, 64, 8))
+    data.dataset = ds
+    out = trainer.train_epoch_pep(data, model, Adam(model.parameters(), lr=1e-2), device=DEV, log_step=2, weight_decay=1e-3,
+                                  target_sparsity=2.0)
+    assert set(out) == {"loss", "rec_loss", "reg_loss", "cl_loss", "sparsity", "num_params"}
+    assert 0.0 <= out["sparsity"] <= 1.0 and out["num_params"] > 0 and out["rec_loss"] > 0
+    # a target already met: the epoch ends at the first logging step (one batch)
+    step = trainer.GraphedCFTrainStep(model, ds.adj.to(DEV), Adam(model.parameters(), lr=1e-2), 1e-3)
+    trainer.train_epoch_pep(data, model, None, device=DEV, log_step=1, target_sparsity=-1.0, step=step)
+    assert step.steps == 1
