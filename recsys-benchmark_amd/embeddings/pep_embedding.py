@@ -16,6 +16,31 @@ from .. import _kernels
 from .base import IEmbedding
 
 
+_THRESHOLD_SHAPES = {          # one threshold logit per ...
+    "global": lambda n, d: (1,),
+    "dimension": lambda n, d: (d,),
+    "feature": lambda n, d: (n, 1),
+    "feature_dim": lambda n, d: (n, d),
+}
+
+
+def _num_rows(field_dims: Union[List[int], int]) -> int:
+    return field_dims if isinstance(field_dims, int) else sum(field_dims)
+
+
+def _soft(v: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """sign(v) * relu(|v| - sigmoid(s)): the PEP re-parametrisation of a pruned weight."""
+    return torch.sign(v) * torch.relu(torch.abs(v) - torch.sigmoid(s))
+
+
+def _initial_weights_file(directory: str, field_name: str) -> str:
+    return os.path.join(directory, field_name + ".pth")
+
+
+def _milestone_file(directory: str, sparsity) -> str:
+    return os.path.join(directory, f"{sparsity}.pth")
+
+
 class PepEmbeeding(IEmbedding):   # (sic: the reference's class name)
     def __init__(
         self,
@@ -30,69 +55,66 @@ class PepEmbeeding(IEmbedding):   # (sic: the reference's class name)
         sparsity: Optional[List[float]] = None,
     ):
         super().__init__()
-        if isinstance(field_dims, int):
-            field_dims = [field_dims]
-        num_item = sum(field_dims)
-        if sparsity is None:
-            sparsity = [0.8, 0.9, 0.99]
-        assert isinstance(sparsity, list) and isinstance(sparsity[0], float)
-        self.sparsity = list(sorted(sparsity))
-        self._cur_min_spar_idx = 0
+        rows = _num_rows(field_dims)
+        milestones = [0.8, 0.9, 0.99] if sparsity is None else sparsity
+        if not (isinstance(milestones, list) and isinstance(milestones[0], float)):
+            raise AssertionError("sparsity must be a list of floats")
+        self.sparsity = sorted(milestones)
+        self._cur_min_spar_idx = 0            # milestones below this index have been written out
+        self._mode = mode
+        self.field_name = field_name
+        self.threshold_type = threshold_type
 
-        self.emb = nn.Embedding(num_item, hidden_size)
+        self.emb = nn.Embedding(rows, hidden_size)
         nn.init.xavier_uniform_(self.emb.weight)
+        self.s = self.init_threshold(init_threshold, rows, hidden_size)
+
+        # side files: the untouched initial table (for the retrain stage) and one state_dict per sparsity milestone
         if ori_weight_dir:
             os.makedirs(ori_weight_dir, exist_ok=True)
-            torch.save({"state_dict": self.emb.state_dict()}, os.path.join(ori_weight_dir, field_name + ".pth"))
-
-        self.threshold_type = threshold_type
-        self.s = self.init_threshold(init_threshold, num_item, hidden_size)
-        self.field_name = field_name
-        if field_name:
-            checkpoint_weight_dir = os.path.join(checkpoint_weight_dir, field_name)
-        os.makedirs(checkpoint_weight_dir, exist_ok=True)
-        self.checkpoint_weight_dir = checkpoint_weight_dir
-        self._mode = mode
-
-    def soft_threshold(self, v, s):
-        return torch.sign(v) * torch.relu(torch.abs(v) - torch.sigmoid(s))
-
-    def get_weight(self):
-        arr = torch.arange(self.emb.num_embeddings, device=self.emb.weight.device)
-        return _kernels.soft_threshold_gather(arr, self.emb.weight, self.s)
-
-    def forward(self, x):
-        rows = _kernels.soft_threshold_gather(x, self.emb.weight, self.s)
-        return _kernels.bag_reduce(rows, self._mode)
+            torch.save({"state_dict": self.emb.state_dict()}, _initial_weights_file(ori_weight_dir, field_name))
+        self.checkpoint_weight_dir = os.path.join(checkpoint_weight_dir, field_name) if field_name else checkpoint_weight_dir
+        os.makedirs(self.checkpoint_weight_dir, exist_ok=True)
 
     def init_threshold(self, init, num_item, hidden_size) -> nn.Parameter:
-        """One threshold logit per (global | dimension | feature | feature x dimension)."""
-        shapes = {"global": (1,), "dimension": (hidden_size,), "feature": (num_item, 1),
-                  "feature_dim": (num_item, hidden_size)}
-        if self.threshold_type in ("field", "field_dim"):
+        kind = self.threshold_type
+        if kind in ("field", "field_dim"):
             raise NotImplementedError()
-        if self.threshold_type not in shapes:
-            raise ValueError("Invalid threshold_type: {}".format(self.threshold_type))
-        return nn.Parameter(torch.full(shapes[self.threshold_type], float(init)))
+        if kind not in _THRESHOLD_SHAPES:
+            raise ValueError("Invalid threshold_type: {}".format(kind))
+        return nn.Parameter(torch.full(_THRESHOLD_SHAPES[kind](num_item, hidden_size), float(init)))
 
-    def get_sparsity(self, get_n_params=False):
-        total_params = self.emb.weight.numel()
-        n_params = self.get_num_params()
-        if get_n_params:
-            return (1 - n_params / total_params), n_params
-        return 1 - n_params / total_params
+    def soft_threshold(self, v, s):
+        return _soft(v, s)
+
+    def _all_ids(self):
+        return torch.arange(self.emb.num_embeddings, device=self.emb.weight.device)
+
+    def forward(self, x):
+        # the reference thresholds the whole table, then gathers; the kernel thresholds the gathered rows
+        return _kernels.bag_reduce(_kernels.soft_threshold_gather(x, self.emb.weight, self.s), self._mode)
+
+    def get_weight(self):
+        return _kernels.soft_threshold_gather(self._all_ids(), self.emb.weight, self.s)
 
     def get_num_params(self) -> int:
-        return torch.count_nonzero(self.soft_threshold(self.emb.weight, self.s)).item()
+        return torch.count_nonzero(_soft(self.emb.weight, self.s)).item()
+
+    def get_sparsity(self, get_n_params=False):
+        kept = self.get_num_params()
+        ratio = 1 - kept / self.emb.weight.numel()
+        return (ratio, kept) if get_n_params else ratio
 
     def train_callback(self):
-        """Save the state to {checkpoint_weight_dir}/{sparsity}.pth when a target sparsity is passed."""
+        """Write `state_dict()` to {checkpoint_weight_dir}/{milestone}.pth for every milestone the table's sparsity
+        has passed since the last call."""
         with torch.no_grad():
-            cur_sparsity = self.get_sparsity()
-        while self._cur_min_spar_idx < len(self.sparsity) and self.sparsity[self._cur_min_spar_idx] < cur_sparsity:
-            sparsity = self.sparsity[self._cur_min_spar_idx]
-            torch.save(self.state_dict(), os.path.join(self.checkpoint_weight_dir, f"{sparsity}.pth"))
-            self._cur_min_spar_idx += 1
+            reached = self.get_sparsity()
+        pending = self.sparsity[self._cur_min_spar_idx:]
+        passed = [m for m in pending if m < reached]          # the list is sorted: a prefix of `pending`
+        for milestone in passed:
+            torch.save(self.state_dict(), _milestone_file(self.checkpoint_weight_dir, milestone))
+        self._cur_min_spar_idx += len(passed)
 
 
 class RetrainPepEmbedding(IEmbedding):
@@ -108,37 +130,29 @@ class RetrainPepEmbedding(IEmbedding):
         sparse=False,
     ):
         super().__init__()
-        if isinstance(field_dims, int):
-            field_dims = [field_dims]
-        num_item = sum(field_dims)
-        self.emb = nn.Embedding(num_item, hidden_size)
-        if ori_weight_dir:
-            ori = torch.load(os.path.join(ori_weight_dir, field_name + ".pth"), map_location="cpu")["state_dict"]
-            self.emb.load_state_dict(ori)
-        finish = torch.load(os.path.join(checkpoint_weight_dir, field_name, f"{sparsity}.pth"), map_location="cpu")
-        weight, s = finish["emb.weight"], finish["s"]
-        self.mask = nn.Parameter((torch.abs(weight) - torch.sigmoid(s)) > 0, False)
-        nnz = self.mask.sum()
-        self._nnz = nnz
-        self.sparsity = 1 - (nnz / torch.prod(torch.tensor(self.mask.size()))).item()
-        self._mode = mode
         if sparse:
             raise NotImplementedError("RetrainPepEmbedding(sparse=True): row-form grads are not built for the "
                                       "masked table; use the dense form")
-        self._sparse = sparse
-
-    def get_weight(self):
-        arr = torch.arange(self.emb.num_embeddings, device=self.emb.weight.device)
-        return _kernels.masked_gather(arr, self.emb.weight, self.mask)
+        self._sparse, self._mode = sparse, mode
+        self.emb = nn.Embedding(_num_rows(field_dims), hidden_size)
+        if ori_weight_dir:                      # lottery-ticket style: restart from the saved initial table
+            saved = torch.load(_initial_weights_file(ori_weight_dir, field_name), map_location="cpu")
+            self.emb.load_state_dict(saved["state_dict"])
+        found = torch.load(_milestone_file(os.path.join(checkpoint_weight_dir, field_name), sparsity), map_location="cpu")
+        keep = (torch.abs(found["emb.weight"]) - torch.sigmoid(found["s"])) > 0      # where the pruned table is non-zero
+        self.mask = nn.Parameter(keep, requires_grad=False)
+        self._nnz = keep.sum()
+        self.sparsity = 1 - (self._nnz / torch.prod(torch.tensor(keep.size()))).item()
 
     def forward(self, x):
-        rows = _kernels.masked_gather(x, self.emb.weight, self.mask)
-        return _kernels.bag_reduce(rows, self._mode)
+        return _kernels.bag_reduce(_kernels.masked_gather(x, self.emb.weight, self.mask), self._mode)
 
-    def get_sparsity(self, get_n_params=False):
-        if get_n_params:
-            return self.sparsity, self._nnz
-        return self.sparsity
+    def get_weight(self):
+        ids = torch.arange(self.emb.num_embeddings, device=self.emb.weight.device)
+        return _kernels.masked_gather(ids, self.emb.weight, self.mask)
 
     def get_num_params(self):
         return self._nnz
+
+    def get_sparsity(self, get_n_params=False):
+        return (self.sparsity, self._nnz) if get_n_params else self.sparsity

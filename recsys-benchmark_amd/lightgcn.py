@@ -18,6 +18,8 @@ from .layers import SparseDropout
 
 
 class IGraphBaseCore(nn.Module):
+    """The interface of src/models/base.py:8-35: forward(adjacency) -> (user embeddings, item embeddings)."""
+
     @abstractmethod
     def get_emb_table(self, matrix) -> Tuple[torch.Tensor, torch.Tensor]:
         ...
@@ -26,95 +28,81 @@ class IGraphBaseCore(nn.Module):
     def get_reg_loss(self, users, pos_items, neg_items) -> torch.Tensor:
         ...
 
-    def forward(self, matrix):
-        return self.get_emb_table(matrix)
-
     @abstractmethod
     def get_embs(self) -> List[Tuple[str, nn.Module]]:
         ...
 
+    def forward(self, matrix):
+        return self.get_emb_table(matrix)
 
-class LightGCN(IGraphBaseCore):
-    item_emb_table: IEmbedding
-    user_emb_table: IEmbedding
+
+def _squared_l2(t: torch.Tensor) -> torch.Tensor:
+    return t.norm(2).pow(2)          # as the reference forms it (norm, then square)
+
+
+class _Propagating(IGraphBaseCore):
+    """Constructor bookkeeping shared by the two-table and the one-table model (same arguments, same attributes)."""
 
     def __init__(self, num_user, num_item, num_layers=2, hidden_size=64, p_dropout=0, embedding_config=None):
         super().__init__()
-        if embedding_config is None:
-            embedding_config = {"name": "vanilla"}
-        self.embedding_config = embedding_config
-        self._init_embedding(num_user, num_item, hidden_size)
+        self.embedding_config = {"name": "vanilla"} if embedding_config is None else embedding_config
+        self._num_user, self._num_item, self._hidden_size = num_user, num_item, hidden_size
         self.num_layers = num_layers
-        self._num_user = num_user
-        self._num_item = num_item
-        self._hidden_size = hidden_size
-        if p_dropout > 0:
-            self.sparse_dropout = SparseDropout(p_dropout)
-        else:
-            self.sparse_dropout = torch.nn.Identity(p_dropout)
+        self._init_embedding(num_user, num_item, hidden_size)
+        # dropout on the adjacency's stored values; an Identity keeps the attribute (and module tree) when it is off
+        self.sparse_dropout = SparseDropout(p_dropout) if p_dropout > 0 else torch.nn.Identity(p_dropout)
+
+    def _init_embedding(self, num_user, num_item, hidden_size):
+        raise NotImplementedError
+
+
+class LightGCN(_Propagating):
+    item_emb_table: IEmbedding
+    user_emb_table: IEmbedding
 
     def _init_embedding(self, num_user, num_item, hidden_size):
         self.user_emb_table = get_embedding(self.embedding_config, num_user, hidden_size, field_name="user")
         self.item_emb_table = get_embedding(self.embedding_config, num_item, hidden_size, field_name="item")
 
     def get_emb_table(self, matrix):
-        """matrix: sparse (num_user+num_item)^2 normalised adjacency -> (user_emb, item_emb)."""
-        matrix = self.sparse_dropout(matrix)
-        # E^0 = [user table; item table] is read as two row segments: no torch.cat copy
-        return _kernels.lightgcn_propagate(
-            matrix, self.user_emb_table.get_weight(), self.item_emb_table.get_weight(), self.num_layers)
+        """matrix: sparse (num_user+num_item)^2 normalised adjacency -> (user_emb, item_emb).  E^0 = [user table; item
+        table] is read as two row segments (no concatenated copy) and the result comes back as the two tables."""
+        return _kernels.lightgcn_propagate(self.sparse_dropout(matrix), self.user_emb_table.get_weight(),
+                                           self.item_emb_table.get_weight(), self.num_layers)
+
+    def _plain_tables(self) -> bool:
+        return all(type(t) is VanillaEmbedding and t._mode is None and not t.sparse_grad
+                   for t in (self.user_emb_table, self.item_emb_table))
 
     def get_reg_loss(self, users, pos_items, neg_items) -> torch.Tensor:
-        ut, it = self.user_emb_table, self.item_emb_table
-        if (type(ut) is VanillaEmbedding and type(it) is VanillaEmbedding and ut._mode is None and it._mode is None
-                and not ut.sparse_grad and not it.sparse_grad and users.dim() == 1):
-            # plain tables: gathers, squares and the sum in one launch each way (~30 small launches otherwise)
+        """(|e_u|^2 + |e_i+|^2 + |e_i-|^2) / (2 * batch) over the batch's rows of the INPUT tables."""
+        users_t, items_t = self.user_emb_table, self.item_emb_table
+        if self._plain_tables() and users.dim() == 1:
+            # gathers, squares and the sum in one launch each way (~30 small launches otherwise)
             from .losses import reg_loss_rows
 
-            return reg_loss_rows(ut.get_weight(), it.get_weight(), users, pos_items, neg_items)
-        user_emb = ut(users)
-        pos_item_emb = it(pos_items)
-        neg_item_emb = it(neg_items)
-        reg_loss = (
-            user_emb.norm(2).pow(2) + pos_item_emb.norm(2).pow(2) + neg_item_emb.norm(2).pow(2)
-        ) / (2 * len(users))
-        return reg_loss
+            return reg_loss_rows(users_t.get_weight(), items_t.get_weight(), users, pos_items, neg_items)
+        total = _squared_l2(users_t(users)) + _squared_l2(items_t(pos_items)) + _squared_l2(items_t(neg_items))
+        return total / (2 * len(users))
 
     def get_embs(self):
         return [("user", self.user_emb_table), ("item", self.item_emb_table)]
 
 
-class SingleLightGCN(IGraphBaseCore):
+class SingleLightGCN(_Propagating):
     emb_table: IEmbedding
 
-    def __init__(self, num_user, num_item, num_layers=2, hidden_size=64, p_dropout=0, embedding_config=None):
-        super().__init__()
-        if embedding_config is None:
-            embedding_config = {"name": "vanilla"}
-        self.embedding_config = embedding_config
-        self._init_embedding(num_user, num_item, hidden_size)
-        self.num_layers = num_layers
-        self._num_user = num_user
-        self._num_item = num_item
-        self._hidden_size = hidden_size
-        if p_dropout > 0:
-            self.sparse_dropout = SparseDropout(p_dropout)
-        else:
-            self.sparse_dropout = torch.nn.Identity(p_dropout)
-
     def _init_embedding(self, num_user, num_item, hidden_size):
-        self.emb_table = get_embedding(self.embedding_config, [num_user, num_item], hidden_size,
-                                       field_name="user-item")
+        self.emb_table = get_embedding(self.embedding_config, [num_user, num_item], hidden_size, field_name="user-item")
 
     def get_emb_table(self, matrix):
-        matrix = self.sparse_dropout(matrix)
-        res = _kernels.lightgcn_propagate(matrix, self.emb_table.get_weight(), None, self.num_layers)
-        return torch.split(res, (self._num_user, self._num_item))
+        both = _kernels.lightgcn_propagate(self.sparse_dropout(matrix), self.emb_table.get_weight(), None, self.num_layers)
+        return torch.split(both, (self._num_user, self._num_item))
 
     def get_reg_loss(self, users, pos_items, neg_items) -> torch.Tensor:
-        indices = torch.cat([users, pos_items + self._num_user, neg_items + self._num_user])
-        emb = self.emb_table(indices)
-        return emb.norm(2).pow(2) / (2 * len(users))
+        item_base = self._num_user                         # items follow the users in the one table
+        batch_rows = torch.cat([users, pos_items + item_base, neg_items + item_base])
+        return _squared_l2(self.emb_table(batch_rows)) / (2 * len(users))
 
     def get_embs(self):
         return [("user-item", self.emb_table)]
@@ -129,15 +117,12 @@ class LightGCNConfig:
 
 
 def get_sparsity_and_param(model: Union[LightGCN, SingleLightGCN]):
-    if isinstance(model, LightGCN):
-        embs = [model.user_emb_table, model.item_emb_table]
-    elif isinstance(model, SingleLightGCN):
-        embs = [model.emb_table]
-    else:
+    """(1 - stored parameters / dense parameters, stored parameters) over the model's tables."""
+    if not isinstance(model, (LightGCN, SingleLightGCN)):
         raise ValueError()
-    max_params = (model._num_user + model._num_item) * model._hidden_size
-    num_params = sum(emb.get_num_params() for emb in embs)
-    return 1 - num_params / max_params, num_params
+    stored = sum(table.get_num_params() for _, table in model.get_embs())
+    dense = (model._num_user + model._num_item) * model._hidden_size
+    return 1 - stored / dense, stored
 
 
 def train_items_csr(graph, num_users: int, device=None):
