@@ -42,6 +42,28 @@ def synth_batch(dims, B, seed, device):
     return x.to(device), y.to(device)
 
 
+def measured_copy_ceiling(dev, nbytes=1 << 30, reps=10):
+    """What a plain streaming copy reaches on THIS box (SURVEY.md §8d asks for it next to the 8 TB/s spec peak):
+    GB/s of a 1 GiB device-to-device copy counting the bytes read plus the bytes written, and of a read-only pass."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    out = {}
+    for name, fn, moved in (("copy_read_plus_write_GBps", lambda: b.copy_(a), 2 * nbytes),
+                            ("read_only_GBps", lambda: a.sum(), nbytes)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
     """Oracle (= reference op sequence in stock PyTorch CPU ops, dense grads like the
     reference's default nn.Embedding) timed on the host cores; bounded sample."""
@@ -300,6 +322,8 @@ def main():
                         "fwd_bwd_pair": {"us": round(pair_us, 3),
                                          "GBps": round((fb + bb) * B / (pair_us * 1e-6) / 1e9, 1),
                                          "frac": round((fb + bb) * B / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if roofline is not None and not args.c4:
+            roofline["measured_stream_ceiling"] = measured_copy_ceiling(dev)
         out = {
             "metric": "samples/sec fwd+bwd, Criteo-26field DeepFM b=4096; HBM GB/s vs roofline",
             "value": round(B * world * args.steps / elapsed, 1),
