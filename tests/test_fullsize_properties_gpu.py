@@ -102,6 +102,37 @@ def yelp():
     return A.to(DEV), deg.to(DEV), U, I
 
 
+def test_c2_first_sparse_adam_step_is_the_sign_of_the_coalesced_gradient(c2):
+    """Full-size table (33.8 M rows), the batch's own row-form gradient, ids sorted by the field sort: after the FIRST Adam
+    step from zero moments every touched element has moved by lr * g / (|g| + eps / sqrt(1 - beta2)) with g the SUM over
+    the row's duplicates (bias corrections cancel), every other element is bit-identical; a second run is bit-identical."""
+    from recsys_benchmark_amd.optim import SparseAdam
+
+    W, w1, bias, off, x = c2
+    N, D = W.shape
+    runs = []
+    for _ in range(2):
+        p = torch.nn.Parameter(W.clone())
+        emb, yfm = _kernels.gather_fm(x, off, p, w1, bias, sparse_W=True)
+        ((emb * emb).sum() * 0.5 + yfm.sum()).backward()
+        grad = p.grad
+        opt = SparseAdam([p], lr=1e-3)
+        opt.step()
+        runs.append(p.detach())
+    assert torch.equal(runs[0], runs[1]), "the step is deterministic"
+    rows, vals = grad._indices()[0], grad._values()
+    uniq, inverse = torch.unique(rows, return_inverse=True)
+    g = torch.zeros(uniq.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, inverse, vals.double())
+    expect = W[uniq].double() - 1e-3 * g / (g.abs() + 1e-8 / (1 - 0.999) ** 0.5)
+    # fp32 duplicate sums in a different order than the float64 index_add: elements whose sum nearly cancels move by
+    # less than a full step, so the comparison is on the parameter scale (one step = 1e-3)
+    assert_close(runs[0][uniq].double(), expect, 0.0, 2e-6, "touched rows")
+    untouched = torch.ones(N, dtype=torch.bool, device=DEV)
+    untouched[uniq] = False
+    assert torch.equal(runs[0][untouched], W[untouched]), "rows outside the batch must not change"
+    _lib.check_index_errors()
+
+
 def test_c5_fixed_point_of_the_normalised_adjacency(yelp):
     """A_hat = D^-1/2 A D^-1/2  =>  A_hat (D^1/2 1) = D^1/2 1 on every non-isolated node, so the L-layer
     mean propagation of v = D^1/2 1 (broadcast over D columns) returns v."""
