@@ -165,3 +165,53 @@ def test_dense_adam_matches_torch_adam(weight_decay):
     r.grad = torch.ones(10, device=DEV)
     o3.step()
     assert_close(r, torch.full((10,), 0.9), 1e-5, 1e-6, "amsgrad fallback")
+
+
+def test_optimizer_state_dicts_interoperate_with_torch():
+    """A checkpoint written with these optimizers resumes under torch's (and the other way round): same state keys."""
+    gen = torch.Generator().manual_seed(21)
+    w0 = torch.randn(50, 8, generator=gen).to(DEV)
+
+    def dense_grad():
+        return torch.randn(50, 8, generator=gen).to(DEV)
+
+    # dense: optim.Adam -> torch.optim.Adam(capturable=True) and back
+    a, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    oa, ob = Adam([a], lr=1e-2, weight_decay=1e-4), torch.optim.Adam([b], lr=1e-2, weight_decay=1e-4, capturable=True)
+    for _ in range(2):
+        g = dense_grad()
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+    ob2 = torch.optim.Adam([b], lr=1e-2, weight_decay=1e-4, capturable=True)
+    ob2.load_state_dict(oa.state_dict())                      # ours -> torch
+    oa2 = Adam([a], lr=1e-2, weight_decay=1e-4)
+    oa2.load_state_dict(ob.state_dict())                      # torch -> ours
+    g = dense_grad()
+    a.grad, b.grad = g.clone(), g.clone()
+    oa2.step(), ob2.step()
+    # torch's capturable GPU path forms 1 - beta^t in fp32 tensor ops (the kernel, like torch's CPU path, in double):
+    # 1e-4 relative on the step
+    assert_close(a, b, 1e-4, 1e-6, "dense Adam after swapping state dicts")
+    assert float(oa2.state[a]["step"]) == float(ob2.state[b]["step"]) == 3.0
+
+    # row-sparse: optim.SparseAdam (host-side step count) <-> torch.optim.SparseAdam
+    c, d = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    oc, od = SparseAdam([c], lr=1e-2), torch.optim.SparseAdam([d], lr=1e-2)
+
+    def sparse_grad():
+        rows = torch.randint(0, 50, (70,), generator=gen).to(DEV)
+        return torch.sparse_coo_tensor(rows.view(1, -1), torch.randn(70, 8, generator=gen).to(DEV), (50, 8))
+
+    for _ in range(2):
+        g = sparse_grad()
+        c.grad, d.grad = g, g.clone()
+        oc.step(), od.step()
+    oc2, od2 = SparseAdam([c], lr=1e-2), torch.optim.SparseAdam([d], lr=1e-2)
+    oc2.load_state_dict(od.state_dict())
+    od2.load_state_dict({k: v for k, v in oc.state_dict().items()})
+    for grp in od2.param_groups:
+        grp.pop("capturable", None)
+    g = sparse_grad()
+    c.grad, d.grad = g, g.clone()
+    oc2.step(), od2.step()
+    assert_close(c, d, 1e-4, 1e-6, "sparse Adam after swapping state dicts")
