@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam_anyD(AdamArgs a, int D) 
 // (p, g, m, v in; p, m, v out), HBM-bound for the big tables and one launch instead of a 40 us multi_tensor_apply for the
 // MLP's 0.5 M parameters.  The step count is a device float per tensor (torch's capturable layout): this kernel reads
 // t = step + 1, k_adam_steps_inc advances the counters afterwards.
-constexpr int kAdamTensors = 12;
+constexpr int kAdamTensors = 24;
 constexpr int kAdamChunk = kBlock * 16;
 struct AdamDenseTable {
   float *p[kAdamTensors];

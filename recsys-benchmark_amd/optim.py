@@ -122,7 +122,7 @@ class SparseSGD(torch.optim.Optimizer):
 
 class Adam(torch.optim.Adam):
     """torch.optim.Adam (same constructor, param_groups and state_dict: it IS a torch.optim.Adam with `capturable=True`,
-    i.e. device-side step counts) whose step over fp32 GPU parameters is mi_adam_dense_multi: one launch per 12 tensors,
+    i.e. device-side step counts) whose step over fp32 GPU parameters is mi_adam_dense_multi: one launch per 24 tensors,
     one read and one write of p, m, v.  At the headline model: the 574 M-parameter dense config 12.5 ms (torch's default
     multi-pass implementation) / 3.8 ms (torch `fused=True`) -> see DESIGN.md §5; the MLP's 0.5 M parameters 42 us
     (torch fused, 8 workgroups) -> one 5 us launch.  Options the kernel does not implement (amsgrad, maximize, decoupled

@@ -129,7 +129,7 @@ def test_sparse_sgd_and_factory_end_to_end():
 @pytest.mark.parametrize("weight_decay", [0.0, 1e-3])
 def test_dense_adam_matches_torch_adam(weight_decay):
     gen = torch.Generator().manual_seed(4)
-    shapes = [(1,), (5,), (4096,), (4097,), (400, 416), (16, 3, 7), (100003,)] + [(33,)] * 9       # 16 tensors: two launches
+    shapes = [(1,), (5,), (4096,), (4097,), (400, 416), (16, 3, 7), (100003,)] + [(33,)] * 20      # 27 tensors: two launches
     ref = [torch.nn.Parameter(torch.randn(*sh, generator=gen)) for sh in shapes]
     flat = torch.zeros(50, device=DEV)
     mine = [torch.nn.Parameter(t.detach().clone().to(DEV)) for t in ref]
