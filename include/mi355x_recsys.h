@@ -440,11 +440,13 @@ MI_API int mi_adam_tick(float *step, float *step_size, double lr, double beta1, 
  *   t = step + 1 and advanced by one after the update:
  *   g += wd*p; m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
  *   The betas are doubles: 1 - beta is formed in double and then rounded (1.f - 0.999f is off by 1.3e-5).
+ *   tickets (nullable): ceil(count/24) device words, zero between calls — the last workgroup of each launch advances the
+ *   step counts itself; without them a second one-wave launch does.
  */
 MI_API int mi_adam_dense_multi(float *const *params, const float *const *grads, float *const *exp_avgs,
                                float *const *exp_avg_sqs, float *const *steps, const int64_t *numels,
                                int32_t count, float lr, double beta1, double beta2, float eps,
-                               float weight_decay, void *stream);
+                               float weight_decay, uint32_t *tickets, void *stream);
 MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha, float *W,
                                 int64_t n, int32_t D, int64_t N, void *stream);
 

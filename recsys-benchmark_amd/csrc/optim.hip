@@ -195,6 +195,7 @@ struct AdamDenseTable {
   int64_t chunk_end[kAdamTensors];   // prefix sum of ceil(numel / kAdamChunk)
   int32_t count;
   uint32_t vec_ok;                   // bit k: all four pointers of tensor k are 16-byte aligned
+  unsigned *ticket;                  // when given: the last workgroup to finish advances the step counts (no second launch)
 };
 
 __device__ __forceinline__ void adam_dense1(float &p, float g, float &m, float &v, float omb1, float b2, float omb2, float wd,
@@ -243,6 +244,16 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(AdamDenseTable t, float l
       float p = P[e], m = M[e], v = V[e];
       adam_dense1(p, G[e], m, v, omb1, b2, omb2, wd, step_size, inv_bc2s, eps);
       P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+  if (t.ticket) {
+    // every workgroup read its tensor's step count before doing anything else, so once all of them have finished the
+    // counts may advance: the last one to take a ticket does it (and re-arms the ticket for the next launch)
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      for (int i = 0; i < t.count; ++i) t.step[i][0] += 1.f;
+      __hip_atomic_store(t.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -313,10 +324,11 @@ int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double 
 
 int mi_adam_dense_multi(float *const *params, const float *const *grads, float *const *exp_avgs,
                         float *const *exp_avg_sqs, float *const *steps, const int64_t *numels, int32_t count, float lr,
-                        double beta1, double beta2, float eps, float weight_decay, void *stream) {
+                        double beta1, double beta2, float eps, float weight_decay, uint32_t *tickets, void *stream) {
   if (count < 0) return MI_ERR_INVALID_ARG;
   if (count == 0) return MI_OK;
   if (!params || !grads || !exp_avgs || !exp_avg_sqs || !steps || !numels) return MI_ERR_INVALID_ARG;
+  int launch = 0;
   for (int32_t first = 0; first < count; first += kAdamTensors) {
     AdamDenseTable t{};
     int64_t chunks = 0;
@@ -334,8 +346,9 @@ int mi_adam_dense_multi(float *const *params, const float *const *grads, float *
     }
     if (t.count == 0) continue;
     if (chunks > 0x7fffffff) return MI_ERR_UNSUPPORTED;
+    t.ticket = tickets ? tickets + launch++ : nullptr;
     MI_LAUNCH("adam_dense", k_adam_dense, (int)chunks, kBlock, stream, t, lr, beta1, beta2, eps, weight_decay);
-    MI_LAUNCH("adam_steps_inc", k_adam_steps_inc, 1, kWave, stream, t);
+    if (!tickets) MI_LAUNCH("adam_steps_inc", k_adam_steps_inc, 1, kWave, stream, t);
   }
   return launch_status();
 }

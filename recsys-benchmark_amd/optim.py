@@ -135,6 +135,14 @@ class Adam(torch.optim.Adam):
         kwargs.setdefault("capturable", bool(tensors) and all(t.is_cuda for t in tensors))
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
 
+    def _tickets(self, dev, n_tensors: int) -> torch.Tensor:
+        """Completion tickets of the launches (zero between steps): the last workgroup of a launch advances the counts."""
+        need = -(-n_tensors // 24)
+        t = self.__dict__.get("_ticket_buf")
+        if t is None or t.numel() < need or t.device != dev:
+            t = self.__dict__["_ticket_buf"] = torch.zeros(max(need, 4), dtype=torch.int32, device=dev)
+        return t
+
     def _kernel_ok(self, group) -> bool:
         if group["amsgrad"] or group["maximize"] or group.get("decoupled_weight_decay", False) or group["differentiable"]:
             return False
@@ -168,7 +176,8 @@ class Adam(torch.optim.Adam):
                                                arr(*[t.data_ptr() for t in exp_avg_sqs]),
                                                arr(*[t.data_ptr() for t in steps]),
                                                (ctypes.c_int64 * n)(*[t.numel() for t in params]), n, group["lr"], beta1,
-                                               beta2, group["eps"], group["weight_decay"], _lib.stream_ptr(dev)),
+                                               beta2, group["eps"], group["weight_decay"], self._tickets(dev, n).data_ptr(),
+                                               _lib.stream_ptr(dev)),
                        "mi_adam_dense_multi")
         return loss
 
