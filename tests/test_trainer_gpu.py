@@ -316,3 +316,38 @@ def test_train_epoch_pep_reports_sparsity_and_stops_at_the_target(tmp_path):
     step = trainer.GraphedCFTrainStep(model, ds.adj.to(DEV), Adam(model.parameters(), lr=1e-2), 1e-3)
     trainer.train_epoch_pep(data, model, None, device=DEV, log_step=1, target_sparsity=-1.0, step=step)
     assert step.steps == 1
+
+
+@pytest.mark.parametrize("cls_name", ["DCN_Mix", "DCNv2"])
+def test_dcn_with_row_form_gradients_trains_like_torch_optimizers(cls_name):
+    """The DCN models note the field layout of their ids too: SparseAdam sorts them field by field, and the parameters
+    follow the same model stepped by torch.optim.SparseAdam + torch.optim.Adam."""
+    from recsys_benchmark_amd import _kernels, dcn
+
+    torch.manual_seed(6)
+    make = getattr(dcn, cls_name)
+    kw = dict(num_layers=2, embedding_config={"name": "vanilla", "sparse": True}, p_dropout=0.0)
+    if cls_name == "DCN_Mix":
+        kw.update(num_experts=2, rank=8)
+    model = make(DIMS, 8, [32], **kw).to(DEV)
+    twin = copy.deepcopy(model)
+    cfg = {"sparse": True, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    mine = trainer.GraphedTrainStep(model, get_optimizers(model, cfg))
+    dense = [p for n, p in twin.named_parameters() if "embedding." not in n]
+    theirs = [torch.optim.SparseAdam(list(twin.embedding.parameters()), lr=1e-2),
+              torch.optim.Adam(dense, lr=1e-2, weight_decay=1e-6)]
+    crit = torch.nn.BCEWithLogitsLoss()
+    hits = 0
+    for x, y in _batches(5, 128, 41):
+        x, y = x.to(DEV), y.to(DEV)
+        mine(x, y)
+        for o in theirs:
+            o.zero_grad()
+        crit(twin(x), y).backward()
+        rows = twin.embedding.get_weight().grad._indices()[0]
+        hits += _kernels.sort_field_rows(rows, sum(DIMS)) is not None
+        for o in theirs:
+            o.step()
+    assert hits == 5, "the ids' field layout was not found for the optimizer's sort"
+    for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert_close(a, b, 1e-3, 2e-5, k)
