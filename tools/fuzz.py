@@ -1,0 +1,100 @@
+"""Randomised shapes through the optimizer-side kernels against stock torch (run once in a while on a GPU box):
+    python tools/fuzz.py [cases]
+field sort, sparse Adam (all widths), dense Adam (mixed sizes / unaligned views), masked InfoNCE, gather+FM with both
+gradient forms.  Stops at the first mismatch with the seed that reproduces it."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import reference_ops as ro  # noqa: E402  (a checker, as in tests/)
+from recsys_benchmark_amd import _kernels, losses, optim  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def close(a, b, rtol, atol, what, seed):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    if not torch.allclose(a, b, rtol=rtol, atol=atol):
+        raise SystemExit(f"MISMATCH {what} seed={seed}: max abs {float((a - b).abs().max()):.3e}")
+
+
+def one(seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    # ---- field sort
+    F, B = ri(1, 9), ri(1, 5000)
+    dims = [ri(1, 3000) for _ in range(F)]
+    off = torch.tensor([0] + dims[:-1]).cumsum(0)
+    rows = torch.stack([torch.randint(0, d, (B,), generator=g) for d in dims], 1) + off
+    N = sum(dims)
+    drows = rows.to(DEV)
+    _kernels.note_field_layout(drows, off.to(DEV), N)
+    srt, perm = optim.sort_rows(drows.view(-1), N)
+    want = torch.sort(rows.view(-1), stable=True)
+    # stable within a column; columns laid end to end == global stable sort because the ranges ascend
+    assert torch.equal(srt.cpu(), want[0]), f"field sort keys seed={seed}"
+    assert torch.equal(rows.view(-1)[perm.cpu()], want[0]), f"field sort perm seed={seed}"
+    # ---- sparse Adam, random width
+    D = [1, 2, 3, 4, 8, 12, 16, 64][ri(0, 7)]
+    n, Nr = ri(1, 3000), ri(1, 400)
+    W0 = torch.randn(Nr, D, generator=g)
+    p, q = torch.nn.Parameter(W0.clone().to(DEV)), torch.nn.Parameter(W0.clone())
+    o1, o2 = optim.SparseAdam([p], lr=0.01, capturable=bool(seed & 1)), torch.optim.SparseAdam([q], lr=0.01)
+    for _ in range(2):
+        r = (Nr * torch.rand(n, generator=g).pow(ri(1, 3))).long().clamp_(max=Nr - 1)
+        v = torch.randn(n, D, generator=g)
+        p.grad = torch.sparse_coo_tensor(r.view(1, -1).to(DEV), v.to(DEV), (Nr, D), check_invariants=False)
+        q.grad = torch.sparse_coo_tensor(r.view(1, -1), v, (Nr, D))
+        o1.step(), o2.step()
+    close(p, q, 1e-4, 1e-5, f"sparse adam D={D} n={n} N={Nr}", seed)
+    # ---- dense Adam over a few odd tensors
+    shapes = [(ri(1, 70), ri(1, 70)) for _ in range(ri(1, 5))] + [(ri(1, 5000),)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    pd = [torch.nn.Parameter(t.detach().clone().to(DEV)) for t in ps]
+    a1, a2 = optim.Adam(pd, lr=1e-2, weight_decay=1e-3), torch.optim.Adam(ps, lr=1e-2, weight_decay=1e-3)
+    for _ in range(2):
+        for a, b in zip(ps, pd):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr, gr.to(DEV)
+        a1.step(), a2.step()
+    for a, b in zip(ps, pd):
+        close(b, a, 5e-6, 1e-7, f"dense adam {tuple(a.shape)}", seed)
+    # ---- masked InfoNCE
+    m, Dn = ri(2, 300), [8, 16, 64][ri(0, 2)]
+    v = torch.randn(m, Dn, generator=g)
+    keep = torch.rand(m, generator=g) < 0.7
+    keep[ri(0, m - 1)] = True
+    sel = v[keep].clone().requires_grad_(True)
+    ref = ro.info_nce(sel, sel, 0.2)
+    ref.backward()
+    h = v.to(DEV).requires_grad_(True)
+    out = losses.info_nce(h, h, 0.2, valid=keep.to(DEV))
+    out.backward()
+    close(out, ref, 1e-4, 1e-5, f"masked info_nce n={m}", seed)
+    close(h.grad[keep.to(DEV)], sel.grad, 1e-3, 1e-6, "masked info_nce grad", seed)
+    # ---- gather + FM, row-form vs dense gradients
+    Bf, Df = ri(1, 300), [4, 8, 16][ri(0, 2)]
+    x = torch.stack([torch.randint(0, d, (Bf,), generator=g) for d in dims], 1).to(DEV)
+    Wt = torch.randn(N, Df, generator=g).to(DEV)
+    w1 = torch.randn(N, 1, generator=g).to(DEV)
+    outs = []
+    for sparse in (False, True):
+        Wp, wp = torch.nn.Parameter(Wt.clone()), torch.nn.Parameter(w1.clone())
+        emb, y = _kernels.gather_fm(x, off.view(1, -1).to(DEV), Wp, wp, None, sparse_W=sparse, sparse_w1=sparse)
+        ((emb * emb).sum() * 0.5 + (y * y).sum()).backward()
+        outs.append((emb, y, Wp.grad.to_dense() if sparse else Wp.grad, wp.grad.to_dense() if sparse else wp.grad))
+    close(outs[0][2], outs[1][2], 1e-4, 1e-5, "gather_fm table gradient forms", seed)
+    close(outs[0][3], outs[1][3], 1e-4, 1e-5, "gather_fm first-order gradient forms", seed)
+    rw = (x.cpu() + off)
+    close(outs[0][0], Wt.cpu()[rw], 0, 0, "gather_fm rows", seed)
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    for s in range(cases):
+        one(1000 + s)
+        if s % 25 == 24:
+            print(f"{s + 1} cases ok", flush=True)
+    print("FUZZ_OK")
