@@ -1,7 +1,7 @@
 """Randomised shapes through the optimizer-side kernels against stock torch (run once in a while on a GPU box):
     python tools/fuzz.py [cases]
 field sort, sparse Adam (all widths), dense Adam (mixed sizes / unaligned views), masked InfoNCE, gather+FM with both
-gradient forms.  Stops at the first mismatch with the seed that reproduces it."""
+gradient forms, and the fp32 MFMA GEMM at random small shapes.  Stops at the first mismatch with the seed that reproduces it."""
 import os
 import sys
 
@@ -91,10 +91,36 @@ def one(seed):
     close(outs[0][0], Wt.cpu()[rw], 0, 0, "gather_fm rows", seed)
 
 
+def gemm_case(seed):
+    """mi_gemm_f32 at random small shapes / transposes / split-K / plain epilogues vs a float64 product."""
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    M, N, K = ri(1, 260), ri(1, 260), ri(1, 700)
+    tA, tB = bool(ri(0, 1)), bool(ri(0, 1))
+    A = torch.randn((K, M) if tA else (M, K), generator=g).to(DEV)
+    Bm = torch.randn((N, K) if tB else (K, N), generator=g).to(DEV)
+    ref = (A.double().t() if tA else A.double()) @ (Bm.double().t() if tB else Bm.double())
+    mode = ri(0, 2)
+    C = torch.randn(M, N, generator=g).to(DEV) if mode == 2 else torch.zeros(M, N, device=DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if mode == 1 else None
+    if mode == 2:
+        ref = ref + C.double()
+    if mode == 1:
+        ref = ref + bias.double()
+    sk = 0 if mode == 1 else ri(0, 6)
+    _kernels.gemm(A, Bm, C, M, N, K, A.shape[1], Bm.shape[1], N, transA=tA, transB=tB, splitk=sk,
+                  epi=("none", "bias", "accum")[mode], bias=bias)
+    scale = float(ref.abs().max()) + 1e-6
+    if float((C.double() - ref).abs().max()) > 2e-5 * scale * max(1.0, K / 64):
+        raise SystemExit(f"MISMATCH gemm M={M} N={N} K={K} tA={tA} tB={tB} mode={mode} splitk={sk} seed={seed}")
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     for s in range(cases):
         one(1000 + s)
+        for j in range(4):
+            gemm_case(100000 + 4 * s + j)
         if s % 25 == 24:
             print(f"{s + 1} cases ok", flush=True)
     print("FUZZ_OK")
