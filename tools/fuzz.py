@@ -115,12 +115,50 @@ def gemm_case(seed):
         raise SystemExit(f"MISMATCH gemm M={M} N={N} K={K} tA={tA} tB={tB} mode={mode} splitk={sk} seed={seed}")
 
 
+def lookup_case(seed):
+    """dual-table gather (QR forms), CSR SpMM with hub rows, and the sharded routing vs their torch restatements."""
+    from oracle.sharded_ops import TorchOps
+
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    # ---- out = T1[idx % mod1] (op) T2[idx // div2]
+    N, D, div = ri(2, 5000), [4, 8, 16, 12][ri(0, 3)], ri(1, 9)
+    T1, T2 = torch.randn(div, D, generator=g), torch.randn((N - 1) // div + 1, D, generator=g)
+    shape = (ri(1, 200), ri(1, 7))
+    idx = torch.randint(0, N, shape, generator=g)
+    for op, fn in (("add", lambda a, b: a + b), ("mult", lambda a, b: a * b)):
+        got = _kernels.dual_gather(idx.to(DEV), T1.to(DEV), T2.to(DEV), div, div, op=op)
+        want = fn(T1[idx % div], T2[idx // div])
+        if not torch.equal(got.cpu(), want):
+            raise SystemExit(f"MISMATCH dual_gather {op} seed={seed}")
+    # ---- y = A x on a random sparse matrix with a few very long rows
+    n_r, n_c, Dx = ri(1, 400), ri(1, 400), [16, 64, 8][ri(0, 2)]
+    dense = (torch.rand(n_r, n_c, generator=g) < 0.03).float() * torch.randn(n_r, n_c, generator=g)
+    dense[ri(0, n_r - 1)] = torch.randn(n_c, generator=g)            # a hub row
+    X = torch.randn(n_c, Dx, generator=g)
+    y = _kernels.spmm(dense.to_sparse_csr().to(DEV), X.to(DEV))
+    close(y, dense.double() @ X.double(), 1e-4, 1e-4, f"spmm {n_r}x{n_c} D={Dx}", seed)
+    # ---- routing: bit-exact against the torch restatement the gloo tests use
+    world, F = ri(1, 8), ri(1, 6)
+    dims = [ri(1, 500) for _ in range(F)]
+    x = torch.stack([torch.randint(0, d, (ri(1, 1) * 97,), generator=g) for d in dims], 1)
+    off = torch.tensor([0] + dims[:-1]).cumsum(0)
+    rows_total = sum(dims)
+    cap = max(1, int(1.5 * x.numel() / world) + 8)
+    flag_d, flag_h = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32)
+    send_d, slot_d = _kernels.route_buckets(x.to(DEV), off.to(DEV), world, rows_total, cap, flag_d)
+    send_h, slot_h = TorchOps.route_buckets(x, off, world, rows_total, cap, flag_h)
+    if not (torch.equal(send_d.cpu(), send_h) and torch.equal(slot_d.cpu(), slot_h) and int(flag_d) == int(flag_h)):
+        raise SystemExit(f"MISMATCH route_buckets world={world} F={F} seed={seed}")
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     for s in range(cases):
         one(1000 + s)
         for j in range(4):
             gemm_case(100000 + 4 * s + j)
+        lookup_case(500000 + s)
         if s % 25 == 24:
             print(f"{s + 1} cases ok", flush=True)
     print("FUZZ_OK")
