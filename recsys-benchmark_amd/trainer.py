@@ -77,7 +77,7 @@ class GraphedTrainStep:
             self.extra_sum += extra.detach()
         for opt in self.optimizers:
             opt.zero_grad(set_to_none=True)
-        total.backward()
+        total.backward(self._one)          # d(loss)/d(loss) from a resident scalar: no fill launch per step
         if self.clip_grad:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
         for opt in self.optimizers:
@@ -101,6 +101,7 @@ class GraphedTrainStep:
         if self.loss_sum is None:
             self.loss_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
             self.extra_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
+            self._one = torch.ones((), dtype=torch.float32, device=inputs.device)
         self.steps += 1
         shape = (tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype)
         if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:
@@ -300,7 +301,7 @@ class GraphedCFTrainStep:
             cl_loss = losses.info_nce(view, view, 0.2, valid=valid) * self.info_nce_weight
         loss = rec_loss + self.weight_decay * reg_loss + cl_loss
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(self._one)
         self.optimizer.step()
         parts = torch.stack([loss.detach(), rec_loss.detach(), reg_loss.detach(), cl_loss.detach()])
         self.sums += parts
@@ -309,6 +310,7 @@ class GraphedCFTrainStep:
     def __call__(self, users, pos_items, neg_items) -> torch.Tensor:
         if self.sums is None:
             self.sums = torch.zeros(4, dtype=torch.float32, device=users.device)
+            self._one = torch.ones((), dtype=torch.float32, device=users.device)
         self.steps += 1
         shape = (tuple(users.shape), users.dtype)
         if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:
