@@ -434,6 +434,9 @@ MI_API int mi_sort_field_rows(const int64_t *rows, const int64_t *offsets, int64
                               void *stream);
 MI_API int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2,
                         void *stream);
+/* the same for `count` tables that share lr and betas, in one launch per 8 (host arrays of device pointers) */
+MI_API int mi_adam_tick_multi(float *const *steps, float *const *step_sizes, int32_t count, double lr,
+                              double beta1, double beta2, void *stream);
 /* mi_adam_dense_multi: torch.optim.Adam (L2 weight decay, no amsgrad) over `count` dense fp32 tensors in as few launches as
  *   possible — get_optimizers' dense groups (src/models/deepfm.py:178-193).  The five pointer arrays and numels live in
  *   HOST memory; steps[i] points at tensor i's device-side step count (a float, torch's capturable layout), read as

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mi_adam_dense_multi": [_p, _p, _p, _p, _p, _p, _i32, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_float,
                             ctypes.c_float, _p, _p],
     "mi_adam_tick": [_p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p],
+    "mi_adam_tick_multi": [_p, _p, _i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p],
     "mi_scatter_axpy_rows": [_p, _p, ctypes.c_float, _p, _i64, _i32, _i64, _p],
     "mi_tt_digits": [_p, _i64, _i64, _p, _i32, _p, _p, _p, _p],
     "mi_move_chunks": [_p, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _i32, _p],

@@ -25,10 +25,18 @@ struct AdamArgs {
 };
 
 // t += 1; step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) in double, like the host computes it in the eager path
-__global__ void k_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2) {
-  const double t = (double)step[0] + 1.0;
-  step[0] = (float)t;
-  step_size[0] = (float)(lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
+constexpr int kTickSlots = 8;
+struct TickTable {
+  float *step[kTickSlots];
+  float *step_size[kTickSlots];
+  int count;
+};
+__global__ void k_adam_tick(TickTable tt, double lr, double beta1, double beta2) {
+  const int i = threadIdx.x;
+  if (i >= tt.count) return;
+  const double t = (double)tt.step[i][0] + 1.0;
+  tt.step[i][0] = (float)t;
+  tt.step_size[i][0] = (float)(lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
 }
 
 __device__ __forceinline__ float adam1(const AdamArgs &a, float g, float &m, float &v) {
@@ -318,7 +326,24 @@ int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const
 
 int mi_adam_tick(float *step, float *step_size, double lr, double beta1, double beta2, void *stream) {
   if (!step || !step_size) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("adam_tick", k_adam_tick, 1, 1, stream, step, step_size, lr, beta1, beta2);
+  TickTable tt{};
+  tt.step[0] = step; tt.step_size[0] = step_size; tt.count = 1;
+  MI_LAUNCH("adam_tick", k_adam_tick, 1, kWave, stream, tt, lr, beta1, beta2);
+  return launch_status();
+}
+
+int mi_adam_tick_multi(float *const *steps, float *const *step_sizes, int32_t count, double lr, double beta1, double beta2,
+                       void *stream) {
+  if (count < 0 || (count > 0 && (!steps || !step_sizes))) return MI_ERR_INVALID_ARG;
+  for (int32_t first = 0; first < count; first += kTickSlots) {
+    TickTable tt{};
+    for (int32_t i = first; i < count && tt.count < kTickSlots; ++i) {
+      if (!steps[i] || !step_sizes[i]) return MI_ERR_INVALID_ARG;
+      tt.step[tt.count] = steps[i];
+      tt.step_size[tt.count++] = step_sizes[i];
+    }
+    MI_LAUNCH("adam_tick", k_adam_tick, 1, kWave, stream, tt, lr, beta1, beta2);
+  }
   return launch_status();
 }
 

@@ -55,6 +55,7 @@ class SparseAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             capturable = group.get("capturable", False)
+            todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -65,14 +66,22 @@ class SparseAdam(torch.optim.Optimizer):
                     state["step"] = torch.zeros((), dtype=torch.float32, device=dev) if capturable else 0
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                todo.append((p, dev, rows, vals, state))
+            if not todo:
+                continue
+            if capturable:          # one launch advances every table's step count and bias-corrected step size
+                for p, dev, *_ in todo:
+                    if (p, "step_size") not in self._workspace:
+                        self._workspace[(p, "step_size")] = torch.zeros(1, dtype=torch.float32, device=dev)
+                n = len(todo)
+                arr = ctypes.c_void_p * n
+                _lib.check(lib.mi_adam_tick_multi(arr(*[st["step"].data_ptr() for *_, st in todo]),
+                                                  arr(*[self._workspace[(p, "step_size")].data_ptr() for p, *_ in todo]), n,
+                                                  group["lr"], beta1, beta2, _lib.stream_ptr(todo[0][1])), "mi_adam_tick_multi")
+            for p, dev, rows, vals, state in todo:
                 stream = _lib.stream_ptr(dev)
                 if capturable:
-                    ss = self._workspace.get((p, "step_size"))
-                    if ss is None:
-                        ss = self._workspace[(p, "step_size")] = torch.zeros(1, dtype=torch.float32, device=dev)
-                    _lib.check(lib.mi_adam_tick(state["step"].data_ptr(), ss.data_ptr(), group["lr"], beta1, beta2, stream),
-                               "mi_adam_tick")
-                    step_size, step_size_dev = 0.0, ss.data_ptr()
+                    step_size, step_size_dev = 0.0, self._workspace[(p, "step_size")].data_ptr()
                 else:
                     state["step"] += 1
                     t = state["step"]
