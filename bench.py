@@ -253,7 +253,10 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
-        one = torch.ones((), device=dev)          # d(loss)/d(loss): without it every backward() fills a fresh scalar
+        from recsys_benchmark_amd.losses import unit_scalar
+
+        one = unit_scalar(dev)      # d(loss)/d(loss) = 1 from a resident scalar: no fill per step, and the fused criterion
+        #                             hands back the gradient its forward already wrote
         with torch.cuda.graph(graph):
             lossf(model(x), y).backward(one)
 

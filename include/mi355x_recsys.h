@@ -337,8 +337,10 @@ MI_API int mi_colsum(const float *X, int32_t ldx, const float *rowscale, int32_t
 MI_API int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias,
                      const float *addend, float *out, int32_t M, int32_t N, void *stream);
 /* The trainer's loss on the logits (src/trainer/deepfm.py:32,51: BCEWithLogitsLoss, reduction "mean"):
- * loss[0] = mean(max(x,0) - x*y + log1p(exp(-|x|)));  dx = g[0]*(sigmoid(x) - y)/n.  One launch each way. */
-MI_API int mi_bce_logits_fwd(const float *x, const float *y, float *loss, int64_t n, void *stream);
+ * loss[0] = mean(max(x,0) - x*y + log1p(exp(-|x|)));  dx = g[0]*(sigmoid(x) - y)/n.  One launch each way; dx_unit
+ * (nullable, [n]): the forward also writes dx for g = 1, so a backward seeded with 1 has nothing to launch. */
+MI_API int mi_bce_logits_fwd(const float *x, const float *y, float *loss, float *dx_unit, int64_t n,
+                             void *stream);
 MI_API int mi_bce_logits_bwd(const float *x, const float *y, const float *g, float *dx, int64_t n,
                              void *stream);
 MI_API int mi_outer(const float *g, const float *w, float *out, int32_t M, int32_t N,

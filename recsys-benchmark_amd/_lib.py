@@ -44,7 +44,7 @@ SIGNATURES = {
     "mi_cross_bwd_pre": [_p, _p, _p, _p, _p, _i64, _i32, _p],
     "mi_colsum": [_p, _i32, _p, _i32, _p, _p, _i32, _i32, _p],
     "mi_rowdot": [_p, _i32, _p, _p, _p, _p, _i32, _i32, _p],
-    "mi_bce_logits_fwd": [_p, _p, _p, _i64, _p],
+    "mi_bce_logits_fwd": [_p, _p, _p, _p, _i64, _p],
     "mi_bce_logits_bwd": [_p, _p, _p, _p, _i64, _p],
     "mi_outer": [_p, _p, _p, _i32, _i32, _p],
     "mi_mix_gate_bwd": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p],

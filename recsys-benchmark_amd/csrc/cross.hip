@@ -128,13 +128,18 @@ __global__ __launch_bounds__(kBlock) void k_mix_gate_bwd(const float *__restrict
 
 // mean_i [ max(x,0) - x*y + log1p(exp(-|x|)) ]  (torch's numerically stable binary_cross_entropy_with_logits,
 // reduction="mean"); ONE workgroup so the reduction needs no atomics and no zeroed target.
+// dx_unit (optional): the gradient for an upstream gradient of exactly 1, (sigmoid(x) - y)/n in the backward kernel's own
+// arithmetic — when the criterion is the last op of the step the backward pass then has nothing left to launch
 __global__ __launch_bounds__(1024) void k_bce_logits_fwd(const float *__restrict__ x, const float *__restrict__ y,
-                                                         float *__restrict__ loss, int64_t n) {
+                                                         float *__restrict__ loss, float *__restrict__ dx_unit,
+                                                         int64_t n) {
   __shared__ float part[16];
   float s = 0.f;
+  const float sc = 1.f / (float)n;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const float xv = x[i];
-    s += fmaxf(xv, 0.f) - xv * y[i] + log1pf(expf(-fabsf(xv)));
+    const float xv = x[i], yv = y[i];
+    s += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+    if (dx_unit) dx_unit[i] = sc * (1.f / (1.f + expf(-xv)) - yv);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -198,9 +203,9 @@ int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias, co
   return launch_status();
 }
 
-int mi_bce_logits_fwd(const float *x, const float *y, float *loss, int64_t n, void *stream) {
+int mi_bce_logits_fwd(const float *x, const float *y, float *loss, float *dx_unit, int64_t n, void *stream) {
   if (n <= 0 || !x || !y || !loss) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("bce_logits_fwd", k_bce_logits_fwd, 1, 1024, stream, x, y, loss, n);
+  MI_LAUNCH("bce_logits_fwd", k_bce_logits_fwd, 1, 1024, stream, x, y, loss, dx_unit, n);
   return launch_status();
 }
 

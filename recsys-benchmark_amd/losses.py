@@ -11,6 +11,19 @@ from torch import nn
 from . import _kernels, _lib
 
 
+_unit: dict = {}
+
+
+def unit_scalar(device) -> torch.Tensor:
+    """A resident, read-only fp32 scalar 1 per device: `loss.backward(unit_scalar(dev))` seeds a backward without a fill
+    launch, and the fused criterion recognises it (its gradient for an upstream 1 was already written by its forward)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _unit:
+        _unit[key] = torch.ones((), dtype=torch.float32, device=torch.device("cuda", key))
+    return _unit[key]
+
+
 class _BCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
@@ -20,15 +33,19 @@ class _BCEFn(torch.autograd.Function):
         if x.numel() != y.numel():
             raise ValueError("logits and target must have the same number of elements")
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().mi_bce_logits_fwd(x.data_ptr(), y.data_ptr(), loss.data_ptr(), x.numel(),
+        # the gradient for an upstream gradient of 1 comes out of the same launch (16 KB at B = 4096)
+        dx_unit = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.load().mi_bce_logits_fwd(x.data_ptr(), y.data_ptr(), loss.data_ptr(), _lib.ptr(dx_unit), x.numel(),
                                                  _lib.stream_ptr(dev)), "mi_bce_logits_fwd")
-        ctx.save_for_backward(x, y)
+        ctx.save_for_backward(x, y, *([dx_unit] if dx_unit is not None else []))
         ctx.shape = tuple(logits.shape)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
-        x, y = ctx.saved_tensors
+        x, y, *rest = ctx.saved_tensors
+        if rest and g.data_ptr() == unit_scalar(x.device).data_ptr():
+            return rest[0].view(ctx.shape), None          # seeded with the resident 1: nothing to launch
         g = _kernels._f32c(g).view(1)
         dx = torch.empty_like(x)
         _lib.check(_lib.load().mi_bce_logits_bwd(x.data_ptr(), y.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(),

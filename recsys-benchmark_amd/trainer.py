@@ -101,7 +101,7 @@ class GraphedTrainStep:
         if self.loss_sum is None:
             self.loss_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
             self.extra_sum = torch.zeros((), dtype=torch.float32, device=inputs.device)
-            self._one = torch.ones((), dtype=torch.float32, device=inputs.device)
+            self._one = losses.unit_scalar(inputs.device)
         self.steps += 1
         shape = (tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype)
         if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:
@@ -310,7 +310,7 @@ class GraphedCFTrainStep:
     def __call__(self, users, pos_items, neg_items) -> torch.Tensor:
         if self.sums is None:
             self.sums = torch.zeros(4, dtype=torch.float32, device=users.device)
-            self._one = torch.ones((), dtype=torch.float32, device=users.device)
+            self._one = losses.unit_scalar(users.device)
         self.steps += 1
         shape = (tuple(users.shape), users.dtype)
         if self.use_graph and self._graph is None and self._seen >= self.warmup and self._shape == shape:

@@ -176,3 +176,31 @@ def test_tail_last_add_is_fused_and_differentiable():
     assert_close(out, ref, 1e-5, 1e-5)
     out.sum().backward()
     assert_close(a.grad, torch.ones(50), 0, 0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 5000])
+def test_bce_with_logits_matches_torch_and_the_unit_seed_shortcut(n):
+    """losses.BCEWithLogitsLoss == torch.nn.BCEWithLogitsLoss (value and gradient); a backward seeded with the resident
+    unit scalar returns the gradient the forward already wrote — bit-identical to the backward kernel's."""
+    from recsys_benchmark_amd.losses import BCEWithLogitsLoss, unit_scalar
+
+    gen = torch.Generator().manual_seed(n)
+    z = (torch.randn(n, generator=gen) * 4).requires_grad_(True)
+    y = (torch.rand(n, generator=gen) < 0.4).float()
+    ref = torch.nn.BCEWithLogitsLoss()(z, y)
+    (ref * 3.0).backward()
+    dev = torch.device("cuda", 0)
+    crit = BCEWithLogitsLoss()
+    a = z.detach().to(dev).requires_grad_(True)
+    out = crit(a, y.to(dev))
+    (out * 3.0).backward()                                  # an arbitrary upstream gradient: the backward kernel
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(a.grad.cpu(), z.grad, rtol=1e-5, atol=1e-8)
+    b = z.detach().to(dev).requires_grad_(True)
+    crit(b, y.to(dev)).backward(unit_scalar(dev))           # the shortcut
+    c = z.detach().to(dev).requires_grad_(True)
+    crit(c, y.to(dev)).backward(torch.ones((), device=dev))  # same value, another tensor: the kernel
+    assert torch.equal(b.grad, c.grad)
+    # no gradient wanted: the forward skips the extra output
+    with torch.no_grad():
+        assert torch.equal(crit(b.detach(), y.to(dev)), out.detach())
