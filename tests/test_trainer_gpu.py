@@ -349,5 +349,8 @@ def test_dcn_with_row_form_gradients_trains_like_torch_optimizers(cls_name):
         for o in theirs:
             o.step()
     assert hits == 5, "the ids' field layout was not found for the optimizer's sort"
+    # five Adam steps (lr 1e-2) apart; the cross network's weight gradients are split-K sums with float atomics, whose
+    # last-bit freedom Adam amplifies where a gradient is almost zero (seen: 5e-5 on 2 of 10 080 elements in one run of
+    # ten) — 2e-4 is 2 % of one step, a wrong sort or a stale buffer would be off by whole steps
     for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
-        assert_close(a, b, 1e-3, 2e-5, k)
+        assert_close(a, b, 5e-3, 2e-4, k)
