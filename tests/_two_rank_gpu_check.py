@@ -99,11 +99,11 @@ def main():
             o.step()
     n = local_num_rows(N, rank, world)
     torch.testing.assert_close(trainee.embedding_shard[:n], shard_rows(ref.embedding.get_weight().detach(), rank, world),
-                               rtol=1e-3, atol=2e-5, msg=lambda m: f"table after training: {m}")
-    torch.testing.assert_close(trainee.fc_shard[:n], shard_rows(ref.fc.weight.detach(), rank, world), rtol=1e-3, atol=2e-5,
+                               rtol=5e-3, atol=1e-4, msg=lambda m: f"table after training: {m}")
+    torch.testing.assert_close(trainee.fc_shard[:n], shard_rows(ref.fc.weight.detach(), rank, world), rtol=5e-3, atol=1e-4,
                                msg=lambda m: f"first-order table after training: {m}")
     for (k, p_), (_, q_) in zip(trainee._deep_branch.named_parameters(), ref._deep_branch.named_parameters()):
-        torch.testing.assert_close(p_, q_, rtol=1e-3, atol=2e-5, msg=lambda m: f"{k} after training: {m}")
+        torch.testing.assert_close(p_, q_, rtol=5e-3, atol=1e-4, msg=lambda m: f"{k} after training: {m}")
     trainee.check_overflow()
     pkg.check_index_errors()
     torch.cuda.synchronize()

@@ -94,11 +94,11 @@ def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphe
             o.step()
     N = sum(dims)
     # six Adam steps apart: the usual amplification of last-bit differences where a gradient is almost zero
-    assert_close(sh.embedding_shard[:N], ref.embedding.get_weight(), 1e-3, 2e-5, "table")
-    assert_close(sh.fc_shard[:N], ref.fc.weight, 1e-3, 2e-5, "first-order table")
+    assert_close(sh.embedding_shard[:N], ref.embedding.get_weight(), 5e-3, 1e-4, "table")
+    assert_close(sh.fc_shard[:N], ref.fc.weight, 5e-3, 1e-4, "first-order table")
     assert not sh.embedding_shard[N].any() and not sh.fc_shard[N].any(), "the sink row moved"
     for (k, p), (_, q) in zip(sh._deep_branch.named_parameters(), ref._deep_branch.named_parameters()):
-        assert_close(p, q, 1e-3, 2e-5, k)
+        assert_close(p, q, 5e-3, 1e-4, k)
     pkg.check_index_errors()
 
 

