@@ -64,9 +64,12 @@ def test_fused_bn_relu_vs_cpu_modules(M, N, bn, training):
     (y * G.to(DEV)).sum().backward()
     assert_mostly_close(z2.grad, z1.grad, 1e-4, 2e-5, 1e-4, "dz")
     if bn:
+        # column sums of M terms of size ~|G||z_hat| that largely cancel, added in a run-dependent order (float atomics):
+        # the error scales with sum|terms| (~1e4 at M = 4096), not with the result — 4e-4 of the largest column sum
+        # (1.2e-4 was seen once in ~25 runs)
         s = max(1.0, float(ref_bn.weight.grad.abs().max()))
-        assert_close(gamma.grad, ref_bn.weight.grad, 1e-4, 1e-4 * s, "dgamma")
-        assert_close(beta.grad, ref_bn.bias.grad, 1e-4, 1e-4 * s, "dbeta")
+        assert_close(gamma.grad, ref_bn.weight.grad, 1e-4, 4e-4 * s, "dgamma")
+        assert_close(beta.grad, ref_bn.bias.grad, 1e-4, 4e-4 * s, "dbeta")
         assert_close(rm, ref_bn.running_mean, 1e-5, 1e-6, "running_mean")
         assert_close(rv, ref_bn.running_var, 1e-5, 1e-6, "running_var")
 
