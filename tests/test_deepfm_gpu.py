@@ -170,14 +170,15 @@ def test_vanilla_embedding_lookup_and_grad(n, N, D, shape2d):
     (out * G.to(DEV)).sum().backward()
     Wc = W.detach().cpu().requires_grad_(True)
     (torch.nn.functional.embedding(idx, Wc) * G).sum().backward()
-    assert_close(W.grad, Wc.grad, 1e-5, 1e-5, "dense scatter-add")
+    # hot rows sum ~150 unit-size terms in a run-dependent order (float atomics): the error follows sum|terms|, not the result
+    assert_close(W.grad, Wc.grad, 1e-5, 1e-4, "dense scatter-add")
     semb = pkg.VanillaEmbedding(N, D, sparse=True).to(DEV)
     out = semb(idx.to(DEV))
     (out * G.to(DEV)).sum().backward()
     assert semb.get_weight().grad.is_sparse
     Wc2 = semb.get_weight().detach().cpu().requires_grad_(True)
     (torch.nn.functional.embedding(idx, Wc2) * G).sum().backward()
-    assert_close(semb.get_weight().grad, Wc2.grad, 1e-5, 1e-5, "row-form grad")
+    assert_close(semb.get_weight().grad, Wc2.grad, 1e-5, 1e-4, "row-form grad")
 
 
 @pytest.mark.parametrize("mode", ["sum", "mean", "max"])
