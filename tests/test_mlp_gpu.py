@@ -68,8 +68,12 @@ def test_fused_bn_relu_vs_cpu_modules(M, N, bn, training):
         # the error scales with sum|terms| (~1e4 at M = 4096), not with the result — 4e-4 of the largest column sum
         # (1.2e-4 was seen once in ~25 runs)
         s = max(1.0, float(ref_bn.weight.grad.abs().max()))
-        assert_close(gamma.grad, ref_bn.weight.grad, 1e-4, 4e-4 * s, "dgamma")
-        assert_close(beta.grad, ref_bn.bias.grad, 1e-4, 4e-4 * s, "dbeta")
+        # ... and a pre-activation within rounding of 0 may land on either side of the ReLU kink (the batch statistics
+        # themselves are float-atomic sums): that element's whole term then moves in ITS column's sums — seen on one
+        # element of the (4096, 400) case in ~3 of 80 runs — so, as for y and dz, a column or two may disagree
+        flips = 2.0 / N if M * N >= 100000 else 0.0
+        assert_mostly_close(gamma.grad, ref_bn.weight.grad, 1e-4, 4e-4 * s, flips, "dgamma")
+        assert_mostly_close(beta.grad, ref_bn.bias.grad, 1e-4, 4e-4 * s, flips, "dbeta")
         assert_close(rm, ref_bn.running_mean, 1e-5, 1e-6, "running_mean")
         assert_close(rv, ref_bn.running_var, 1e-5, 1e-6, "running_var")
 
