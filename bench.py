@@ -116,6 +116,37 @@ def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
                       "oracle/reference_ops.py deepfm_forward on torch CPU, dense weight.grad as the reference"}
 
 
+def self_launch(n):
+    """Parent of an N-rank run: start `torch.distributed.run` as a CHILD process (never exec: see the GPU-box rules), one
+    rank per device, rendezvous on 127.0.0.1; forward the ranks' stderr, print exactly rank 0's JSON line on stdout and
+    return the launcher's exit code (non-zero when any rank failed or no line was produced)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +161,14 @@ def main():
     ap.add_argument("--c4", action="store_true", help="BASELINE config 4: the same 26 fields with the largest one scaled so that "
                     "the table has 1e9 rows (64 GB fp32); row-sharded model (implies --sharded)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
+    ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
+                    "all-reduce and rank 0 prints a JSON line with no measurement in it (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` with no launcher around it: this process has made no GPU call yet, so it
+        # only starts N fresh rank processes (one per device), relays rank 0's JSON line and exits with their code
+        raise SystemExit(self_launch(args.gpus))
 
     # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
     # on stdout, so everything before the final print goes to stderr.
@@ -140,7 +178,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_launch:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        dist.destroy_process_group()
+        if os.environ.get("MI_BENCH_DRY_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            os.dup2(real_stdout, 1)
+            print(json.dumps({"metric": "dry-launch (no measurement)", "value": None, "n_gpus": world,
+                              "joined_ranks": int(t.item())}), flush=True)
+        return
     import torch.distributed as dist
 
     # Rehearsal knobs (NOT a measurement mode): MI_BENCH_REHEARSE=1 runs N ranks on ONE GPU with gloo carrying the
@@ -158,6 +210,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # how many ranks the collective backend really joins: every rank adds 1 through an all-reduce
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        collective_ranks = int(ones.item())
+        if collective_ranks != world:
+            raise SystemExit(f"all-reduce over {dist.get_backend()} joined {collective_ranks} ranks, expected {world}")
 
     import recsys_benchmark_amd as pkg
     from recsys_benchmark_amd import mlp as _mlp
@@ -335,6 +394,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": (collective_ranks if (sharded and not rehearse) else None),
+            "collective_backend": (dist.get_backend() if sharded else None),
             "launch": "hipGraph replay" if use_graph else ("eager RCCL collectives + one hipGraph for the local compute"
                                                            if (sharded and graphed_local) else "eager"),
             "config": {"workload": f"{'C4' if args.c4 else 'C2'} DeepFM Criteo-26field full embedding: F={F}, D={D}, N={sum(dims)} rows, "

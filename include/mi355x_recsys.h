@@ -463,6 +463,9 @@ MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha,
  *   bwd: dU[ui[b]] += c_b (p_b - n_b), dP[pi[b]] += c_b u_b, dN[ni[b]] -= c_b u_b, c_b = -g sig[b] / B
  *   (float atomics into caller-zeroed dense gradients when the index array is given, stores otherwise;
  *   any of dU/dP/dN may be NULL).  workspace: mi_bpr_workspace_elems(B) floats.
+ *   nU/nP/nN = rows of U/P/Nn: a triple with an index outside its table touches no memory, counts as
+ *   u = p = n = 0 forward, adds nothing backward, and ORs MI_IDX_OUT_OF_RANGE into *err (the
+ *   reference's index_select raises: src/trainer/lightgcn.py:395-397).  Same for mi_rowsq_*.
  * mi_mask_topk_rows: src/trainer/lightgcn.py:122-138: for row b (user users[b], or b if NULL)
  *   scores[b, col[crow[u] .. crow[u+1])] = -inf (in place; crow may be NULL = no mask), then the
  *   indices (and optionally values) of the k largest entries, score descending, ties by ascending
@@ -472,18 +475,19 @@ MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha,
  *   bwd: dU[ui[b]] += g U[ui[b]] / B (and likewise dP, dN; float atomics, caller-zeroed, nullable).
  *   workspace: mi_bpr_workspace_elems(B) floats.                                                      */
 MI_API int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
-                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, float *workspace,
-                        float *out, void *stream);
+                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                        int64_t nN, int32_t *err, float *workspace, float *out, void *stream);
 MI_API int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
-                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, const float *g,
-                        float *dU, float *dP, float *dN, void *stream);
+                        const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                        int64_t nN, const float *g, float *dU, float *dP, float *dN, void *stream);
 MI_API int64_t mi_bpr_workspace_elems(int64_t B);
 MI_API int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
-                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, float *sig,
-                      float *workspace, float *loss, void *stream);
+                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                      int64_t nN, int32_t *err, float *sig, float *workspace, float *loss, void *stream);
 MI_API int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
-                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, const float *sig,
-                      const float *g, float *dU, float *dP, float *dN, void *stream);
+                      const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                      int64_t nN, const float *sig, const float *g, float *dU, float *dP, float *dN,
+                      void *stream);
 MI_API int mi_mask_topk_rows(float *scores, int64_t ld, int64_t nrows, int64_t ncol,
                              const int64_t *users, const int64_t *crow, const int64_t *col, int32_t k,
                              int64_t *out_idx, float *out_val, void *stream);

@@ -417,6 +417,10 @@ class CsrPlan:
         self.shape = (n_rows, n_cols)
         self.nnz = nnz
         dev = crow.device
+        # the plan is cached under the ADDRESSES of the caller's index tensors (csr_plan): keep them alive so that no
+        # other graph's indices can be allocated there while the entry exists
+        self.src_crow, self.src_col = crow, col
+        self.src_versions = (crow._version, col._version)
         self.crow = crow.to(torch.int32).contiguous()
         self.col = col.to(torch.int32).contiguous()
         deg = (crow[1:] - crow[:-1])
@@ -443,19 +447,26 @@ class CsrPlan:
         return (torch.nonzero(~hub).flatten().to(torch.int32).contiguous(),
                 torch.nonzero(hub).flatten().to(torch.int32).contiguous())
 
+    @staticmethod
+    def _same_values(kept, kept_version, val) -> bool:
+        """True when `val` is provably the tensor the cache was filled from.  The cache keeps a strong reference to
+        that tensor, so its address cannot be handed to a new allocation while it is the key (a SparseDropout draw
+        freed and re-allocated at the same address must miss); a tensor at the same address with the same size and
+        version counter is then the kept tensor itself or a view / detach of it."""
+        return (kept is not None and val.data_ptr() == kept.data_ptr() and val.numel() == kept.numel()
+                and val.dtype == kept.dtype and val._version == kept_version)
+
     def transposed_values(self, val: torch.Tensor) -> torch.Tensor:
         if self.pattern_symmetric:
-            key = (val.data_ptr(), val._version)
-            if key != self._sym_vals_key:
+            if not self._same_values(self._sym_vals_key, self.__dict__.get("_sym_vals_version"), val):
                 self._sym_vals = bool(torch.equal(val.index_select(0, self.perm), val))
-                self._sym_vals_key = key
+                self._sym_vals_key, self._sym_vals_version = val, val._version
             if self._sym_vals:
                 return val
         # the adjacency values are constants between SparseDropout draws: permute them once per tensor version
-        key = (val.data_ptr(), val._version, val.numel())
-        if key != self.__dict__.get("_tv_key"):
+        if not self._same_values(self.__dict__.get("_tv_src"), self.__dict__.get("_tv_version"), val):
             self._tv = val.index_select(0, self.perm)
-            self._tv_key = key
+            self._tv_src, self._tv_version = val, val._version
         return self._tv
 
 
@@ -466,6 +477,8 @@ def csr_plan(matrix: torch.Tensor) -> CsrPlan:
     crow, col = matrix.crow_indices(), matrix.col_indices()
     key = (crow.data_ptr(), col.data_ptr(), col.numel(), tuple(matrix.shape), str(crow.device))
     plan = _plans.get(key)
+    if plan is not None and (plan.src_versions != (crow._version, col._version)):
+        plan = None     # the index tensors were written in place since the plan was built
     if plan is None:
         if len(_plans) > 16:
             _plans.clear()

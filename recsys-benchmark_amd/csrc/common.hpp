@@ -62,12 +62,15 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
 // "last workgroup sums the partials" without agent-scope fences (on gfx950 a __threadfence() is an L2 write-back +
-// invalidate per workgroup: the loss kernels took 13 us with it): the partial travels as a device-scope (sc1) atomic
-// store, a workgroup-scope release drains it (s_waitcnt) before the ticket is taken, and the last workgroup reads the
-// partials with sc1 atomic loads — everything meets at the coherence point behind the per-XCD L2s.
+// invalidate per workgroup: the loss kernels took 13 us with it).  ONE lane per workgroup publishes: the partial travels
+// as a device-scope (sc1, write-through) store, an explicit `s_waitcnt vmcnt(0)` holds the lane until that store has
+// been acknowledged by the coherence point behind the per-XCD L2s, and only then is the ticket taken (a workgroup-scope
+// fence emits NO wait between the store and the atomic — checked in the .s — so the two, at different addresses, could
+// be observed out of order).  The workgroup whose ticket came back last reads the partials with sc1 loads after its
+// atomic has returned, behind a workgroup barrier (MI355X_MICROARCH.md, hand-offs measured with sc1 loads, row 1).
 __device__ __forceinline__ void publish_partial(float *part, unsigned *ticket, float s, bool &last) {
   __hip_atomic_store(part + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
 }
 __device__ __forceinline__ float read_partial(const float *p) {

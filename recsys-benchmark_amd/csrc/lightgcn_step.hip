@@ -15,6 +15,16 @@
 namespace {
 using namespace mi;
 
+// row counts of the three tables the index arrays address, and the sticky error word (common convention of the lookups:
+// an out-of-range id never touches memory, it is skipped and MI_IDX_OUT_OF_RANGE is OR-ed into *err)
+struct RowBounds {
+  int64_t nU, nP, nN;
+  int *err;
+  __device__ __forceinline__ bool ok(int64_t u, int64_t p, int64_t n) const {
+    return (uint64_t)u < (uint64_t)nU && (uint64_t)p < (uint64_t)nP && (uint64_t)n < (uint64_t)nN;
+  }
+};
+
 __device__ __forceinline__ float softplus(float x) {   // log(1 + e^x), stable
   return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
 }
@@ -25,26 +35,31 @@ __device__ __forceinline__ float softplus(float x) {   // log(1 + e^x), stable
 __global__ __launch_bounds__(kBlock) void k_bpr_fwd(
     const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
     const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
-    int64_t B, int D, float *__restrict__ sig, float *__restrict__ part, unsigned *ticket,
+    int64_t B, int D, RowBounds nb, float *__restrict__ sig, float *__restrict__ part, unsigned *ticket,
     float *__restrict__ loss) {
   __shared__ float red[kWavesPerBlock];
   __shared__ bool last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float acc = 0.f;
+  bool bad = false;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t b = wave0; b < B; b += nwaves) {
-    const float *u = U + (ui ? ui[b] : b) * D;
-    const float *p = P + (pi ? pi[b] : b) * D;
-    const float *q = Nn + (ni ? ni[b] : b) * D;
+    const int64_t ur = ui ? ui[b] : b, pr = pi ? pi[b] : b, nr = ni ? ni[b] : b;
     float d = 0.f;
-    for (int j = lane; j < D; j += kWave) d += u[j] * (p[j] - q[j]);
+    if (nb.ok(ur, pr, nr)) {               // an out-of-range triple reads nothing and counts as u = p = n = 0
+      const float *u = U + ur * D, *p = P + pr * D, *q = Nn + nr * D;
+      for (int j = lane; j < D; j += kWave) d += u[j] * (p[j] - q[j]);
+    } else {
+      bad = true;
+    }
     d = wave_sum(d);                       // y_pos - y_neg
     if (lane == 0) {
       sig[b] = 1.f / (1.f + expf(d));      // sigmoid(-d) = -dL_b/dd
       acc += softplus(-d);                 // -logsigmoid(d)
     }
   }
+  if (bad && lane == 0 && nb.err) atomicOr(nb.err, MI_IDX_OUT_OF_RANGE);
   if (lane == 0) red[wv] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_bpr_fwd(
 __global__ __launch_bounds__(kBlock) void k_bpr_bwd(
     const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
     const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
-    int64_t B, int D, const float *__restrict__ sig, const float *__restrict__ g,
+    int64_t B, int D, RowBounds nb, const float *__restrict__ sig, const float *__restrict__ g,
     float *__restrict__ dU, float *__restrict__ dP, float *__restrict__ dN) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -81,6 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_bpr_bwd(
   const float scale = -g[0] / (float)B;
   for (int64_t b = wave0; b < B; b += nwaves) {
     const int64_t ur = ui ? ui[b] : b, pr = pi ? pi[b] : b, nr = ni ? ni[b] : b;
+    if (!nb.ok(ur, pr, nr)) continue;      // flagged by the forward; nothing is read or added out of bounds
     const float c = scale * sig[b];
     for (int j = lane; j < D; j += kWave) {
       const float u = U[ur * D + j], p = P[pr * D + j], q = Nn[nr * D + j];
@@ -98,17 +114,21 @@ __global__ __launch_bounds__(kBlock) void k_bpr_bwd(
 __global__ __launch_bounds__(kBlock) void k_rowsq_fwd(
     const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
     const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
-    int64_t B, int D, float *__restrict__ part, unsigned *ticket, float *__restrict__ out) {
+    int64_t B, int D, RowBounds nb, float *__restrict__ part, unsigned *ticket, float *__restrict__ out) {
   __shared__ float red[kWavesPerBlock];
   __shared__ bool last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float acc = 0.f;
+  bool bad = false;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t b = wave0; b < B; b += nwaves) {
-    const float *u = U + ui[b] * D, *p = P + pi[b] * D, *q = Nn + ni[b] * D;
+    const int64_t ur = ui[b], pr = pi[b], nr = ni[b];
+    if (!nb.ok(ur, pr, nr)) { bad = true; continue; }
+    const float *u = U + ur * D, *p = P + pr * D, *q = Nn + nr * D;
     for (int j = lane; j < D; j += kWave) acc += u[j] * u[j] + p[j] * p[j] + q[j] * q[j];
   }
+  if (bad && lane == 0 && nb.err) atomicOr(nb.err, MI_IDX_OUT_OF_RANGE);
   acc = wave_sum(acc);
   if (lane == 0) red[wv] = acc;
   __syncthreads();
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_rowsq_fwd(
 __global__ __launch_bounds__(kBlock) void k_rowsq_bwd(
     const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
     const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
-    int64_t B, int D, const float *__restrict__ g, float *__restrict__ dU, float *__restrict__ dP,
+    int64_t B, int D, RowBounds nb, const float *__restrict__ g, float *__restrict__ dU, float *__restrict__ dP,
     float *__restrict__ dN) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -144,6 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_rowsq_bwd(
   const float c = g[0] / (float)B;          // d/dw of w^2 / (2B) = w / B
   for (int64_t b = wave0; b < B; b += nwaves) {
     const int64_t ur = ui[b], pr = pi[b], nr = ni[b];
+    if (!nb.ok(ur, pr, nr)) continue;
     for (int j = lane; j < D; j += kWave) {
       if (dU) atomicAdd(dU + ur * D + j, c * U[ur * D + j]);
       if (dP) atomicAdd(dP + pr * D + j, c * P[pr * D + j]);
@@ -311,47 +332,54 @@ int64_t mi_bpr_workspace_elems(int64_t B) {
 }
 
 int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
-               const int64_t *ni, int64_t B, int32_t D, float *sig, float *workspace, float *loss,
-               void *stream) {
+               const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+               float *sig, float *workspace, float *loss, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if ((!ui && nU < B) || (!pi && nP < B) || (!ni && nN < B)) return MI_ERR_INVALID_ARG;
+  const RowBounds nb{nU, nP, nN, err};
   if (!U || !P || !Nn || !sig || !workspace || !loss) return MI_ERR_INVALID_ARG;
   const int grid = grid_for_waves(B);
   // workspace[grid] is the ticket: zeroed here once per call (captured as a memset node in a graph)
   if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
-  MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, sig, workspace,
+  MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace,
             reinterpret_cast<unsigned *>(workspace + grid), loss);
   return launch_status();
 }
 
 int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
-               const int64_t *ni, int64_t B, int32_t D, const float *sig, const float *g, float *dU,
-               float *dP, float *dN, void *stream) {
+               const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, const float *sig,
+               const float *g, float *dU, float *dP, float *dN, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if ((!ui && nU < B) || (!pi && nP < B) || (!ni && nN < B)) return MI_ERR_INVALID_ARG;
+  const RowBounds nb{nU, nP, nN, nullptr};
   if (!U || !P || !Nn || !sig || !g) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("bpr_bwd", k_bpr_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, sig, g,
+  MI_LAUNCH("bpr_bwd", k_bpr_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, g,
             dU, dP, dN);
   return launch_status();
 }
 
 int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
-                 const int64_t *ni, int64_t B, int32_t D, float *workspace, float *out, void *stream) {
+                 const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+                 float *workspace, float *out, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  const RowBounds nb{nU, nP, nN, err};
   if (!U || !P || !Nn || !ui || !pi || !ni || !workspace || !out) return MI_ERR_INVALID_ARG;
   const int grid = grid_for_waves(B);
   if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
-  MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, workspace,
+  MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, workspace,
             reinterpret_cast<unsigned *>(workspace + grid), out);
   return launch_status();
 }
 
 int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
-                 const int64_t *ni, int64_t B, int32_t D, const float *g, float *dU, float *dP, float *dN,
-                 void *stream) {
+                 const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, const float *g,
+                 float *dU, float *dP, float *dN, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  const RowBounds nb{nU, nP, nN, nullptr};
   if (!U || !P || !Nn || !ui || !pi || !ni || !g) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("rowsq_bwd", k_rowsq_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, g, dU, dP, dN);
+  MI_LAUNCH("rowsq_bwd", k_rowsq_bwd, grid_for_waves(B), kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, g, dU, dP, dN);
   return launch_status();
 }
 

@@ -78,7 +78,8 @@ class _BPRFn(torch.autograd.Function):
         ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         _lib.check(lib.mi_bpr_fwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
-                                  _lib.ptr(idx[2]), B, D, sig.data_ptr(), ws.data_ptr(), loss.data_ptr(),
+                                  _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
+                                  _lib.err_word(dev).data_ptr(), sig.data_ptr(), ws.data_ptr(), loss.data_ptr(),
                                   _lib.stream_ptr(dev)), "mi_bpr_fwd")
         ctx.save_for_backward(U, P, Nn, sig, *[i for i in idx if i is not None])
         ctx.has_idx = [i is not None for i in idx]
@@ -97,7 +98,8 @@ class _BPRFn(torch.autograd.Function):
             # rows repeat under an index array: the kernel accumulates with atomics into zeros
             grads.append(None if not need else (torch.zeros_like(t) if i is not None else torch.empty_like(t)))
         _lib.check(_lib.load().mi_bpr_bwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
-                                          _lib.ptr(idx[2]), B, D, sig.data_ptr(), g.data_ptr(), _lib.ptr(grads[0]),
+                                          _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
+                                          sig.data_ptr(), g.data_ptr(), _lib.ptr(grads[0]),
                                           _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.stream_ptr(U.device)),
                    "mi_bpr_bwd")
         return grads[0], grads[1], grads[2], None, None, None
@@ -130,7 +132,8 @@ class _RowSqFn(torch.autograd.Function):
         ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
         _lib.check(lib.mi_rowsq_fwd(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(), ni.data_ptr(),
-                                    B, D, ws.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
+                                    B, D, U.shape[0], P.shape[0], Nn.shape[0], _lib.err_word(dev).data_ptr(),
+                                    ws.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
         ctx.save_for_backward(U, P, Nn, ui, pi, ni)
         return out.view(())
 
@@ -143,7 +146,8 @@ class _RowSqFn(torch.autograd.Function):
         dP = torch.zeros_like(P) if (ctx.needs_input_grad[1] or (same and ctx.needs_input_grad[2])) else None
         dN = dP if same else (torch.zeros_like(Nn) if ctx.needs_input_grad[2] else None)
         _lib.check(_lib.load().mi_rowsq_bwd(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(),
-                                            ni.data_ptr(), ui.numel(), U.shape[1], g.data_ptr(), _lib.ptr(dU),
+                                            ni.data_ptr(), ui.numel(), U.shape[1], U.shape[0], P.shape[0], Nn.shape[0],
+                                            g.data_ptr(), _lib.ptr(dU),
                                             _lib.ptr(dP), _lib.ptr(dN), _lib.stream_ptr(g.device)), "mi_rowsq_bwd")
         # one buffer holds both item contributions when the tables coincide: hand it to the first, nothing to the second
         return dU, dP, (None if same else dN), None, None, None

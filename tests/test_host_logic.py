@@ -203,3 +203,42 @@ def test_adam_subclass_on_cpu_parameters_is_plain_torch_adam():
         b.step()
     assert torch.equal(p, q)
     assert Adam([{"params": [torch.nn.Parameter(torch.zeros(2))], "lr": 0.1}]).param_groups[0]["lr"] == 0.1
+
+
+def test_csr_plan_caches_never_serve_a_recycled_address():
+    """CsrPlan.transposed_values / csr_plan are keyed on tensor addresses: consecutive SparseDropout draws (each a new
+    tensor, typically at the address the previous one freed) must each get their own permuted values, and a second
+    graph of the same shape allocated where a dead one lived must get its own plan."""
+    from recsys_benchmark_amd import _kernels as K
+    from recsys_benchmark_amd.layers import SparseDropout
+
+    torch.manual_seed(0)
+    n = 120
+
+    def graph(seed):
+        g = torch.Generator().manual_seed(seed)
+        a = (torch.rand(n, n, generator=g) < 0.06).float()
+        a = ((a + a.t()) > 0).float() * torch.rand(n, n, generator=g)
+        return a.to_sparse_csr()
+
+    csr = graph(1)
+    plan = K.csr_plan(csr)
+    drop = SparseDropout(0.5).train()
+    for _ in range(10):
+        d = drop(csr)
+        v = d.values()
+        assert torch.equal(plan.transposed_values(v), v.index_select(0, plan.perm))
+        del d, v
+    # same tensor again -> served from the cache (identity), in-place edit -> recomputed
+    v = csr.values().clone()
+    t1 = plan.transposed_values(v)
+    assert plan.transposed_values(v) is t1
+    v.mul_(2.0)
+    assert torch.equal(plan.transposed_values(v), v.index_select(0, plan.perm))
+    # plans keep their source index tensors alive, so a new graph cannot alias a cached key
+    K._plans.clear()
+    for seed in range(2, 8):
+        g = graph(seed)
+        p = K.csr_plan(g)
+        assert torch.equal(p.crow.long(), g.crow_indices()) and torch.equal(p.col.long(), g.col_indices())
+        del g, p

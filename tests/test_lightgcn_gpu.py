@@ -139,3 +139,26 @@ def test_lightgcn_with_sparse_dropout_and_qr_tables_runs_and_backprops():
     (ue.sum() + ie.sum()).backward()
     assert model.user_emb_table.emb1.weight.grad is not None
     _lib.check_index_errors()
+
+
+def test_consecutive_dropout_draws_use_their_own_transposed_values():
+    """Every SparseDropout draw is a fresh value tensor that the allocator may place at the address of the previous
+    draw: the cached A^T values must never be served for a different draw (gradient vs the oracle on 6 draws)."""
+    from recsys_benchmark_amd.layers import SparseDropout
+
+    adj = _random_graph(60, 80, 900, seed=11)
+    adj_d = adj.to(DEV)
+    drop = SparseDropout(0.5).train()
+    gen = torch.Generator().manual_seed(3)
+    E = torch.randn(140, 16, generator=gen)
+    G = torch.randn(140, 16, generator=gen)
+    for it in range(6):
+        drawn = drop(adj_d)                      # new values, same pattern -> same CsrPlan
+        vals = drawn.values().cpu()
+        adj_cpu = torch.sparse_csr_tensor(adj.crow_indices(), adj.col_indices(), vals, adj.shape)
+        e = E.clone().requires_grad_(True)
+        (ro.lightgcn_propagate(adj_cpu, e, 2) * G).sum().backward()
+        d = E.to(DEV).requires_grad_(True)
+        (_kernels.lightgcn_propagate(drawn, d, None, 2) * G.to(DEV)).sum().backward()
+        assert_close(d.grad, e.grad, 1e-4, 1e-5, f"draw {it}")
+        del drawn, d
