@@ -62,7 +62,8 @@ def sort_field_rows(rows_flat: torch.Tensor, N: int):
     nbytes = int(lib.mi_sort_field_rows_workspace_bytes(B, F))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=rows.device) if nbytes else None
     _lib.check(lib.mi_sort_field_rows(rows.data_ptr(), offsets.data_ptr(), N, B, F, rows_sorted.data_ptr(),
-                                      perm.data_ptr(), _lib.ptr(ws), _lib.stream_ptr(rows.device)), "mi_sort_field_rows")
+                                      perm.data_ptr(), _lib.ptr(ws), _lib.err_word(rows.device).data_ptr(),
+                                      _lib.stream_ptr(rows.device)), "mi_sort_field_rows")
     return rows_sorted, perm
 
 

@@ -57,7 +57,7 @@ SIGNATURES = {
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
                               ctypes.c_double, ctypes.c_float, _p],
     "mi_sort_field_rows_workspace_bytes": [_i64, _i32],
-    "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p],
+    "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p],
     "mi_adam_dense_multi": [_p, _p, _p, _p, _p, _p, _i32, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_float,
                             ctypes.c_float, _p, _p],
     "mi_adam_tick": [_p, _p, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p],
@@ -92,12 +92,26 @@ SIGNATURES = {
     "mi_slot_fm_fwd": [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
     "mi_prof_enable": [_i32],
+    "mi_tail_dropout_masks": [_p, _i32, _p, _p, _p, _p, _i32, _p],
+    "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _i32, _i32, _i32, _p],
+    "mi_tail_part_elems": [_i32, _i32],
+    "mi_tail_bn_finalize_fwd": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
+                                _p, _p],
+    "mi_tail_head_fwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _i32, _i32, _p],
+    "mi_tail_head_blocks": [_i32],
+    "mi_tail_head_bwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+    "mi_tail_bn_finalize_bwd": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
+    "mi_tail_dgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
+                           _i32, _p, _i32, _i32, _i32, _p],
+    "mi_tail_wgrad_splits": [_i32, _i32, _i32],
+    "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
+                           _i32, _i32, _p],
     "mi_prof_count": [],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
 _RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
              "mi_bpr_workspace_elems": ctypes.c_int64, "mi_lse_diag_workspace_elems": ctypes.c_int64,
-             "mi_sort_field_rows_workspace_bytes": ctypes.c_int64}
+             "mi_sort_field_rows_workspace_bytes": ctypes.c_int64, "mi_tail_part_elems": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()
@@ -185,6 +199,11 @@ def check_index_errors(device: Optional[torch.device] = None) -> None:
     """
     words = _err_words.values() if device is None else [err_word(device)]
     for w in words:
-        if int(w.item()) != 0:
+        bits = int(w.item())
+        if bits != 0:
             w.zero_()
-            raise IndexError("index out of range in embedding lookup (mi355x_recsys)")
+            if bits & 1:
+                raise IndexError("index out of range in embedding lookup (mi355x_recsys)")
+            raise IndexError("an id lies outside its own field's range (inside the concatenated table): the lookup read "
+                             "another field's row like the reference does, but the field-sorted sparse optimizer dropped "
+                             "its gradient (mi355x_recsys)")

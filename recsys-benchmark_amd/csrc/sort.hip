@@ -31,7 +31,7 @@ __device__ __forceinline__ void emit(uint64_t key, int64_t lo, int64_t N, int F,
 __global__ __launch_bounds__(kSortThreads) void k_sort_runs(const int64_t *__restrict__ rows,
                                                             const int64_t *__restrict__ offsets, int64_t N, int B, int F,
                                                             uint64_t *__restrict__ runs, int64_t *__restrict__ rows_sorted,
-                                                            int64_t *__restrict__ perm) {
+                                                            int64_t *__restrict__ perm, int *err) {
   __shared__ uint64_t lds[kRun];
   const int f = blockIdx.x, r = blockIdx.y, R = gridDim.y, t = threadIdx.x;
   const int64_t lo = offsets[f], hi = f + 1 < F ? offsets[f + 1] : N;
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_runs(const int64_t *__res
     const int64_t id = rows[(int64_t)b * F + f];
     const uint64_t rel = (id >= lo && id < hi) ? (uint64_t)(id - lo) : kBadRel;
     key = rel << 32 | (uint64_t)b;
+    // an id in [0, N) but outside its own field was ACCEPTED by the lookup (the reference reads another field's row there,
+    // src/models/deepfm.py:88); its gradient cannot be placed by a per-field sort, so it is dropped LOUDLY: sticky bit
+    if (rel == kBadRel && id >= 0 && id < N && err) atomicOr(err, MI_IDX_OUT_OF_FIELD);
   }
   for (int k = 2; k <= kRun; k <<= 1) {
     const bool up = (t & k) == 0;
@@ -96,7 +99,7 @@ int64_t mi_sort_field_rows_workspace_bytes(int64_t B, int32_t F) {
 }
 
 int mi_sort_field_rows(const int64_t *rows, const int64_t *offsets, int64_t N, int64_t B, int32_t F, int64_t *rows_sorted,
-                       int64_t *perm, void *workspace, void *stream) {
+                       int64_t *perm, void *workspace, int32_t *err, void *stream) {
   if (B < 0 || F <= 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!rows || !offsets || !rows_sorted || !perm) return MI_ERR_INVALID_ARG;
@@ -104,7 +107,8 @@ int mi_sort_field_rows(const int64_t *rows, const int64_t *offsets, int64_t N, i
   const int R = (int)((B + kRun - 1) / kRun);
   if (R > 1 && !workspace) return MI_ERR_INVALID_ARG;
   uint64_t *runs = static_cast<uint64_t *>(workspace);
-  MI_LAUNCH("sort_runs", k_sort_runs, dim3(F, R), kSortThreads, stream, rows, offsets, N, (int)B, F, runs, rows_sorted, perm);
+  MI_LAUNCH("sort_runs", k_sort_runs, dim3(F, R), kSortThreads, stream, rows, offsets, N, (int)B, F, runs, rows_sorted, perm,
+            err);
   if (R > 1) {
     const int64_t total = (int64_t)F * R * kRun;
     MI_LAUNCH("merge_runs", k_merge_runs, (int)((total + kBlock - 1) / kBlock), kBlock, stream, runs, offsets, N, (int)B, F,

@@ -1,0 +1,389 @@
+// tail_gemm.hpp — the fp32 contractions of the MLP tail (reference src/models/deepfm.py:53-66,
+// src/models/dcn.py:56-66) on the gfx950 matrix cores, with the BatchNorm / ReLU / Dropout element work folded into the
+// operand loads and the epilogues so that no activation makes a second trip through HBM.
+//
+//   C[r][c] = sum_red  R(r, red) * Cc(c, red)          v_mfma_f32_16x16x4_f32 (exact fp32)
+//
+// Shape-driven tiling.  The tail's products are M = 4096 by N,K in {400, 416}: 64 x 64 tiles give 448 workgroups = 1.75
+// waves over the 256 CUs (what the library GEMM and round 1's generic kernel pay for).  Here a workgroup owns 64 rows of
+// R (4 row blocks of 16) by ONE QUARTER of the columns (100 or 104, computed as 7 sub-tiles of 16 with the surplus
+// masked): exactly 64 x 4 = 256 workgroups, one per CU; 8 waves, two per SIMD, 28 accumulator registers per lane.
+//
+// MFMA roles are swapped (A := Cc fragment, B := R fragment) so that a lane ends up with 4 CONSECUTIVE columns of one
+// output row: the epilogue stores float4 and the column reductions (BatchNorm statistics, dgamma / dbeta) are 16-lane
+// shuffles.
+//
+// Operand sources, both staged through LDS (register-staged, transform applied between the global load and the LDS
+// write; the loads of tile i+1 are in flight during the MFMAs of tile i):
+//   KC  "reduction contiguous": global [row][red]; LDS [row][32] with the eight 16-B chunks of a row XOR-swizzled by
+//       (row >> 1) & 7 — conflict-free ds_read_b128 fragments for the 16x16x4 lane pattern, no padding.
+//   OC  "output contiguous":   global [red][out]; LDS [32][out] (row pitch = 4 mod 8 floats), ds_read_b32 fragments.
+// One b128 (or four b32) per operand feeds 4 MFMA k-steps; lane group g = lane / 16 supplies reduction index
+// 16h + 4g + j at step (h, j) for BOTH operands, which a sum over the reduction index does not see.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;     // 8 waves: 4 consumers (MFMA, one per SIMD) + 4 producers (load / transform / LDS write)
+constexpr int kProd = 256;        // producer threads; their index is threadIdx.x - 256
+constexpr int BM = 64;            // rows of R per workgroup (4 waves x 16)
+constexpr int BK = 32;            // reduction indices per stage
+constexpr int NSUB = 7;           // 16-column sub-tiles per wave
+constexpr int BNT = NSUB * 16;    // 112 >= columns per workgroup
+constexpr int SR_OC = 68;         // LDS row pitch (floats) of an OC tile of R (64 wide)
+constexpr int SC_OC = 116;        // ... of Cc (112 wide); both = 4 mod 8: lane groups 4 rows apart fall 16 banks apart
+
+__device__ __forceinline__ float4 vld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void vst4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---- dropout --------------------------------------------------------------------------------------------------------
+// The keep decisions of a layer are one BIT per element, written once per step by k_tail_dropmask (tail.hip) from a
+// counter-based hash: 16 bits of splitmix64(seed + salt', (m*ld + c) / 4) per feature, keep when >= round(p * 65536).
+// An integer hash inside the operand loads would be paid by the matrix pipe: the f32 MFMA runs at the vector-ALU rate
+// and shares its issue with the producers' VALU work, and the 64-bit multiplies of the hash are quarter-rate (measured:
+// +4 us on a 17 us product, and the same tile is loaded by 4 to 7 workgroups).  Element (m, c) of an activation with
+// row pitch ld is bit (c & 7) of byte (m*ld + c) >> 3; a float4 of features reads one byte and uses one nibble.
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct Drop {
+  const uint8_t *bits;   // nullptr = no dropout
+  float inv_keep;        // 1 / (1 - p)
+  int ld;                // features per row of the activation the mask belongs to (multiple of 8)
+  __device__ __forceinline__ uint32_t fetch(int m, int c) const {
+    return bits ? (uint32_t)bits[((int64_t)m * ld + c) >> 3] : 0xFFu;
+  }
+  // multipliers (0 or inv_keep) of the 4 consecutive features starting at column c (c % 4 == 0), from the fetched byte
+  __device__ __forceinline__ float4 scale4(uint32_t byte, int c) const {
+    const uint32_t nib = byte >> (c & 4);
+    float4 s;
+    s.x = (nib & 1u) ? inv_keep : 0.f;
+    s.y = (nib & 2u) ? inv_keep : 0.f;
+    s.z = (nib & 4u) ? inv_keep : 0.f;
+    s.w = (nib & 8u) ? inv_keep : 0.f;
+    return s;
+  }
+};
+
+// ---- operand loaders ------------------------------------------------------------------------------------------------
+// Every loader is split in two so that nothing computed from a loaded value sits between a global load and the MFMA
+// phase it is meant to hide under:  fetch(m, c) only ISSUES loads (raw vectors + the per-column constants),
+// finish(raw, consts, m, c) turns them into the operand value right before the LDS write, one or two MFMA phases later.
+// (m, c) = row and first of 4 consecutive features of a [M, ld] matrix.
+struct NoConsts {};
+// Plain: the matrix itself (weights, the embedding block, a finished gradient).
+struct LoadPlain {
+  const float *P;
+  int ld;
+  struct Raw { float4 a; };
+  typedef NoConsts Consts;
+  __device__ __forceinline__ Raw fetch(int m, int c) const { return Raw{vld4(P + (int64_t)m * ld + c)}; }
+  __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
+  __device__ __forceinline__ float4 finish(const Raw &r, const Consts &, int, int) const { return r.a; }
+};
+// Act: the activation a = dropout(relu(bn(z))) recomputed from the saved pre-activation z:
+//   pre = (z - mu[c]) * sc[c] + be[c]   (sc = gamma * rstd; BatchNorm off: mu = 0, sc = 1, be = bias or 0)
+struct LoadAct {
+  const float *Z;
+  int ld;
+  const float *mu, *sc, *be;
+  Drop drop;
+  struct Raw { float4 z; uint32_t keep; };
+  struct Consts { float4 u, s, b; };
+  __device__ __forceinline__ Raw fetch(int m, int c) const { return Raw{vld4(Z + (int64_t)m * ld + c), drop.fetch(m, c)}; }
+  __device__ __forceinline__ Consts consts(int c) const { return Consts{vld4(mu + c), vld4(sc + c), vld4(be + c)}; }
+  __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int m, int c) const {
+    const float4 d = drop.scale4(r.keep, c);
+    float4 a;
+    a.x = fmaxf(fmaf(r.z.x - k.u.x, k.s.x, k.b.x), 0.f) * d.x;
+    a.y = fmaxf(fmaf(r.z.y - k.u.y, k.s.y, k.b.y), 0.f) * d.y;
+    a.z = fmaxf(fmaf(r.z.z - k.u.z, k.s.z, k.b.z), 0.f) * d.z;
+    a.w = fmaxf(fmaf(r.z.w - k.u.w, k.s.w, k.b.w), 0.f) * d.w;
+    return a;
+  }
+};
+// Dz: the gradient w.r.t. the pre-activation of a training-mode BatchNorm layer, from dy (= dL/d(bn output), already
+// masked by ReLU and dropout) and z:  dz = al[c] * dy + bz[c] * (z - mu[c]) + de[c]
+//   al = gamma*rstd, bz = -gamma*rstd^2 * dgamma/M, de = -gamma*rstd * dbeta/M   (bn_finalize_bwd writes them;
+//   eval-mode / no BatchNorm: bz = de = 0)
+struct LoadDz {
+  const float *DY, *Z;
+  int ld;
+  const float *mu, *al, *bz, *de;
+  struct Raw { float4 dy, z; };
+  struct Consts { float4 u, a, b, d; };
+  __device__ __forceinline__ Raw fetch(int m, int c) const {
+    return Raw{vld4(DY + (int64_t)m * ld + c), vld4(Z + (int64_t)m * ld + c)};
+  }
+  __device__ __forceinline__ Consts consts(int c) const { return Consts{vld4(mu + c), vld4(al + c), vld4(bz + c), vld4(de + c)}; }
+  __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int, int) const {
+    float4 o;
+    o.x = fmaf(k.a.x, r.dy.x, fmaf(k.b.x, r.z.x - k.u.x, k.d.x));
+    o.y = fmaf(k.a.y, r.dy.y, fmaf(k.b.y, r.z.y - k.u.y, k.d.y));
+    o.z = fmaf(k.a.z, r.dy.z, fmaf(k.b.z, r.z.z - k.u.z, k.d.z));
+    o.w = fmaf(k.a.w, r.dy.w, fmaf(k.b.w, r.z.w - k.u.w, k.d.w));
+    return o;
+  }
+};
+
+__device__ __forceinline__ int ptid() { return (int)threadIdx.x - (kThreads - kProd); }
+
+// ---- LDS tiles -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+// One BK slice of one operand on its way from global memory to LDS: raw vectors + constants in registers.
+// KC tile: ROWS x 32, chunk id q = t + 256 i -> (row q / 8, reduction chunk q % 8); all chunks of a thread share the
+// reduction columns, so ONE set of constants serves them (the transformed matrices of a KC operand are indexed
+// [row = m][red = feature]).  Rows beyond rows_valid re-read the last valid row (finite values that only feed masked
+// outputs); reduction indices >= red_end are fetched from a clamped (valid) address and zeroed at the LDS write.
+template <int ROWS, class L>
+struct KcStage {
+  static constexpr int NV = (ROWS * 8 + kProd - 1) / kProd;
+  typename L::Raw raw[NV];
+  typename L::Consts k;
+  int red;       // this thread's first reduction index of the slice (unclamped)
+};
+template <int ROWS, class L>
+__device__ __forceinline__ KcStage<ROWS, L> kc_fetch(const L &ld, int row0, int rows_valid, int red0, int red_end) {
+  KcStage<ROWS, L> st;
+  st.red = red0 + ((ptid() & 7) << 2);
+  const int redc = st.red < red_end ? st.red : red_end - 4;
+  st.k = ld.consts(redc);
+#pragma unroll
+  for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
+    int row = (ptid() >> 3) + i * (kProd / 8);
+    row = row < rows_valid ? row : rows_valid - 1;
+    st.raw[i] = ld.fetch(row0 + row, redc);
+  }
+  return st;
+}
+template <int ROWS, class L>
+__device__ __forceinline__ void kc_finish(float *T, const L &ld, const KcStage<ROWS, L> &st, int row0, int rows_valid, int red_end) {
+  const bool live = st.red < red_end;
+  const int redc = live ? st.red : red_end - 4;
+#pragma unroll
+  for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
+    const int trow = (ptid() >> 3) + i * (kProd / 8);
+    if (trow < ROWS) {
+      const int row = trow < rows_valid ? trow : rows_valid - 1;
+      float4 v = ld.finish(st.raw[i], st.k, row0 + row, redc);
+      if (!live) v = zero4();
+      vst4(T + kc_off(trow, ptid() & 7), v);
+    }
+  }
+}
+// OC tile: 32 x WIDTH (pitch S): chunk id q -> (reduction row q / (WIDTH/4), outputs (q % (WIDTH/4)) * 4 ..).  The
+// transformed matrices of an OC operand are indexed [red = m][out = feature]: constants per chunk.  Outputs beyond
+// out_valid re-read the last valid group; reduction rows >= red_end are zeroed at the LDS write.
+template <int WIDTH, class L>
+struct OcStage {
+  static constexpr int NV = (WIDTH * 8 + kProd - 1) / kProd;
+  typename L::Raw raw[NV];     // the per-column constants are fetched at the LDS write (small L1/L2-resident vectors; the
+                               // producers have the slack, and 4 x 16 registers per stage in flight would spill)
+};
+template <int WIDTH, class L>
+__device__ __forceinline__ OcStage<WIDTH, L> oc_fetch(const L &ld, int out0, int out_valid, int red0, int red_end) {
+  constexpr int CPR = WIDTH / 4;
+  OcStage<WIDTH, L> st;
+#pragma unroll
+  for (int i = 0; i < OcStage<WIDTH, L>::NV; ++i) {
+    int q = ptid() + i * kProd;
+    q = q < WIDTH * 8 ? q : WIDTH * 8 - 1;
+    int red = red0 + q / CPR;
+    red = red < red_end ? red : red_end - 1;
+    int o = (q % CPR) << 2;
+    o = o < out_valid ? o : out_valid - 4;
+    st.raw[i] = ld.fetch(red, out0 + o);
+  }
+  return st;
+}
+template <int WIDTH, int S, class L>
+__device__ __forceinline__ void oc_finish(float *T, const L &ld, const OcStage<WIDTH, L> &st, int out0, int out_valid, int red0,
+                                          int red_end) {
+  constexpr int CPR = WIDTH / 4, NV = OcStage<WIDTH, L>::NV;
+  typename L::Consts k[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int q = ptid() + i * kProd;
+    q = q < WIDTH * 8 ? q : WIDTH * 8 - 1;
+    int o = (q % CPR) << 2;
+    o = o < out_valid ? o : out_valid - 4;
+    k[i] = ld.consts(out0 + o);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = ptid() + i * kProd;
+    if (q < WIDTH * 8) {
+      const int red = red0 + q / CPR;
+      const bool live = red < red_end;
+      int o = (q % CPR) << 2;
+      const int oc = o < out_valid ? o : out_valid - 4;
+      float4 v = ld.finish(st.raw[i], k[i], live ? red : red_end - 1, out0 + oc);
+      if (!live) v = zero4();
+      vst4(T + (q / CPR) * S + o, v);
+    }
+  }
+}
+
+// fragments of step half h (16 reduction indices): 4 values per lane = k-steps j = 0..3
+__device__ __forceinline__ float4 kc_frag(const float *T, int row, int h, int g) { return vld4(T + kc_off(row, 4 * h + g)); }
+template <int S>
+__device__ __forceinline__ float4 oc_frag(const float *T, int col, int h, int g) {
+  const float *p = T + (16 * h + 4 * g) * S + col;
+  return make_float4(p[0], p[S], p[2 * S], p[3 * S]);
+}
+
+// Fragment registers of one half-slice (16 reduction indices) for a consumer wave: its 16 rows of R and the 7 sub-tiles
+// of Cc.
+struct Frags {
+  float4 b, a[NSUB];
+};
+template <bool R_KC, bool C_KC>
+__device__ __forceinline__ void read_frags(Frags &f, const float *Rt, const float *Ct, int wave, int lane, int h) {
+  const int r = lane & 15, g = lane >> 4;
+  f.b = R_KC ? kc_frag(Rt, wave * 16 + r, h, g) : oc_frag<SR_OC>(Rt, wave * 16 + r, h, g);
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) f.a[s] = C_KC ? kc_frag(Ct, s * 16 + r, h, g) : oc_frag<SC_OC>(Ct, s * 16 + r, h, g);
+}
+// 28 MFMAs, j-major: consecutive ones hit different accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an
+// independent one issues every 32).
+__device__ __forceinline__ void mma_half(floatx4 (&acc)[NSUB], const Frags &f) {
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].x, f.b.x, acc[s], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].y, f.b.y, acc[s], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].z, f.b.z, acc[s], 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].w, f.b.w, acc[s], 0, 0, 0);
+}
+
+constexpr int kStageFloats = 64 * BK + BNT * BK > 32 * SR_OC + 32 * SC_OC ? 64 * BK + BNT * BK : 32 * SR_OC + 32 * SC_OC;
+constexpr int kRing = 4;                            // LDS slots
+constexpr int kLdsFloats = kRing * kStageFloats;    // 94 KB
+constexpr int kROffKC = 0, kCOffKC = 64 * BK;      // offsets of the two tiles inside a slot
+constexpr int kROffOC = 0, kCOffOC = 32 * SR_OC;
+
+// Barriers of the main loop.  __syncthreads() drains vmcnt(0) in front of s_barrier, which would make a producer wait at
+// every phase for the global loads it has JUST issued (their latency, not the MFMA phase, then sets the pace: measured
+// 21 us against 17 for the forward product).  The ring only needs LDS ordering:
+//   producer: its LDS writes have landed (lgkmcnt(0)) before it signals; its global loads stay in flight;
+//   consumer: the fragments it read out of the slot that is overwritten next were consumed by MFMAs it has already
+//             issued (the waits the compiler placed in front of them), so it arrives without waiting for anything.
+__device__ __forceinline__ void producer_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0), vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void consumer_barrier() { __builtin_amdgcn_s_barrier(); }
+
+// The main loop over the BK slices [red_begin, red_end), one barrier per slice, roles split by wave:
+//   waves 4-7 (producers): in phase i they transform slice i+3 (fetched during phase i-3) and write it to LDS slot
+//     (i+3) % 4, then issue the global loads of slice i+6 into the register stage that just became free (three register
+//     stages with fixed roles: the loop is unrolled by three) — every load has three phases (~2 us) to land;
+//   waves 0-3 (consumers, one per SIMD): in phase i they run the 56 MFMAs of slice i out of slot i % 4.  The second
+//     half's fragments are read at the top of the phase and the first half of slice i+1 (written in phase i-2) in the
+//     middle of it, so the matrix pipe never waits for an LDS read across the barrier.
+// The element work of the operand loads (BatchNorm / ReLU / dropout bit) runs on the producers' VALU slots beside the
+// consumers' MFMAs (not for free: the f32 MFMA shares the vector issue, so it is kept to a few instructions per float4).  fetchR/fetchC(red0) issue the loads of one slice, finishR/finishC(T, stage, red0)
+// transform and write it.  Fetches past the last slice re-read the last slice (never written).
+template <bool R_KC, bool C_KC, class FR, class FC, class SR, class SC>
+__device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const FR &fetchR,
+                                          const FC &fetchC, const SR &finishR, const SC &finishC) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int rOff = R_KC ? kROffKC : kROffOC, cOff = C_KC ? kCOffKC : kCOffOC;
+  const int nst = (red_end - red_begin + BK - 1) / BK;
+  if (nst <= 0) return;
+  auto at = [&](int i) { return red_begin + (i < nst ? i : nst - 1) * BK; };
+  auto slot = [&](int i) { return lds + (i % kRing) * kStageFloats; };
+  if (wave >= 4) {
+    // ---------------------------------------------------------------------------------------------- producers
+    // slices 0..2 straight into their slots, slices 3..5 left in flight in the three register stages
+    auto r0 = fetchR(at(0));
+    auto c0 = fetchC(at(0));
+    auto r1 = fetchR(at(1));
+    auto c1 = fetchC(at(1));
+    auto r2 = fetchR(at(2));
+    auto c2 = fetchC(at(2));
+    finishR(slot(0) + rOff, r0, at(0));
+    finishC(slot(0) + cOff, c0, at(0));
+    r0 = fetchR(at(3));
+    c0 = fetchC(at(3));
+    if (nst > 1) {
+      finishR(slot(1) + rOff, r1, at(1));
+      finishC(slot(1) + cOff, c1, at(1));
+    }
+    r1 = fetchR(at(4));
+    c1 = fetchC(at(4));
+    if (nst > 2) {
+      finishR(slot(2) + rOff, r2, at(2));
+      finishC(slot(2) + cOff, c2, at(2));
+    }
+    r2 = fetchR(at(5));
+    c2 = fetchC(at(5));
+    producer_barrier();
+    for (int i = 0; i < nst; i += 3) {
+      // phase i: (r0, c0) = slice i+3, (r1, c1) = slice i+4, (r2, c2) = slice i+5
+      if (i + 3 < nst) {
+        finishR(slot(i + 3) + rOff, r0, at(i + 3));
+        finishC(slot(i + 3) + cOff, c0, at(i + 3));
+      }
+      r0 = fetchR(at(i + 6));
+      c0 = fetchC(at(i + 6));
+      producer_barrier();
+      if (i + 1 >= nst) break;
+      if (i + 4 < nst) {
+        finishR(slot(i + 4) + rOff, r1, at(i + 4));
+        finishC(slot(i + 4) + cOff, c1, at(i + 4));
+      }
+      r1 = fetchR(at(i + 7));
+      c1 = fetchC(at(i + 7));
+      producer_barrier();
+      if (i + 2 >= nst) break;
+      if (i + 5 < nst) {
+        finishR(slot(i + 5) + rOff, r2, at(i + 5));
+        finishC(slot(i + 5) + cOff, c2, at(i + 5));
+      }
+      r2 = fetchR(at(i + 8));
+      c2 = fetchC(at(i + 8));
+      producer_barrier();
+    }
+  } else {
+    // ---------------------------------------------------------------------------------------------- consumers
+    Frags f0, f1;
+    __builtin_amdgcn_s_setprio(3);     // the matrix pipe's wave wins the issue arbitration against the producer beside it
+    consumer_barrier();
+    read_frags<R_KC, C_KC>(f0, slot(0) + rOff, slot(0) + cOff, wave, lane, 0);
+    for (int i = 0; i < nst; ++i) {
+      const float *T = slot(i), *Tn = slot(i + 1);
+      read_frags<R_KC, C_KC>(f1, T + rOff, T + cOff, wave, lane, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(acc, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < nst) read_frags<R_KC, C_KC>(f0, Tn + rOff, Tn + cOff, wave, lane, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(acc, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      consumer_barrier();
+    }
+  }
+  __syncthreads();     // (full fence) every wave has passed 1 + nst ring barriers; the ring is free from here on
+}
+
+// XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2, so
+// linear id -> (id % 8) * ceil(total / 8) + id / 8 gives every XCD a contiguous run of logical tiles (the tiles that
+// share operand rows).  Returns -1 for the padding ids of a grid rounded up to a multiple of 8.
+__device__ __forceinline__ int xcd_logical(int id, int total) {
+  const int per = (total + 7) >> 3;
+  const int l = (id & 7) * per + (id >> 3);
+  return ((id >> 3) < per && l < total) ? l : -1;
+}
+
+}  // namespace tg

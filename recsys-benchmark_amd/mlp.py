@@ -36,6 +36,11 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
 # backward products only, and only when a training loop opts in (it makes the first step of every new shape slow).
 TUNE_BACKWARD_GEMMS = False
 
+# The training-mode (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail runs as ONE autograd node over the fused
+# MFMA kernels of csrc/tail.hip (tail.py); False keeps every tail on the general path below (library GEMMs + the
+# BatchNorm/ReLU/Dropout passes of csrc/mlp.hip), which also serves every pattern the fused node does not cover.
+FUSED_TAIL = True
+
 
 class _tuned_gemms:
     _named = False
@@ -260,8 +265,14 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
     """last_add ([B], optional): added to the tail's [B,1] output inside its last kernel when that layer is a
     1-output Linear (DeepFM: scores = y_fm + deep(emb)); otherwise added with a plain op."""
     dev = x.device
-    seed = _seed_word(dev)
     groups = _groups(seq)
+    if FUSED_TAIL and x.is_cuda:
+        from . import tail as _tail
+
+        plan = _tail.fused_tail_plan(seq, x, groups)
+        if plan is not None:       # training-mode BatchNorm tail ending in Linear(., 1): one node over csrc/tail.hip
+            return _tail.run_fused_tail(plan, groups[-1][1], _seed_word(dev), x, last_add)
+    seed = _seed_word(dev)
     # one zero-filled workspace for every reduction target of this pass (forward statistics,
     # backward dgamma/dbeta, bias gradients): a single fill launch instead of one per buffer
     need = 0

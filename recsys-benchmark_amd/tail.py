@@ -1,0 +1,212 @@
+"""The fused MLP tail: (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) of
+DeepFM._deep_branch / DCN._dnn (reference: src/models/deepfm.py:53-66,100-102, src/models/dcn.py:56-66) in TRAINING mode
+as ONE autograd node over the kernels of csrc/tail.hip:
+
+    forward   masks (one launch, only with dropout) ; per layer: MFMA product with the previous layer's
+              BatchNorm+ReLU+Dropout applied in its operand load and the BatchNorm statistics in its epilogue, then a
+              one-block finalize ; head (row dot + bias + y_fm)                                   -> 2k + 2 launches
+    backward  head backward ; per layer: finalize, weight-gradient product (+ slab sum), input-gradient product whose
+              epilogue already is the next layer's dy and its dgamma / dbeta pieces                -> 4k + 1 launches
+
+against 3 library GEMMs + 4 BatchNorm-family passes per layer each way before.  No activation is written or read a
+second time, the dropout decisions are one bit per element, and every reduction is joined in a fixed order: two runs
+of the same step give bit-identical results.
+
+`fused_tail_plan(seq, x)` decides whether a Sequential matches (every hidden group has a training-mode BatchNorm1d that
+tracks running statistics, widths are multiples of 8, fp32 2-D input); everything else keeps the general path of mlp.py.
+"""
+import ctypes
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _kernels, _lib
+
+SALT = 7919          # per-layer salt of the dropout hash: SALT * (layer index + 1)
+
+
+class _Layer:
+    __slots__ = ("lin", "bn", "p")
+
+    def __init__(self, lin, bn, p):
+        self.lin, self.bn, self.p = lin, bn, p
+
+
+def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[List[_Layer]]:
+    """groups: mlp._groups(seq).  The plan (hidden layers; the head is groups[-1]) or None when the pattern does not fit."""
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+        return None
+    if len(groups) < 2 or groups[-1][0] != "plain":
+        return None
+    head = groups[-1][1]
+    if not (isinstance(head, nn.Linear) and head.out_features == 1):
+        return None
+    plan, width = [], x.shape[1]
+    for g in groups[:-1]:
+        if g[0] != "fused":
+            return None
+        _, lin, bn, dp = g
+        if bn is None or not bn.training or not bn.track_running_stats or bn.momentum is None or not bn.affine:
+            return None
+        if lin.in_features != width or lin.in_features % 8 or lin.out_features % 8 or lin.out_features > 1024:
+            return None
+        plan.append(_Layer(lin, bn, float(dp.p) if (dp is not None and dp.training) else 0.0))
+        width = lin.out_features
+    if head.in_features != width or x.shape[0] < 2:
+        return None
+    return plan
+
+
+def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev) -> List[Optional[torch.Tensor]]:
+    lib = _lib.load()
+    n = len(plan)
+    bits = [torch.empty(M * L.lin.out_features // 8, dtype=torch.uint8, device=dev) if L.p > 0 else None for L in plan]
+    if not any(b is not None for b in bits):
+        return bits
+    salts = (ctypes.c_int64 * n)(*[SALT * (i + 1) for i in range(n)])
+    ps = (ctypes.c_float * n)(*[L.p for L in plan])
+    lds = (ctypes.c_int32 * n)(*[L.lin.out_features for L in plan])
+    ptrs = (ctypes.c_void_p * n)(*[0 if b is None else b.data_ptr() for b in bits])
+    _lib.check(lib.mi_tail_dropout_masks(seed.data_ptr(), n, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
+                                         ctypes.addressof(ptrs), M, _lib.stream_ptr(dev)), "mi_tail_dropout_masks")
+    return bits
+
+
+class FusedTailFn(torch.autograd.Function):
+    """out[M, 1] = head(a_k) + last_add, a_l = dropout(relu(bn(a_{l-1} W_l^T + b_l))).
+
+    Differentiable inputs: x, last_add, then per hidden layer (W, b, gamma, beta), then the head's (w, b).  `plan`, `head`
+    and `seed` ride along as plain Python objects / buffers.  The Linear biases of the hidden layers cancel in the
+    training-mode normalisation: they are left out of the products, shift the running mean only (mean_offset) and get an
+    exactly zero gradient."""
+
+    @staticmethod
+    def forward(ctx, plan, head, seed, x, last_add, *params):
+        lib = _lib.load()
+        dev = _lib.require_gpu(x)
+        s = _lib.stream_ptr(dev)
+        x = _kernels._f32c(x)
+        M = x.shape[0]
+        k = len(plan)
+        Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
+        w_head = _kernels._f32c(params[4 * k]).view(-1)
+        b_head = params[4 * k + 1]
+        bits = _masks(seed, plan, M, dev)
+        Zs, consts = [], []
+        prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
+        for i, L in enumerate(plan):
+            N, K = L.lin.out_features, L.lin.in_features
+            Z = torch.empty((M, N), dtype=torch.float32, device=dev)
+            part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
+            c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
+            _lib.check(lib.mi_tail_fwd_gemm(
+                prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
+                _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
+                float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), M, N, K, s),
+                "mi_tail_fwd_gemm")
+            bn = L.bn
+            _lib.check(lib.mi_tail_bn_finalize_fwd(
+                part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (i == 0 and any(b is not None for b in bits)) else None,
+                c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), s), "mi_tail_bn_finalize_fwd")
+            Zs.append(Z)
+            consts.append(c)
+            prev, prev_c, prev_p, prev_bits = Z, c, L.p, bits[i]
+        out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+        add = None if last_add is None else _kernels._f32c(last_add).view(-1)
+        N = plan[-1].lin.out_features
+        _lib.check(lib.mi_tail_head_fwd(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
+                                        float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
+                                        out.data_ptr(), M, N, s), "mi_tail_head_fwd")
+        ctx.plan, ctx.k = plan, k
+        ctx.ps = [L.p for L in plan]
+        ctx.has_head_bias = b_head is not None
+        ctx.add_shape = None if last_add is None else tuple(last_add.shape)
+        ctx.save_for_backward(x, w_head, *Ws, *Zs, *consts, *[b if b is not None else x.new_empty(0) for b in bits],
+                              *[L.bn.weight for L in plan])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        k, plan = ctx.k, ctx.plan
+        saved = ctx.saved_tensors
+        x, w_head = saved[0], saved[1]
+        Ws, Zs, consts = saved[2:2 + k], saved[2 + k:2 + 2 * k], saved[2 + 2 * k:2 + 3 * k]
+        bits = [b if b.numel() else None for b in saved[2 + 3 * k:2 + 4 * k]]
+        gammas = saved[2 + 4 * k:2 + 5 * k]
+        dev = x.device
+        s = _lib.stream_ptr(dev)
+        M = x.shape[0]
+        gvec = _kernels._f32c(g).view(M)
+        need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, *params)
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * k + 2)
+
+        # ---- head: dy of the last hidden layer, its column sums, dw / db of the head
+        N = Zs[-1].shape[1]
+        c = consts[-1]
+        nblk = int(lib.mi_tail_head_blocks(M))
+        DY = torch.empty((M, N), dtype=torch.float32, device=dev)
+        part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
+        wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_tail_head_bwd(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(ctx.ps[-1]),
+                                        _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
+                                        wpart.data_ptr(), M, N, s), "mi_tail_head_bwd")
+        dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
+        db_head = torch.empty((1,), dtype=torch.float32, device=dev)
+        part_rows, wp, nw = nblk, wpart, nblk
+        dx = None
+        for i in range(k - 1, -1, -1):
+            N, K = Zs[i].shape[1], Ws[i].shape[1]
+            c = consts[i]
+            dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
+            dzc = torch.empty((3, N), dtype=torch.float32, device=dev)         # al, bz, de
+            _lib.check(lib.mi_tail_bn_finalize_bwd(
+                part.data_ptr(), part_rows, M, N, gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp), nw, dw_head.data_ptr() if wp is not None else None,
+                db_head.data_ptr() if wp is not None else None, s), "mi_tail_bn_finalize_bwd")
+            wp = None
+            grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
+            if need[5 + 4 * i + 1] and plan[i].lin.bias is not None:
+                grads[4 * i + 1] = torch.zeros((N,), dtype=torch.float32, device=dev)   # exact: the batch mean is removed
+            below = Zs[i - 1] if i > 0 else x
+            bc = consts[i - 1] if i > 0 else None
+            bp = ctx.ps[i - 1] if i > 0 else 0.0
+            bb = bits[i - 1] if i > 0 else None
+            if need[5 + 4 * i]:
+                splits = int(lib.mi_tail_wgrad_splits(M, N, K))
+                slab = torch.empty((splits, N, K), dtype=torch.float32, device=dev)
+                dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+                _lib.check(lib.mi_tail_wgrad_gemm(
+                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                    below.data_ptr(), K, _lib.ptr(bc[0]) if bc is not None else None, _lib.ptr(bc[1]) if bc is not None else None,
+                    _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb), slab.data_ptr(), dW.data_ptr(), M, N, K, s),
+                    "mi_tail_wgrad_gemm")
+                grads[4 * i] = dW
+            if i > 0 or need[3]:
+                OUT = torch.empty((M, K), dtype=torch.float32, device=dev)
+                npart = torch.empty(int(lib.mi_tail_part_elems(M, K)), dtype=torch.float32, device=dev) if i > 0 else None
+                _lib.check(lib.mi_tail_dgrad_gemm(
+                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                    Ws[i].data_ptr(), K, below.data_ptr() if i > 0 else None, K, _lib.ptr(bc[0]) if bc is not None else None,
+                    _lib.ptr(bc[1]) if bc is not None else None, _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb),
+                    OUT.data_ptr(), K, _lib.ptr(npart), M, N, K, s), "mi_tail_dgrad_gemm")
+                if i > 0:
+                    DY, part, part_rows = OUT, npart, (M + 63) // 64
+                else:
+                    dx = OUT
+        grads[4 * k] = dw_head
+        grads[4 * k + 1] = db_head if ctx.has_head_bias else None
+        dadd = gvec.view(ctx.add_shape) if (ctx.add_shape is not None and need[4]) else None
+        return (None, None, None, dx, dadd, *grads)
+
+
+def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
+                   last_add: Optional[torch.Tensor]) -> torch.Tensor:
+    params = []
+    for L in plan:
+        params += [L.lin.weight, L.lin.bias, L.bn.weight, L.bn.bias]
+    params += [head.weight, head.bias]
+    return FusedTailFn.apply(plan, head, seed, x, last_add, *params)

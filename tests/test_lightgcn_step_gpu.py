@@ -58,6 +58,42 @@ def test_bpr_loss_rows_equals_index_select_path():
     assert_close(hI.grad, I.grad, 1e-4, 1e-7, "dI")
 
 
+def test_bpr_and_reg_rows_out_of_range_ids_touch_no_memory_and_are_flagged():
+    """index_select raises in the reference (src/trainer/lightgcn.py:395-397); here a bad triple reads and adds nothing,
+    counts as zero rows, and the sticky word turns into IndexError at the next check."""
+    from recsys_benchmark_amd.losses import reg_loss_rows
+
+    g = torch.Generator().manual_seed(5)
+    nu, ni, D, B = 50, 70, 64, 256
+    U = torch.randn(nu, D, generator=g)
+    I = torch.randn(ni, D, generator=g)
+    users = torch.randint(0, nu, (B,), generator=g)
+    pos, neg = torch.randint(0, ni, (B,), generator=g), torch.randint(0, ni, (B,), generator=g)
+    bad_b = [3, 77, 200]
+    users_bad, pos_bad, neg_bad = users.clone(), pos.clone(), neg.clone()
+    users_bad[3], pos_bad[77], neg_bad[200] = nu + 10**9, -1, ni
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[bad_b] = False
+    for fn in (bpr_loss_rows, reg_loss_rows):
+        hU, hI = U.to(DEV).requires_grad_(True), I.to(DEV).requires_grad_(True)
+        out = fn(hU, hI, users_bad.to(DEV), pos_bad.to(DEV), neg_bad.to(DEV))
+        out.backward()
+        with pytest.raises(IndexError):
+            _lib.check_index_errors()
+        # the same batch with the bad triples replaced by zero rows (an extra all-zero row in each table)
+        U0, I0 = torch.cat([U, torch.zeros(1, D)]).requires_grad_(True), torch.cat([I, torch.zeros(1, D)]).requires_grad_(True)
+        u2, p2, n2 = (torch.where(keep, t, torch.full_like(t, z)) for t, z in ((users, nu), (pos, ni), (neg, ni)))
+        if fn is bpr_loss_rows:
+            ref = ro.bpr_loss(U0[u2], I0[p2], I0[n2])
+        else:
+            ref = (U0[u2].norm(2).pow(2) + I0[p2].norm(2).pow(2) + I0[n2].norm(2).pow(2)) / (2 * B)
+        ref.backward()
+        assert_close(out, ref, 1e-5, 1e-6, fn.__name__)
+        assert_close(hU.grad, U0.grad[:nu], 1e-4, 1e-7, "dU")
+        assert_close(hI.grad, I0.grad[:ni], 1e-4, 1e-7, "dI")
+    _lib.check_index_errors()
+
+
 def _graph(nu, ni, gen, max_items=40):
     return {u: torch.randperm(ni, generator=gen)[: int(torch.randint(0, max_items, (1,), generator=gen))].tolist()
             for u in range(nu)}

@@ -65,6 +65,12 @@ def test_field_sort_is_a_stable_sort_of_the_batch_ids(B, dims):
     assert torch.equal(got_perm.cpu(), torch.cat(want_perm))
     if not bad.any():
         assert torch.equal(got_rows.cpu(), torch.sort(rows.view(-1))[0])
+    # an id the lookup accepts (inside [0, N)) but outside its own field: its gradient is dropped by the row-wise step,
+    # and that is reported through the sticky word instead of staying silent
+    if B > 8 and F > 1:
+        with pytest.raises(IndexError, match="outside its own field"):
+            pkg.check_index_errors()
+    pkg.check_index_errors()
 
 
 def test_ids_without_a_noted_layout_are_sorted_generically():
