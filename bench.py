@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--c4", action="store_true", help="BASELINE config 4: the same 26 fields with the largest one scaled so that "
                     "the table has 1e9 rows (64 GB fp32); row-sharded model (implies --sharded)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
+    ap.add_argument("--fused-tail", action="store_true", help="run the MLP tail on the fused MFMA kernels of csrc/tail.hip "
+                    "(deterministic; slower than the library GEMMs at this shape, see DESIGN.md)")
     ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
                     "all-reduce and rank 0 prints a JSON line with no measurement in it (tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -225,6 +227,7 @@ def main():
     # the MLP's two backward GEMMs per layer: let PyTorch pick the fastest rocBLAS/hipBLASLt solution per shape
     # (searched once, during the warm-up steps)
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
+    _mlp.FUSED_TAIL = bool(args.fused_tail)
 
     dims, D, hidden, p_drop = list(CRITEO_KAGGLE_26), 16, [400, 400, 400], 0.5
     if args.c4:

@@ -205,21 +205,53 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restr
                                                             int64_t *nbt, int64_t *seed_bump, float *__restrict__ mu,
                                                             float *__restrict__ sc, float *__restrict__ be,
                                                             float *__restrict__ rstd_out) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n == 0) {
+  // 64 columns x 4 tile groups per workgroup: a group merges its run of 64-row tiles in tile order (8 loads in flight —
+  // a single thread walking all tiles is one exposed memory latency per tile: 19 us at 64 tiles), then the 4 groups are
+  // merged in group order through LDS.  Same tree for every launch: deterministic.
+  __shared__ float sh[4][64][3];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (nbt) nbt[0] += 1;
     if (seed_bump) seed_bump[0] += 1;
   }
-  if (n >= N) return;
   const int MT = (M + BM - 1) / BM;
+  const int per = (MT + 3) / 4, t0 = grp * per, t1 = min(MT, t0 + per);
   float n_a = 0.f, mean_a = 0.f, m2_a = 0.f;
-  for (int t = 0; t < MT; ++t) {
-    const float n_b = (float)min(BM, M - t * BM);
-    const float mean_b = part[((int64_t)t * N + n) * 2], m2_b = part[((int64_t)t * N + n) * 2 + 1];
-    const float tot = n_a + n_b, delta = mean_b - mean_a;
-    mean_a += delta * (n_b / tot);
-    m2_a += m2_b + delta * delta * (n_a * n_b / tot);
-    n_a = tot;
+  if (n < N) {
+    for (int base = t0; base < t1; base += 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = min(base + u, t1 - 1);
+        v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)t * N + n) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = base + u;
+        if (t < t1) {
+          const float n_b = (float)min(BM, M - t * BM);
+          const float tot = n_a + n_b, delta = v[u].x - mean_a;
+          mean_a += delta * (n_b / tot);
+          m2_a += v[u].y + delta * delta * (n_a * n_b / tot);
+          n_a = tot;
+        }
+      }
+    }
+  }
+  sh[grp][cl][0] = n_a; sh[grp][cl][1] = mean_a; sh[grp][cl][2] = m2_a;
+  __syncthreads();
+  if (grp != 0 || n >= N) return;
+  n_a = 0.f; mean_a = 0.f; m2_a = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float n_b = sh[q][cl][0];
+    if (n_b > 0.f) {
+      const float tot = n_a + n_b, delta = sh[q][cl][1] - mean_a;
+      mean_a += delta * (n_b / tot);
+      m2_a += sh[q][cl][2] + delta * delta * (n_a * n_b / tot);
+      n_a = tot;
+    }
   }
   const float var = m2_a / (float)M;
   const float rstd = rsqrtf(var + eps);
@@ -271,28 +303,44 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
   const bool cv = c < N;
   float4 s_dy = zero4(), s_dyz = zero4(), s_ga = zero4();
   float s_g = 0.f;
-  float4 u = zero4(), sc = zero4(), be = zero4(), ww = zero4();
-  if (cv) { u = ld4(x.mu + c); sc = ld4(x.sc + c); be = ld4(x.be + c); ww = ld4(w + c); }
+  float4 u_ = zero4(), sc = zero4(), be = zero4(), ww = zero4();
+  if (cv) { u_ = ld4(x.mu + c); sc = ld4(x.sc + c); be = ld4(x.be + c); ww = ld4(w + c); }
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int mb = blockIdx.x * rows_per, me = min(M, mb + rows_per);
-  for (int m = mb; m < me; ++m) {
-    const float gm = g[m];
-    s_g += gm;
-    if (!cv) continue;
-    const float4 z = ld4(x.Z + (int64_t)m * x.ld + c);
-    const float4 k = drop.scale4(drop.fetch(m, c), c);
-    const float4 zc = make_float4(z.x - u.x, z.y - u.y, z.z - u.z, z.w - u.w);
-    const float4 pre = make_float4(fmaf(zc.x, sc.x, be.x), fmaf(zc.y, sc.y, be.y), fmaf(zc.z, sc.z, be.z), fmaf(zc.w, sc.w, be.w));
-    float4 dy;
-    dy.x = pre.x > 0.f ? gm * ww.x * k.x : 0.f;
-    dy.y = pre.y > 0.f ? gm * ww.y * k.y : 0.f;
-    dy.z = pre.z > 0.f ? gm * ww.z * k.z : 0.f;
-    dy.w = pre.w > 0.f ? gm * ww.w * k.w : 0.f;
-    st4(DY + (int64_t)m * x.ld + c, dy);
-    s_dy.x += dy.x; s_dy.y += dy.y; s_dy.z += dy.z; s_dy.w += dy.w;
-    s_dyz.x += dy.x * zc.x; s_dyz.y += dy.y * zc.y; s_dyz.z += dy.z * zc.z; s_dyz.w += dy.w * zc.w;
-    s_ga.x += gm * fmaxf(pre.x, 0.f) * k.x; s_ga.y += gm * fmaxf(pre.y, 0.f) * k.y;
-    s_ga.z += gm * fmaxf(pre.z, 0.f) * k.z; s_ga.w += gm * fmaxf(pre.w, 0.f) * k.w;
+  for (int m4 = mb; m4 < me; m4 += 4) {          // 4 rows in flight per thread
+    float4 z[4];
+    uint32_t kb[4];
+    float gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = min(m4 + u, me - 1);
+      gv[u] = g[m];
+      if (cv) {
+        z[u] = ld4(x.Z + (int64_t)m * x.ld + c);
+        kb[u] = drop.fetch(m, c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m4 + u;
+      if (m >= me) break;
+      const float gm = gv[u];
+      s_g += gm;
+      if (!cv) continue;
+      const float4 k = drop.scale4(kb[u], c);
+      const float4 zc = make_float4(z[u].x - u_.x, z[u].y - u_.y, z[u].z - u_.z, z[u].w - u_.w);
+      const float4 pre = make_float4(fmaf(zc.x, sc.x, be.x), fmaf(zc.y, sc.y, be.y), fmaf(zc.z, sc.z, be.z), fmaf(zc.w, sc.w, be.w));
+      float4 dy;
+      dy.x = pre.x > 0.f ? gm * ww.x * k.x : 0.f;
+      dy.y = pre.y > 0.f ? gm * ww.y * k.y : 0.f;
+      dy.z = pre.z > 0.f ? gm * ww.z * k.z : 0.f;
+      dy.w = pre.w > 0.f ? gm * ww.w * k.w : 0.f;
+      st4(DY + (int64_t)m * x.ld + c, dy);
+      s_dy.x += dy.x; s_dy.y += dy.y; s_dy.z += dy.z; s_dy.w += dy.w;
+      s_dyz.x += dy.x * zc.x; s_dyz.y += dy.y * zc.y; s_dyz.z += dy.z * zc.z; s_dyz.w += dy.w * zc.w;
+      s_ga.x += gm * fmaxf(pre.x, 0.f) * k.x; s_ga.y += gm * fmaxf(pre.y, 0.f) * k.y;
+      s_ga.z += gm * fmaxf(pre.z, 0.f) * k.z; s_ga.w += gm * fmaxf(pre.w, 0.f) * k.w;
+    }
   }
   if (cv) {
     float *o = part + ((int64_t)blockIdx.x * N + c) * 2;
@@ -313,18 +361,44 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
                                                             float *__restrict__ al, float *__restrict__ bz,
                                                             float *__restrict__ de, const float *__restrict__ wpart,
                                                             int nwblk, float *__restrict__ dw, float *__restrict__ db) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  // 32 columns x 8 row groups per workgroup (see k_bn_finalize_fwd): a group adds its run of partial rows in row order
+  // with 8 loads in flight, the 8 groups are added in group order through LDS.  Column N of the head's pieces is db.
+  __shared__ float sh[8][32][3];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cl;
+  float s1 = 0.f, s2 = 0.f, sw = 0.f;
+  if (n < N) {
+    const int per = (nblk + 7) / 8, t0 = grp * per, t1 = min(nblk, t0 + per);
+    for (int base = t0; base < t1; base += 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)min(base + u, t1 - 1) * N + n) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u < t1) { s1 += v[u].x; s2 += v[u].y; }
+    }
+  }
   if (wpart && n <= N) {
-    float s = 0.f;
-    for (int t = 0; t < nwblk; ++t) s += wpart[(int64_t)t * (N + 4) + n];
-    if (n < N) dw[n] = s; else if (db) db[0] = s;
+    const int per = (nwblk + 7) / 8, t0 = grp * per, t1 = min(nwblk, t0 + per);
+    for (int base = t0; base < t1; base += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wpart[(int64_t)min(base + u, t1 - 1) * (N + 4) + n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u < t1) sw += v[u];
+    }
+  }
+  sh[grp][cl][0] = s1; sh[grp][cl][1] = s2; sh[grp][cl][2] = sw;
+  __syncthreads();
+  if (grp != 0 || n > N) return;
+  s1 = 0.f; s2 = 0.f; sw = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1 += sh[q][cl][0]; s2 += sh[q][cl][1]; sw += sh[q][cl][2]; }
+  if (wpart) {
+    if (n < N) dw[n] = sw; else if (db) db[0] = sw;
   }
   if (n >= N) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int t = 0; t < nblk; ++t) {
-    s1 += part[((int64_t)t * N + n) * 2];
-    s2 += part[((int64_t)t * N + n) * 2 + 1];
-  }
   const float r = rstd[n], gm = gamma ? gamma[n] : 1.f;
   const float dg = s2 * r;
   if (dgamma) dgamma[n] = dg;
@@ -584,7 +658,7 @@ int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, const float
                             int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc, float *be, float *rstd,
                             void *stream) {
   if (M <= 0 || N <= 0 || !part || !mu || !sc || !be || !rstd) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd, (N + kBlock - 1) / kBlock, kBlock, stream, part, M, N, gamma, beta,
+  MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd, (N + 63) / 64, kBlock, stream, part, M, N, gamma, beta,
             mean_offset, running_mean, running_var, momentum, eps, num_batches_tracked, seed_bump, mu, sc, be, rstd);
   return launch_status();
 }
@@ -621,7 +695,7 @@ int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t 
                             int32_t nwblk, float *dw, float *db, void *stream) {
   if (M <= 0 || N <= 0 || nblk <= 0 || !part || !rstd || !al || !bz || !de) return MI_ERR_INVALID_ARG;
   if (wpart && !dw) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + kBlock - 1) / kBlock, kBlock, stream, part, nblk, M, N,
+  MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + 31) / 32, kBlock, stream, part, nblk, M, N,
             gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db);
   return launch_status();
 }

@@ -36,10 +36,13 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
 # backward products only, and only when a training loop opts in (it makes the first step of every new shape slow).
 TUNE_BACKWARD_GEMMS = False
 
-# The training-mode (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail runs as ONE autograd node over the fused
-# MFMA kernels of csrc/tail.hip (tail.py); False keeps every tail on the general path below (library GEMMs + the
-# BatchNorm/ReLU/Dropout passes of csrc/mlp.hip), which also serves every pattern the fused node does not cover.
-FUSED_TAIL = True
+# FUSED_TAIL = True runs the training-mode (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail as ONE autograd
+# node over the fused MFMA kernels of csrc/tail.hip (tail.py): no atomics (bit-reproducible steps), no stored activations
+# or masks.  It is opt-in: measured on MI355X at the headline shape it is SLOWER than the general path below (0.348 vs
+# 0.290 ms per step) — at M = 4096, N,K ~ 400 every product is ~10 us of MFMA work behind ~6 us of launch + prologue +
+# epilogue, the f32 MFMA shares the vector issue with the operand transforms, and the library's kernels sit at the same
+# floor without them ("fused tail").
+FUSED_TAIL = False
 
 
 class _tuned_gemms:

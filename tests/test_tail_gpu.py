@@ -21,6 +21,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _fused_tail_on(monkeypatch):
+    monkeypatch.setattr(_mlp, "FUSED_TAIL", True)      # opt-in path (mlp.FUSED_TAIL documents why)
+
+
 def _seq(inp, hidden, p):
     layers = []
     for h in hidden:
