@@ -64,14 +64,39 @@ def measured_copy_ceiling(dev, nbytes=1 << 30, reps=10):
     return out
 
 
-def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
-    """Oracle (= reference op sequence in stock PyTorch CPU ops, dense grads like the
-    reference's default nn.Embedding) timed on the host cores; bounded sample."""
+def physical_cores():
+    """(physical cores, logical cpus) of the host; the CPU legs run on the physical count (SMT siblings only add
+    scheduling noise to a memory-bound embedding step)."""
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or logical
+    except Exception:  # noqa: BLE001
+        phys = logical
+    return int(phys), int(logical)
+
+
+def timed_cpu(step, warm=3, timed=10, budget_s=30.0):
+    """SURVEY.md §8d protocol: `warm` untimed + `timed` timed iterations, median; stops early (never below 2 timed
+    iterations) when the budget is spent and says how many it got."""
+    t_end = time.perf_counter() + budget_s
+    for _ in range(warm):
+        step()
+        if time.perf_counter() > t_end:
+            break
+    times = []
+    while len(times) < timed and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], len(times)
+
+
+def deepfm_cpu_params(dims, D, hidden, gen):
     from oracle import reference_ops as ro
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    gen = torch.Generator().manual_seed(2023)
     N = sum(dims)
     bound = (6.0 / (N + D)) ** 0.5
     p = {
@@ -80,8 +105,7 @@ def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
         "fc.weight": torch.randn(N, 1, generator=gen),
         "_bias": torch.zeros(1),
     }
-    inp = len(dims) * D
-    i = 0
+    inp, i = len(dims) * D, 0
     for h in hidden:
         lin = torch.nn.Linear(inp, h)
         p[f"_deep_branch.{i}.weight"], p[f"_deep_branch.{i}.bias"] = lin.weight.detach(), lin.bias.detach()
@@ -94,26 +118,377 @@ def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=20.0):
     for k, v in p.items():
         if v.is_floating_point() and "running_" not in k:
             v.requires_grad_(True)
+    return p
+
+
+def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=25.0):
+    """The oracle (= the reference's op sequence in stock PyTorch CPU ops, oracle/reference_ops.py) timed on this box's
+    host cores, 3 warm-up + 10 timed iterations, median, threads = physical cores.
+
+    Headline (`value`): the SAME workload as the GPU line, like for like — fwd+bwd with row-form (sparse=True) table
+    gradients, the reference's configs/deepfm/base_config_sparse.yaml:8-10 path — so the two numbers compare the same
+    work.  `lines` adds what the reference's default training script really executes (src/models/deepfm.py:155-219): dense
+    weight.grad, and dense Adam(weight_decay=1e-6) over every parameter; both at the survey's F=39 / N~1M shape where 13
+    iterations fit the time budget, and the dense-gradient step at the full C2 table with as many iterations as the
+    budget allows (its 2.16 GB gradient makes one step take seconds)."""
+    import torch.nn.functional as F_
+
+    from oracle import reference_ops as ro
+
+    phys, logical = physical_cores()
+    torch.set_num_threads(phys)
+    lossf = torch.nn.BCEWithLogitsLoss()
+
+    def make_step(dims_, sparse, adam):
+        gen = torch.Generator().manual_seed(2023)
+        p = deepfm_cpu_params(dims_, D, hidden, gen)
+        x, y = synth_batch(dims_, B, 2023, "cpu")
+        opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=1e-3, weight_decay=1e-6) if adam else None
+
+        def fwd():
+            if not sparse:
+                return ro.deepfm_forward(x, p, len(hidden), True, True, p_dropout=p_dropout)
+            # the same op sequence with nn.Embedding(sparse=True) / EmbeddingBag(sparse=True) gradients
+            rows = x + p["offsets"]
+            emb = F_.embedding(rows, p["embedding._emb_module.weight"], sparse=True)
+            y_fm = F_.embedding_bag(rows, p["fc.weight"], mode="sum", sparse=True) + p["_bias"] + ro.fm_second_order(emb)
+            b = emb.shape[0]
+            return (y_fm + ro.mlp_tail(emb.reshape(b, -1), p, "_deep_branch", len(hidden), True, True,
+                                       p_dropout=p_dropout)).squeeze(-1)
+
+        def step():
+            for v in p.values():
+                v.grad = None
+            lossf(fwd(), y).backward()
+            if opt is not None:
+                opt.step()
+
+        return step
+
+    lines = []
+
+    def line(name, dims_, sparse, adam, budget):
+        med, n = timed_cpu(make_step(dims_, sparse, adam), budget_s=budget)
+        lines.append({"what": name, "samples_per_s": round(B / med, 1), "ms_per_step": round(med * 1e3, 2), "timed_iters": n,
+                      "shape": f"F={len(dims_)}, N={sum(dims_)}, D={D}, B={B}"})
+        return med, n
+
+    med, n = line("fwd+bwd, row-form (sparse=True) table grads — like for like with the GPU line", dims, True, False, budget_s * 0.35)
+    survey39 = [50] * 13 + [max(2, d * 1_000_000 // sum(dims)) for d in dims]          # F=39, N~1M (SURVEY.md §6 shape)
+    line("fwd+bwd, dense weight.grad (reference default), F=39 N~1M", survey39, False, False, budget_s * 0.2)
+    line("fwd+bwd + dense Adam(weight_decay=1e-6) (what train_deepfm.py runs), F=39 N~1M", survey39, False, True, budget_s * 0.2)
+    line("fwd+bwd, dense weight.grad (reference default), full C2 table", dims, False, False, budget_s * 0.25)
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": phys, "logical_cpus": logical, "kind": "port",
+            "sample": f"3 warm-up + {n} timed fwd+bwd steps (median {med*1e3:.1f} ms/step) of the same B={B} C2 workload with "
+                      "row-form table gradients, oracle/reference_ops.py op sequence on torch CPU, "
+                      f"torch.set_num_threads({phys}) = physical cores",
+            "lines": lines}
+
+
+def gather_pair_in_graph_wall_us(model, ring, nx, B, F, D, dev, pairs=32, reps=20):
+    """What the gather+FM forward / backward pair costs a replayed hipGraph in WALL time per pair (fresh ids per launch,
+    kernels back to back): the per-dispatch clock reads ~4 us for an empty kernel, of which only ~1.7 us are paid in a
+    graph — the rest overlaps the neighbouring dispatches — so this is the pair's real cost to a step."""
+    from recsys_benchmark_amd import _lib as L
+
+    lib = L.load()
+    W, w1, bias = model.embedding.get_weight().detach(), model.fc.weight.detach(), model._bias.detach()
+    off = model.offsets.reshape(-1).contiguous()
+    N = W.shape[0]
+    emb = torch.empty(B, F, D, device=dev)
+    yfm, gy = torch.empty(B, device=dev), torch.randn(B, device=dev)
+    rows = torch.empty(B, F, dtype=torch.int64, device=dev)
+    gemb, gvals, g1 = torch.randn(B, F, D, device=dev), torch.empty(B, F, D, device=dev), torch.empty(B, F, device=dev)
+    gb = torch.empty(1, device=dev)
+    err = L.err_word(dev)
+
+    def pair(i):
+        x = ring[i % len(ring)][:nx]
+        s = L.stream_ptr(dev)
+        L.check(lib.mi_gather_fm_fwd(x.data_ptr(), off.data_ptr(), W.data_ptr(), w1.data_ptr(), bias.data_ptr(), emb.data_ptr(),
+                                     yfm.data_ptr(), rows.data_ptr(), B, F, D, N, err.data_ptr(), s), "fwd")
+        L.check(lib.mi_gather_fm_bwd_rows(emb.data_ptr(), gy.data_ptr(), gemb.data_ptr(), gvals.data_ptr(), g1.data_ptr(),
+                                          gb.data_ptr(), B, F, D, s), "bwd")
+
+    pair(0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(pairs):
+            pair(i)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (pairs * reps)
+
+
+AVAZU_22 = [241, 8, 8, 3697, 4614, 25, 5481, 329, 31, 381763, 1611748, 6793, 6, 5, 2509, 9, 10, 432, 5, 68, 169, 61]
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (= the fp32 vector rate)
+
+
+def init_ranks(args, dev_index):
+    """Replica runs (C3 / C5 do not shard: SURVEY.md §8e): every rank runs the whole workload on its own GPU; the only
+    collective is the timing fence (barrier + MAX of the elapsed time)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return rank, world, dev
+
+
+def time_graphed(step, args, world, dev):
+    """Capture `step` (forward + loss + backward into static gradients) as ONE hipGraph, W warm-up replays, K timed
+    replays between fences; returns seconds (max over ranks)."""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    if args.no_graph:            # eager launches (counter collection passes)
+        class _Eager:
+            replay = staticmethod(step)
+        graph = _Eager()
+    else:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        graph.replay()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def kernel_table(kt):
+    return {k: {"avg_us": round(v["avg_us"], 3), "min_us": round(v["min_us"], 3), "launches": v["count"]} for k, v in kt.summary().items()}
+
+
+def emit(out, real_stdout):
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+
+
+def bench_c3(args, real_stdout):
+    """BASELINE config 3 (SURVEY.md §8d "C3"): DCN-Mix on the Avazu-shaped 22 fields (N = 2.02 M rows, D = 16 -> d = 352) with
+    the QR `divider: 2` embedding (configs/avazu/qr_2.yaml:9-10), E = 4 experts, rank 64, L = 3 cross layers
+    (src/models/dcn.py:19-21), MLP 400x3 + BatchNorm + dropout 0.5, B = 4096.  Step = model(x) -> BCE-with-logits ->
+    backward.  Roofline: the CrossNet contractions are MFMA-bound (the library's `gemm_f32` launches): algorithmic flops per
+    sample and layer E(2dr + 2r^2 + 2rd) + 2Ed forward, x3 layers, x3 for forward + backward."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, dev = init_ranks(args, local_rank)
+    import recsys_benchmark_amd as pkg
+    from recsys_benchmark_amd import _lib as L
+    from recsys_benchmark_amd import mlp as _mlp
+    from recsys_benchmark_amd.dcn import DCN_Mix
+    from recsys_benchmark_amd.losses import BCEWithLogitsLoss, unit_scalar
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
+    _mlp.FUSED_TAIL = bool(args.fused_tail)
+    dims, D, hidden, B, E, r, nl = list(AVAZU_22), 16, [400, 400, 400], args.batch, 4, 64, 3
+    F, d = len(dims), len(dims) * D
+    torch.manual_seed(2023)
+    emb_cfg = {"name": "qr", "divider": 2}
+    model = DCN_Mix(dims, D, hidden, num_layers=nl, num_experts=E, rank=r, embedding_config=emb_cfg, p_dropout=0.5).to(dev).train()
+    x, y = synth_batch(dims, B, 2023 + 7919 * rank, dev)
+    lossf, one = BCEWithLogitsLoss(), unit_scalar(dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        lossf(model(x), y).backward(one)
+
+    elapsed = time_graphed(step, args, world, dev)
+    pkg.check_index_errors()
+    n_prof = min(args.steps, 50)
+    with KernelTimer(capacity=96 * n_prof + 64) as kt:
+        for _ in range(n_prof):
+            step()
+            L.load().mi_prof_empty_launch(256, 256, L.stream_ptr(dev))
+        torch.cuda.synchronize()
+    if rank != 0:
+        return
+    kernels = kernel_table(kt)
+    flops_step = 3.0 * nl * (E * (2 * d * r + 2 * r * r + 2 * r * d) + 2 * E * d) * B
+    g = kernels.get("gemm_f32")
+    roofline = None
+    if g:
+        per_step_us = g["avg_us"] * g["launches"] / n_prof
+        ach = flops_step / (per_step_us * 1e-6) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f32 (all CrossNet products of a step)", "achieved": round(ach, 2),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": g["launches"] / n_prof, "us_per_step": round(per_step_us, 2),
+                    "alg_flops_per_step": flops_step, "floor_us": kernels.get("empty", {}).get("avg_us")}
+    out = {"metric": "samples/sec fwd+bwd, Avazu-22field DCN-Mix (QR divider 2) b=4096; MFMA TFLOP/s vs roofline",
+           "value": round(B * world * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay",
+           "config": {"workload": f"C3 DCN-Mix Avazu-22field: F={F}, D={D}, d={d}, N={sum(dims)} rows, QR divider 2 (mult), E={E}, "
+                                  f"rank={r}, L={nl}, MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd",
+                      "global_batch": B * world, "parallelism": "single" if world == 1 else f"{world} independent replicas"},
+           "roofline": roofline, "kernels": kernels}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_c3(model, dims, D, nl, len(hidden), B)
+    emit(out, real_stdout)
+
+
+def cpu_baseline_c3(model, dims, D, nl, n_hidden, B):
+    from oracle import reference_ops as ro
+
+    phys, logical = physical_cores()
+    torch.set_num_threads(phys)
+    p = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
     x, y = synth_batch(dims, B, 2023, "cpu")
     lossf = torch.nn.BCEWithLogitsLoss()
+    divider = 2
 
     def step():
         for v in p.values():
             v.grad = None
-        lossf(ro.deepfm_forward(x, p, len(hidden), True, True, p_dropout=p_dropout), y).backward()
+        rows = x + p["offsets"]
+        emb = ro.qr_forward(rows, p["embedding.emb1.weight"], p["embedding.emb2.weight"], divider, "mult")
+        lossf(ro.dcn_mix_forward(x, p, emb, nl, n_hidden, True), y).backward()
 
-    step()  # warm-up
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 10 and (time.perf_counter() < t_end or len(times) < 2):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} fwd+bwd steps of the same B={B} workload (median {med*1e3:.1f} ms/step), "
-                      "oracle/reference_ops.py deepfm_forward on torch CPU, dense weight.grad as the reference"}
+    med, n = timed_cpu(step, budget_s=20.0)
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": phys, "logical_cpus": logical, "kind": "port",
+            "sample": f"3 warm-up + {n} timed fwd+bwd steps (median {med*1e3:.1f} ms/step) of the same C3 workload, "
+                      "oracle/reference_ops.py qr_forward + dcn_mix_forward on torch CPU (dropout off: the oracle is functional)"}
+
+
+def yelp_graph(U=31668, I=38048, nnz=1128375, seed=2023):
+    """edges user-uniform x item power-law (item = floor(I u^2)), symmetric normalised adjacency of the
+    bipartite graph as the reference builds it (src/graph_utils.py:47-98), CSR fp32."""
+    gen = torch.Generator().manual_seed(seed)
+    u = torch.randint(0, U, (nnz,), generator=gen)
+    i = (I * torch.rand(nnz, generator=gen).pow(2)).long().clamp_(max=I - 1)
+    n = U + I
+    idx = torch.stack([torch.cat([u, i + U]), torch.cat([i + U, u])])
+    adj = torch.sparse_coo_tensor(idx, torch.ones(2 * nnz), size=(n, n)).coalesce()
+    deg = torch.sparse.sum(adj, dim=1).to_dense().clamp_(min=1).pow(-0.5)
+    ii = adj.indices()
+    return torch.sparse_coo_tensor(ii, adj.values() * deg[ii[0]] * deg[ii[1]], size=(n, n)).coalesce().to_sparse_csr()
+
+
+def bench_c5(args, real_stdout):
+    """BASELINE config 5 (SURVEY.md §8d "C5"): LightGCN, Yelp2018-shaped (U = 31 668, I = 38 048, 1 128 375 interactions ->
+    nnz(A) ~ 2.25 M, D = 64, L = 3, configs/yelp2018/lightgcn_config.yaml:1-7), 2048 BPR triples per step.  Step = what the
+    reference's _train_step computes before the optimizer (src/trainer/lightgcn.py:380-421): full propagation, BPR over the
+    batch rows, L2 regulariser, backward.  Roofline: the CSR SpMM launches are HBM-bound; algorithmic (compulsory) bytes per
+    layer 8 nnz + 4 (N + 1) + 8 N D."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, dev = init_ranks(args, local_rank)
+    import recsys_benchmark_amd as pkg
+    from recsys_benchmark_amd import _lib as L
+    from recsys_benchmark_amd.lightgcn import LightGCN
+    from recsys_benchmark_amd.losses import bpr_loss_rows, unit_scalar
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    U, I, D, nl, B = 31668, 38048, 64, 3, 2048
+    adj_cpu = yelp_graph(U, I)
+    adj = adj_cpu.to(dev)
+    N, nnz = U + I, int(adj_cpu.values().numel())
+    torch.manual_seed(2023)
+    model = LightGCN(U, I, num_layers=nl, hidden_size=D).to(dev).train()
+    gen = torch.Generator().manual_seed(2023 + rank)
+    users = torch.randint(0, U, (B,), generator=gen).to(dev)
+    pos, neg = torch.randint(0, I, (B,), generator=gen).to(dev), torch.randint(0, I, (B,), generator=gen).to(dev)
+    one = unit_scalar(dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        au, ai = model(adj)
+        (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * model.get_reg_loss(users, pos, neg)).backward(one)
+
+    elapsed = time_graphed(step, args, world, dev)
+    pkg.check_index_errors()
+    n_prof = min(args.steps, 50)
+    with KernelTimer(capacity=64 * n_prof + 64) as kt:
+        for _ in range(n_prof):
+            step()
+            L.load().mi_prof_empty_launch(256, 256, L.stream_ptr(dev))
+        torch.cuda.synchronize()
+    if rank != 0:
+        return
+    kernels = kernel_table(kt)
+    alg = 8 * nnz + 4 * (N + 1) + 8 * N * D
+    k = kernels.get("spmm_csr")
+    roofline = None
+    if k:
+        ach = alg / (k["avg_us"] * 1e-6) / 1e9
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic = json.load(open(tpath)).get("spmm_csr") if os.path.exists(tpath) else None
+        roofline = {"bound": "hbm", "kernel": "spmm_csr", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_us": k["avg_us"], "alg_bytes": alg,
+                    "launches_per_step": k["launches"] / n_prof, "nnz": nnz,
+                    "gather_bytes_without_reuse": nnz * (8 + 4 * D), "G_nnz_per_s": round(nnz / (k["avg_us"] * 1e-6) / 1e9, 2),
+                    "floor_us": kernels.get("empty", {}).get("avg_us")}
+    out = {"metric": "BPR triples/sec fwd+bwd, LightGCN Yelp2018-shaped 3-layer (full propagation every step); HBM GB/s vs roofline",
+           "value": round(B * world * args.steps / elapsed, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay",
+           "config": {"workload": f"C5 LightGCN Yelp2018-shaped: U={U}, I={I}, N={N}, nnz(A)={nnz}, D={D}, L={nl}, {B} BPR triples/step "
+                                  "+ L2 reg, fwd+bwd (no optimizer)",
+                      "global_batch": B * world, "parallelism": "single" if world == 1 else f"{world} independent replicas (the path does not shard: SURVEY.md §8e)"},
+           "roofline": roofline, "kernels": kernels}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_c5(model, adj_cpu, users.cpu(), pos.cpu(), neg.cpu(), U, nl, B)
+    emit(out, real_stdout)
+
+
+def cpu_baseline_c5(model, adj_cpu, users, pos, neg, U, nl, B):
+    from oracle import reference_ops as ro
+
+    phys, logical = physical_cores()
+    torch.set_num_threads(phys)
+    Eu = model.user_emb_table.get_weight().detach().cpu().clone().requires_grad_(True)
+    Ei = model.item_emb_table.get_weight().detach().cpu().clone().requires_grad_(True)
+
+    def step():
+        Eu.grad = Ei.grad = None
+        res = ro.lightgcn_propagate(adj_cpu, torch.cat([Eu, Ei]), nl)
+        au, ai = res[:U], res[U:]
+        loss = ro.bpr_loss(au[users], ai[pos], ai[neg]) + 1e-4 * ro.l2_reg_loss(Eu[users], Ei[pos], Ei[neg])
+        loss.backward()
+
+    med, n = timed_cpu(step, budget_s=25.0)
+    return {"value": round(B / med, 1), "unit": "triples/s", "cores": phys, "logical_cpus": logical, "kind": "port",
+            "sample": f"3 warm-up + {n} timed fwd+bwd steps (median {med*1e3:.1f} ms/step) of the same C5 workload, "
+                      "oracle/reference_ops.py lightgcn_propagate (torch CSR matmul, as src/models/lightgcn.py:79-87) + bpr_loss + l2_reg_loss on torch CPU"}
 
 
 def self_launch(n):
@@ -161,6 +536,8 @@ def main():
     ap.add_argument("--c4", action="store_true", help="BASELINE config 4: the same 26 fields with the largest one scaled so that "
                     "the table has 1e9 rows (64 GB fp32); row-sharded model (implies --sharded)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2", help="c2 (default): the headline DeepFM workload; c3: DCN-Mix "
+                    "Avazu-shaped with the QR embedding; c5: LightGCN Yelp2018-shaped (SURVEY.md §8d); --c4 is c2's 1e9-row variant")
     ap.add_argument("--fused-tail", action="store_true", help="run the MLP tail on the fused MFMA kernels of csrc/tail.hip "
                     "(deterministic; slower than the library GEMMs at this shape, see DESIGN.md)")
     ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
@@ -181,6 +558,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.config == "c3" and not args.dry_launch:
+        return bench_c3(args, real_stdout)
+    if args.config == "c5" and not args.dry_launch:
+        return bench_c5(args, real_stdout)
     if args.dry_launch:
         import torch.distributed as dist
 
@@ -349,10 +730,15 @@ def main():
     # Eager launches read ~15-20 % slower than the same kernels inside the replayed graph
     # (rocprofv3, profiles/): the reported fraction is conservative.
     n_prof = min(args.steps, 100)
-    with KernelTimer(capacity=32 * n_prof + 64) as kt:
+    from recsys_benchmark_amd import _lib as _mlib
+
+    with KernelTimer(capacity=48 * n_prof + 64) as kt:
         for _ in range(n_prof):
             eager_step()
+            # the floor of this clock: an EMPTY kernel of the gather kernels' geometry, same launcher, same stream
+            _mlib.load().mi_prof_empty_launch(max(1, B // 4), 256, _mlib.stream_ptr(dev))
         torch.cuda.synchronize()
+    pair_wall_us = None if sharded else gather_pair_in_graph_wall_us(model, ring, nx, B, F, D, dev)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -387,6 +773,22 @@ def main():
                         "fwd_bwd_pair": {"us": round(pair_us, 3),
                                          "GBps": round((fb + bb) * B / (pair_us * 1e-6) / 1e9, 1),
                                          "frac": round((fb + bb) * B / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if roofline is not None and "empty" in kernels:
+            # The per-dispatch clock (what rocprofv3 --kernel-trace reports too) reads ~4 us for a launch that does nothing,
+            # whatever its grid: two EMPTY kernels already take ~8.2 of the 9.17 us the 50 % target allows the pair.
+            fl = kernels["empty"]["avg_us"]
+            roofline["floor_us"] = fl
+            roofline["floor_note"] = ("avg duration of an EMPTY kernel (same geometry, launcher, stream and clock) in this run; "
+                                      "net_of_floor subtracts it from each kernel of the pair")
+            net = max(pair_us - fl * len(cand), 1e-3)
+            roofline["fwd_bwd_pair"]["net_of_floor"] = {
+                "us": round(net, 3), "GBps": round((fb + bb) * B / (net * 1e-6) / 1e9, 1),
+                "frac": round((fb + bb) * B / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            if pair_wall_us is not None:
+                roofline["fwd_bwd_pair"]["in_graph_wall"] = {
+                    "us": round(pair_wall_us, 3), "GBps": round((fb + bb) * B / (pair_wall_us * 1e-6) / 1e9, 1),
+                    "frac": round((fb + bb) * B / (pair_wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "what": "wall time per fwd+bwd pair inside a replayed hipGraph of 32 pairs (fresh ids each), i.e. what a step pays"}
         if roofline is not None and not args.c4:
             roofline["measured_stream_ceiling"] = measured_copy_ceiling(dev)
         out = {

@@ -590,6 +590,9 @@ MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, cons
  */
 MI_API int mi_prof_enable(int32_t capacity); /* >0: (re)arm with that many records; 0: disable */
 MI_API int mi_prof_count(void);
+/* An empty kernel of the given geometry through the same launcher / timing ring ("empty"): the duration the
+ * per-dispatch clock reads for a launch that does nothing — the floor under every kernel time it reports. */
+MI_API int mi_prof_empty_launch(int32_t grid, int32_t block, void *stream);
 /* Synchronises on record i's stop event; name_out is a host buffer of >=64 bytes. */
 MI_API int mi_prof_read(int32_t i, char *name_out, float *ms_out);
 

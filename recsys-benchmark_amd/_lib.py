@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
                            _i32, _i32, _p],
     "mi_prof_count": [],
+    "mi_prof_empty_launch": [_i32, _i32, _p],
     "mi_prof_read": [_i32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)],
 }
 _RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
