@@ -424,6 +424,13 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
                                  float *exp_avg_sq, float *acc, int64_t n, int32_t D,
                                  int64_t N, float step_size, const float *step_size_dev,
                                  double beta1, double beta2, float eps, void *stream);
+/* mi_coalesce_rows_sorted: the deterministic dense gradient of a table out of its row-form gradient (what the reference's
+ *   CPU index_add accumulates in a fixed order, src/models/embeddings/base.py:74-75 through autograd): G[row,:] = sum of
+ *   vals[perm[i],:] over the sorted positions with rows_sorted[i] == row, added in a fixed order (the segmented sums of
+ *   mi_sparse_adam_sorted, stored instead of applied; no atomics).  G fp32[N,D] zero-filled by the caller; acc fp32[n,D]
+ *   scratch. */
+MI_API int mi_coalesce_rows_sorted(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *G,
+                                   float *acc, int64_t n, int32_t D, int64_t N, void *stream);
 /* mi_sort_field_rows: rows int64[B,F] with rows[b,f] in [offsets[f], offsets[f+1]) (offsets ascending, offsets[F] := N —
  *   the ids DeepFM forms at src/models/deepfm.py:88).  rows_sorted[B*F] ascending and perm[i] = flat position b*F+f of
  *   the i-th smallest, equal ids in ascending b (a stable sort); an id outside its field's range comes back as N behind

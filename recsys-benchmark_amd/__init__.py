@@ -11,8 +11,20 @@ from .factory import (get_ctr_model, get_graph_model, load_ctr_model, load_graph
                       save_ctr_checkpoint)
 from .lightgcn import LightGCN, SingleLightGCN
 
+
+
+def use_deterministic_algorithms(on: bool = True) -> None:
+    """Bit-reproducible DeepFM / DCN training steps: dense table gradients by sorted, ordered accumulation instead of float
+    atomics, unsplit K in the library's GEMM, and the MLP tail on the fused kernels of csrc/tail.hip.  Slower than the
+    default; the reference's CPU path is deterministic, which is what this mode matches."""
+    from . import _kernels, mlp
+
+    _kernels.DETERMINISTIC = bool(on)
+    mlp.FUSED_TAIL = bool(on)
+
+
 __all__ = [
     "DeepFM", "IEmbedding", "VanillaEmbedding", "NAME_TO_CLS", "get_embedding",
     "LightGCN", "SingleLightGCN", "get_ctr_model", "get_graph_model", "load_ctr_model", "load_graph_model",
-    "save_cf_emb_checkpoint", "save_ctr_checkpoint", "MI355XLibraryError", "check_index_errors",
+    "save_cf_emb_checkpoint", "save_ctr_checkpoint", "MI355XLibraryError", "check_index_errors", "use_deterministic_algorithms",
 ]

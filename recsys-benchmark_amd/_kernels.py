@@ -99,7 +99,7 @@ class GatherFM(torch.autograd.Function):
             ),
             "mi_gather_fm_fwd",
         )
-        if sparse_W or sparse_w1:
+        if sparse_W or sparse_w1 or DETERMINISTIC:
             note_field_layout(rows, offsets, N)
         ctx.save_for_backward(emb, rows)
         ctx.shapes = (B, F, D, N, tuple(W.shape), tuple(w1.shape))
@@ -125,6 +125,8 @@ class GatherFM(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         rows_form = (sparse_W and need_W) or (sparse_w1 and need_w1)
         dense_form = (need_W and not sparse_W) or (need_w1 and not sparse_w1)
+        if DETERMINISTIC and dense_form:
+            rows_form, dense_form = True, False     # row-form values, then a sorted (ordered) accumulation: no atomics
         # the bias gradient (sum of g_y) rides in whichever backward kernel runs first
         gb = torch.empty((1,), dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
         gb_done = False
@@ -163,7 +165,34 @@ class GatherFM(torch.autograd.Function):
         return None, None, gW, gw1, gb, None, None
 
 
+# Deterministic mode (recsys_benchmark_amd.use_deterministic_algorithms): dense table gradients are built by SORTING the
+# row ids and adding each row's contributions in a fixed order (mi_coalesce_rows_sorted) instead of float atomics — the
+# reference's CPU index_add is deterministic too (src/models/embeddings/base.py:74-75 through autograd) —, the products
+# that would split K over atomically accumulating workgroups run unsplit, and the MLP tail runs on the fused kernels of
+# csrc/tail.hip (no atomics).  Off by default: the atomic forms are faster.
+DETERMINISTIC = False
+
+
+def coalesce_dense(rows: torch.Tensor, vals: torch.Tensor, N: int, D: int) -> torch.Tensor:
+    """Dense [N, D] gradient of a table out of row-form (rows[n], vals[n, D]) contributions, added in a fixed order."""
+    dev = vals.device
+    rows = rows.reshape(-1)
+    n = rows.numel()
+    out = torch.zeros((N, D), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    found = sort_field_rows(rows, N)
+    rs, perm = found if found is not None else torch.sort(rows, stable=True)
+    acc = torch.empty((n, D), dtype=torch.float32, device=dev)
+    vals = _f32c(vals).view(n, D)
+    _lib.check(_lib.load().mi_coalesce_rows_sorted(rs.data_ptr(), perm.data_ptr(), vals.data_ptr(), out.data_ptr(), acc.data_ptr(),
+                                                   n, D, N, _lib.stream_ptr(dev)), "mi_coalesce_rows_sorted")
+    return out
+
+
 def _scatter_rows(rows, vals, N, D, stream):
+    if DETERMINISTIC:
+        return coalesce_dense(rows, vals, N, D)
     out = torch.zeros((N, D), dtype=torch.float32, device=vals.device)
     _lib.check(_lib.load().mi_scatter_axpy_rows(rows.data_ptr(), vals.data_ptr(), 1.0, out.data_ptr(), rows.numel(), D, N,
                                                 stream), "mi_scatter_axpy_rows")
@@ -205,6 +234,8 @@ class GatherRows(torch.autograd.Function):
         g = _f32c(g).view(n, D)
         if sparse:
             return None, _coo(idxc.view(-1), g, Wshape), None
+        if DETERMINISTIC:
+            return None, coalesce_dense(idxc, g, N, D).view(Wshape), None
         gW = torch.zeros((N, D), dtype=torch.float32, device=g.device)
         _lib.check(
             _lib.load().mi_scatter_add_rows(idxc.data_ptr(), g.data_ptr(), gW.data_ptr(), n, D, N,
@@ -628,7 +659,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, s
         if epi in ("none", "accum"):
             tiles = -(-M // 64) * -(-N // 64) * batch
             ksteps = -(-K // 32) * kgroups
-            if tiles < 256 and ksteps >= 16:
+            if tiles < 256 and ksteps >= 16 and not DETERMINISTIC:   # slices meet in float atomics
                 splitk = max(1, min(ksteps // 4, -(-512 // tiles), 65535 // max(batch, 1)))
         if splitk > 1 and epi == "none":
             if C.is_contiguous() and C.numel() == batch * M * N:

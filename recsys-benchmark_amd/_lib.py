@@ -56,6 +56,7 @@ SIGNATURES = {
                                _p],
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
                               ctypes.c_double, ctypes.c_float, _p],
+    "mi_coalesce_rows_sorted": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_sort_field_rows_workspace_bytes": [_i64, _i32],
     "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p],
     "mi_adam_dense_multi": [_p, _p, _p, _p, _p, _p, _i32, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_float,

@@ -22,6 +22,7 @@ struct AdamArgs {
   int64_t n, N;
   float step_size, omb1, omb2, eps;   // omb = 1 - beta, formed in double by the host (1.f - 0.999f is off by 1.3e-5)
   const float *step_size_dev;   // when given: the step size lives on the device (mi_adam_tick), hipGraph replays
+  float *G;                     // when given: no update — the coalesced gradient row is STORED to G[row] (mi_coalesce_rows_sorted)
 };
 
 // t += 1; step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) in double, like the host computes it in the eager path
@@ -74,6 +75,7 @@ template <> struct Vec<1> {
 };
 
 __device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, const Vec<4> &g) {
+  if (a.G) { st4(a.G + o, g.v); return; }
   float4 m = ld4(a.M + o), v = ld4(a.V + o), w = ld4(a.W + o);
   w.x -= adam1(a, g.v.x, m.x, v.x);
   w.y -= adam1(a, g.v.y, m.y, v.y);
@@ -84,6 +86,7 @@ __device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, const Vec
   st4(a.W + o, w);
 }
 __device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, const Vec<1> &g) {
+  if (a.G) { a.G[o] = g.v; return; }
   float m = a.M[o], v = a.V[o];
   a.W[o] -= adam1(a, g.v, m, v);
   a.M[o] = m;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam_anyD(AdamArgs a, int D) 
       float g = a.vals[a.perm[i] * D + d];
       for (int64_t j = i + 1; j < a.n && a.rows[j] == row; ++j) g += a.vals[a.perm[j] * D + d];
       const int64_t o = row * D + d;
+      if (a.G) { a.G[o] = g; continue; }
       float m = a.M[o], v = a.V[o];
       a.W[o] -= adam1(a, g, m, v);
       a.M[o] = m;
@@ -287,6 +291,9 @@ inline bool vec_ok(int D) { return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 
 
 extern "C" {
 
+static int launch_sorted_rows(AdamArgs a, int32_t D, const float *vals, const void *p0, const void *p1, const void *p2,
+                              float *acc, void *stream);
+
 int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *W,
                           float *exp_avg, float *exp_avg_sq, float *acc, int64_t n, int32_t D, int64_t N,
                           float step_size, const float *step_size_dev, double beta1, double beta2, float eps,
@@ -295,7 +302,25 @@ int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const
   if (n == 0) return MI_OK;
   if (!rows_sorted || !perm || !vals || !W || !exp_avg || !exp_avg_sq || !acc) return MI_ERR_INVALID_ARG;
   AdamArgs a{rows_sorted, perm, vals, W, exp_avg, exp_avg_sq, acc, n, N, step_size, (float)(1.0 - beta1), (float)(1.0 - beta2),
-             eps, step_size_dev};
+             eps, step_size_dev, nullptr};
+  return launch_sorted_rows(a, D, vals, W, exp_avg, exp_avg_sq, acc, stream);
+}
+
+// The same segmented sums, stored instead of applied: G[row, :] = sum of vals[perm[i], :] over the sorted positions i with
+// rows_sorted[i] == row, added in a FIXED order (no atomics) — a bit-reproducible dense gradient out of row-form values.
+// Rows that do not occur are not written: the caller zero-fills G.
+int mi_coalesce_rows_sorted(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *G, float *acc,
+                            int64_t n, int32_t D, int64_t N, void *stream) {
+  if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!rows_sorted || !perm || !vals || !G || !acc) return MI_ERR_INVALID_ARG;
+  AdamArgs a{rows_sorted, perm, vals, nullptr, nullptr, nullptr, acc, n, N, 0.f, 0.f, 0.f, 0.f, nullptr, G};
+  return launch_sorted_rows(a, D, vals, G, G, G, acc, stream);
+}
+
+static int launch_sorted_rows(AdamArgs a, int32_t D, const float *vals, const void *W, const void *exp_avg,
+                              const void *exp_avg_sq, float *acc, void *stream) {
+  const int64_t n = a.n;
 #define CALL(LPR, VW)                                                                        \
   do {                                                                                       \
     const int grid = grid_for_waves((n + (kWave / LPR) - 1) / (kWave / LPR));                \

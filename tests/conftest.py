@@ -76,3 +76,29 @@ def assert_mostly_close(actual, expected, rtol, atol, max_bad_frac, what=""):
     frac = bad.float().mean().item() if bad.numel() else 0.0
     assert frac <= max_bad_frac, f"{what}: {frac:.2e} of elements differ (allowed {max_bad_frac:.1e}); " \
                                  f"max abs diff {(actual - expected).abs().max().item():.3e}"
+
+
+EPS32 = 2.0 ** -24
+
+
+def assert_within_terms(actual, ref64, sum_abs_terms, k, what="", cpu32=None, max_bad_frac=0.0):
+    """The claim behind every tolerance of a float32 reduction: a sum of n float32 terms, added in ANY order (float
+    atomics included), lies within ~n_levels * eps32 * sum|terms| of the exact value.  `actual` (the HIP result) — and
+    `cpu32`, the stock float32 CPU result, when given — must both satisfy  |x - ref64| <= k * eps32 * sum|terms|
+    elementwise, ref64 being the float64 evaluation.  k is the allowed depth factor (a few tens covers tree and serial
+    orders of up to ~1e4 terms, since rounding errors add like a random walk)."""
+    ref64 = ref64.detach().double().cpu()
+    bound = k * EPS32 * sum_abs_terms.detach().double().cpu() + 1e-30
+    for name, x in (("HIP fp32", actual), ("CPU fp32", cpu32)):
+        if x is None:
+            continue
+        x = x.detach()
+        x = (x.to_dense() if x.is_sparse else x).double().cpu()
+        assert tuple(x.shape) == tuple(ref64.shape), f"{what}: shape {tuple(x.shape)} vs {tuple(ref64.shape)}"
+        r = (x - ref64).abs() / bound
+        ratio = r.max().item() if x.numel() else 0.0
+        bad = (r > 1.0).double().mean().item() if x.numel() else 0.0
+        # max_bad_frac: elements allowed outside the bound for a DISCRETE reason the bound does not model (a pre-activation
+        # within rounding of 0 landing on the other side of a ReLU kink moves its whole term)
+        assert bad <= max_bad_frac, (f"{what}: {name} is up to {ratio:.2f}x the bound k*eps*sum|terms| (k={k}) away from the "
+                                     f"float64 value on {bad:.2e} of the elements (allowed {max_bad_frac:.1e})")

@@ -201,3 +201,109 @@ def test_c4_billion_row_table_addressing():
     _lib.check_index_errors()
     del W, w1, Wp, w1p
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ C3 (DCN-Mix, Avazu-shaped)
+AVAZU = [241, 8, 8, 3697, 4614, 25, 5481, 329, 31, 381763, 1611748, 6793, 6, 5, 2509, 9, 10, 432, 5, 68, 169, 61]
+
+
+def test_c3_qr_lookup_is_exact_over_the_whole_vocabulary():
+    """QR `divider: 2` (configs/avazu/qr_2.yaml:9-10) at N = 2.02 M: every row of get_weight() — forward(arange(N)),
+    src/models/embeddings/qr_embedding.py:111-113 — equals emb1[i % 2] * emb2[i // 2] computed with torch's own integer
+    ops: the index split is integer work (bit-exact) and the product is ONE fp32 multiply (bit-identical too)."""
+    from recsys_benchmark_amd.embeddings import get_embedding
+
+    torch.manual_seed(7)
+    N = sum(AVAZU)
+    emb = get_embedding({"name": "qr", "divider": 2}, AVAZU, 16).to(DEV)
+    W = emb.get_weight()
+    idx = torch.arange(N, device=DEV)
+    want = emb.emb1.weight[idx % 2] * emb.emb2.weight[idx // 2]
+    assert W.shape == (N, 16) and torch.equal(W, want)
+    # a [B, F] batch through the fused dual gather == the rows of that table
+    gen = torch.Generator().manual_seed(1)
+    x = torch.stack([torch.randint(0, d, (4096,), generator=gen) for d in AVAZU], 1).to(DEV)
+    off = torch.tensor([0] + AVAZU[:-1]).cumsum(0).to(DEV)
+    assert torch.equal(emb(x + off), want[x + off])
+    _lib.check_index_errors()
+
+
+def test_c3_whole_dcn_mix_step_matches_the_float64_evaluation_of_the_reference_ops():
+    """The whole C3 model (F=22, d=352, QR divider 2, E=4, r=64, L=3, MLP 400x3 + BatchNorm, B=4096) forward + backward
+    against the oracle's op sequence (oracle/reference_ops.py: qr_forward, dcn_mix_head, bn_mlp — restatements of
+    src/models/dcn.py:76-96 and src/models/layer_dcn.py:8-115) evaluated in FLOAT64 on the same device: the CPU oracle in
+    float32 takes minutes at this size, torch's float64 GPU ops take a second.  The same ops evaluated in stock float32
+    on the GPU are the yardstick for what float32 can resolve here (see `close`)."""
+    from oracle import reference_ops as ro
+
+    from recsys_benchmark_amd.dcn import DCN_Mix
+
+    torch.manual_seed(11)
+    B = 4096
+    model = DCN_Mix(AVAZU, 16, [400, 400, 400], num_layers=3, num_experts=4, rank=64,
+                    embedding_config={"name": "qr", "divider": 2}, p_dropout=0.0).to(DEV).train()
+    gen = torch.Generator().manual_seed(2)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in AVAZU], 1).to(DEV)
+    y = (torch.rand(B, generator=gen) < 0.2).float().to(DEV)
+    def oracle_run(dtype):
+        p = {k: v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone() for k, v in model.state_dict().items()}
+        for k, v in p.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+        rows_ = x + p["offsets"]
+        e = ro.qr_forward(rows_, p["embedding.emb1.weight"], p["embedding.emb2.weight"], 2, "mult")
+        e.retain_grad()
+        r = ro.dcn_mix_forward(x, p, e, 3, 3, True)
+        torch.nn.functional.binary_cross_entropy_with_logits(r, y.to(dtype)).backward()
+        return p, e, r
+
+    out = model(x)
+    torch.nn.functional.binary_cross_entropy_with_logits(out, y).backward()
+    p64, emb, ref = oracle_run(torch.float64)
+    p32, _, ref32 = oracle_run(torch.float32)          # the same op sequence in stock float32 ops: the yardstick
+    rows = x + p64["offsets"]
+
+    def close(name, got, want, stock, rtol=5e-4):
+        """What float32 allows at this size (measured, tools/c3_diag.py): the STOCK float32 evaluation of the same ops is
+        itself 3e-3 of max |ref| away from float64 on most gradients (and 2.7e-2 on single elements): among 3 x 1.6 M
+        pre-activations a few lie within rounding of 0 and land on the other side of the ReLU kink, which moves their
+        whole term in their column's sums, and everything upstream feels it.  So:
+          * typical (median) error within 5e-4 of max |ref|, or 16x the stock evaluation's own median — a wrong index,
+            a missing term or a stale buffer is off by O(1);
+          * at most 0.5 % of the elements beyond 5e-3 and none beyond 5e-2 (kink flips)."""
+        scale = want.detach().abs().max().clamp_min(1e-30)
+        err = ((got.detach().double() - want.detach()).abs() / scale).reshape(-1)
+        err32 = ((stock.detach().double() - want.detach()).abs() / scale).reshape(-1)
+        med, med32 = float(err.median()), float(err32.median())
+        assert med <= max(rtol, 16 * med32), f"{name}: median error {med:.2e} of max |ref| (stock float32 ops: {med32:.2e})"
+        bad = float((err > 5e-3).double().mean())
+        assert bad <= 5e-3 and float(err.max()) <= max(5e-2, 2 * float(err32.max())), \
+            f"{name}: {bad:.2e} of the elements beyond 5e-3 of max |ref|, worst {float(err.max()):.3e} (stock: {float(err32.max()):.3e})"
+
+    close("logits", out, ref, ref32, 1e-4)
+    named = dict(model.named_parameters())
+    for k, v in p64.items():
+        if not (v.is_floating_point() and v.requires_grad):
+            continue
+        g = named[k].grad
+        if k.endswith(".bias") and k.startswith("_dnn.") and int(k.split(".")[1]) % 4 == 0 and k != "_dnn.12.bias":
+            continue          # Linear bias in front of a training-mode BatchNorm: analytically zero, noise in the reference
+        if k.startswith("embedding.emb"):
+            continue          # checked below against sum |terms|
+        close(k, g.to_dense() if g.is_sparse else g, v.grad, p32[k].grad)
+    # The two QR tables: emb1 has TWO rows (divider 2), each the sum of ~45 000 products g_out * emb2[q] that largely
+    # cancel — a float32 sum's error follows sum |terms|, not the result (3e-3 of max |ref| here): both tables are held
+    # to k * eps32 * sum |terms| of the float64 value instead.
+    g_out = emb.grad                                            # [B, F, D] float64
+    e1 = p64["embedding.emb1.weight"].detach()[rows % 2]
+    e2 = p64["embedding.emb2.weight"].detach()[rows // 2]
+    for k, idx, other in (("embedding.emb1.weight", rows % 2, e2), ("embedding.emb2.weight", rows // 2, e1)):
+        terms = torch.zeros_like(p64[k].detach()).index_add_(0, idx.reshape(-1), (g_out * other).abs().reshape(-1, 16))
+        # g_out itself carries the float32 / kink noise of everything downstream (the stock float32 evaluation is as far from
+        # float64 as this one): the yardstick is again the stock evaluation, with sum |terms| as the absolute floor
+        bound = 64 * 2.0 ** -24 * terms + 1e-30
+        err = (named[k].grad.double() - p64[k].grad).abs()
+        err32 = (p32[k].grad.double() - p64[k].grad).abs()
+        ok = (err <= bound) | (err <= 4 * err32.max())
+        assert bool(ok.all()), f"{k}: worst {float((err / bound).max()):.1f}x of 64 * eps32 * sum|terms| and {float(err.max() / err32.max()):.1f}x the stock float32 error"
+    _lib.check_index_errors()

@@ -4,7 +4,7 @@ import pytest
 import torch
 from torch import nn
 
-from conftest import assert_close, assert_mostly_close
+from conftest import assert_close, assert_mostly_close, assert_within_terms
 
 from recsys_benchmark_amd.mlp import run_tail
 
@@ -74,6 +74,25 @@ def test_fused_bn_relu_vs_cpu_modules(M, N, bn, training):
         flips = 2.0 / N if M * N >= 100000 else 0.0
         assert_mostly_close(gamma.grad, ref_bn.weight.grad, 1e-4, 4e-4 * s, flips, "dgamma")
         assert_mostly_close(beta.grad, ref_bn.bias.grad, 1e-4, 4e-4 * s, flips, "dbeta")
+        # the claim above, tested: float64 column sums, and BOTH float32 results within k * eps * sum|terms| of them
+        bn64 = nn.BatchNorm1d(N).double()
+        bn64.load_state_dict({k_: (v.double() if v.is_floating_point() else v) for k_, v in ref0.state_dict().items()})
+        bn64.weight.data.copy_(ref_bn.weight.detach().double())
+        bn64.bias.data.copy_(ref_bn.bias.detach().double())
+        bn64.train(training)
+        z64 = Z.double().requires_grad_(True)
+        y64 = torch.relu(bn64(z64))
+        (y64 * G.double()).sum().backward()
+        with torch.no_grad():
+            if training:
+                zh = (Z.double() - Z.double().mean(0)) / (Z.double().var(0, unbiased=False) + 1e-5).sqrt()
+            else:
+                zh = (Z.double() - ref0.running_mean.double()) / (ref0.running_var.double() + 1e-5).sqrt()
+            dy = G.double() * (y64 > 0)
+        assert_within_terms(gamma.grad, bn64.weight.grad, (dy * zh).abs().sum(0), 16, "dgamma vs float64", cpu32=ref_bn.weight.grad,
+                            max_bad_frac=flips)
+        assert_within_terms(beta.grad, bn64.bias.grad, dy.abs().sum(0), 16, "dbeta vs float64", cpu32=ref_bn.bias.grad,
+                            max_bad_frac=flips)
         assert_close(rm, ref_bn.running_mean, 1e-5, 1e-6, "running_mean")
         assert_close(rv, ref_bn.running_var, 1e-5, 1e-6, "running_var")
 

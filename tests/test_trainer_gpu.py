@@ -354,3 +354,42 @@ def test_dcn_with_row_form_gradients_trains_like_torch_optimizers(cls_name):
     # ten) — 2e-4 is 2 % of one step, a wrong sort or a stale buffer would be off by whole steps
     for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
         assert_close(a, b, 5e-3, 2e-4, k)
+
+
+def test_adam_amplified_differences_are_noise_around_the_float64_run():
+    """The tolerances of the training-equivalence tests above (5e-3 relative / 1 % of one lr-sized step absolute) rest on
+    one claim: float32 summation order (float atomics, split-K) leaves last-bit noise in near-zero gradients, which Adam's
+    1/sqrt(v) normalisation amplifies — noise AROUND the exact trajectory, not a drift away from it.  Tested as such: the
+    same nine steps in FLOAT64 through the oracle's op sequence (oracle/reference_ops.py deepfm_forward = the reference's
+    src/models/deepfm.py:79-105) and torch.optim.Adam(weight_decay) — the reference's dense configuration,
+    src/models/deepfm.py:186-193 — and BOTH float32 runs (hipGraph replay and eager) must sit within that tolerance of the
+    float64 parameters."""
+    from oracle import reference_ops as ro
+
+    cfg = {"sparse": False, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
+    eager_model = _model(False)
+    graph_model = copy.deepcopy(eager_model)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.detach().clone()) for k, v in eager_model.state_dict().items()}
+    leaves = []
+    for k, v in p64.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+            leaves.append(v)
+    opt64 = torch.optim.Adam(leaves, lr=1e-2, weight_decay=1e-6)
+    eager = trainer.GraphedTrainStep(eager_model, get_optimizers(eager_model, cfg), use_graph=False)
+    graphed = trainer.GraphedTrainStep(graph_model, get_optimizers(graph_model, cfg), warmup=2)
+    crit = torch.nn.BCEWithLogitsLoss()
+    for x, y in _batches(9, 256, 11):
+        x, y = x.to(DEV), y.to(DEV)
+        eager(x, y)
+        graphed(x, y)
+        opt64.zero_grad()
+        crit(ro.deepfm_forward(x, p64, 2, True, True), y.double()).backward()
+        opt64.step()
+    assert graphed._graph is not None
+    sd_e, sd_g = eager_model.state_dict(), graph_model.state_dict()
+    for k, v in p64.items():
+        if not (v.is_floating_point() and v.requires_grad) or k == "linear_layer.weight":
+            continue
+        for name, sd in (("eager", sd_e), ("graph", sd_g)):
+            assert_close(sd[k].double(), v.detach(), 5e-3, 1e-4, f"{k} ({name} float32 run vs the float64 run)")
