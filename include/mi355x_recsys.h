@@ -9,6 +9,10 @@
  *   - the caller owns every buffer; the library allocates no persistent memory;
  *   - every entry point enqueues on `stream` (a hipStream_t passed as void*)
  *     and returns without synchronising; no hidden syncs, graph-capture safe;
+ *   - an entry point enqueues its kernel(s) and NOTHING ELSE, with five documented exceptions that also enqueue one
+ *     hipMemsetAsync on the same stream (a memset node when captured): mi_slot_fm_bwd zero-fills gbuf (unused slots must
+ *     read as zero gradients), mi_bpr_fwd / mi_rowsq_fwd / mi_lse_diag_fwd zero the 4-byte arrival ticket at the end
+ *     of their workspace, mi_tt_plan_level zeroes its p digit counters;
  *   - return value: MI_OK (0) or a negative MI_ERR_* code; no exceptions cross
  *     the ABI; calls are re-entrant;
  *   - `err` (nullable) is a device int32 word: kernels OR a bit into it when an

@@ -61,6 +61,31 @@ def bucket_capacity(n: int, world: int, slack: float) -> int:
     return min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
 
 
+def expected_peak_load(field_dims: List[int], batch: int, world: int) -> float:
+    """Largest expected number of lookups one owner receives from a batch of `batch` samples when the ids of every field
+    are uniform over that field: owner = (offset_f + id) % world, so a field with fewer values than ranks sends ALL its
+    `batch` lookups to at most `cardinality` owners (a 3-value Criteo field: batch/3 each to 3 owners, nothing to the
+    other 5) — the plain mean n/world underestimates that."""
+    load = [0.0] * world
+    off = 0
+    for c in field_dims:
+        base, extra = divmod(c, world)               # owners of rows off .. off+c-1
+        for o in range(world):
+            rows = base + (1 if ((o - off) % world) < extra else 0)
+            load[o] += batch * rows / c
+        off += c
+    return max(load)
+
+
+def field_bucket_capacity(field_dims: List[int], batch: int, world: int, slack: float) -> int:
+    """bucket_capacity sized for the fields at hand: expected_peak_load with `slack` headroom + six standard deviations."""
+    n = batch * len(field_dims)
+    if world == 1:
+        return n
+    peak = expected_peak_load(field_dims, batch, world)
+    return min(n, int(peak * slack + 6.0 * (peak ** 0.5)) + 64)
+
+
 class _Exchange(torch.autograd.Function):
     """x[B,F] raw ids -> (packed rows received [world*cap + 1, D+4], slot[B,F]).
 
@@ -73,7 +98,7 @@ class _Exchange(torch.autograd.Function):
     def forward(ctx, x, W_local, w1_local, model):
         ops, world, group = model.ops, model.world, model.group
         D = W_local.shape[1]
-        cap = bucket_capacity(x.numel(), world, model.bucket_slack)
+        cap = model.capacity(x.shape[0])
         S = world * cap
         static = model.__dict__.get("_static_io")
         use_static = static is not None and static[0].shape[0] == S + 1 and tuple(static[1].shape) == tuple(x.shape)
@@ -131,6 +156,7 @@ class ShardedDeepFM(nn.Module):
         super().__init__()
         self.ops = ops or HipOps
         self.bucket_slack = bucket_slack
+        self.field_dims = list(field_dims)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
@@ -203,6 +229,10 @@ class ShardedDeepFM(nn.Module):
                     torch.optim.SGD(self.dense_parameters(), lr=config["learning_rate"], weight_decay=config["weight_decay"])]
         raise ValueError(f"optimizer_name={name!r} is not recognized")
 
+    def capacity(self, batch: int) -> int:
+        """Slots per peer bucket for a batch of `batch` samples (every rank computes the same number)."""
+        return field_bucket_capacity(self.field_dims, batch, self.world, self.bucket_slack)
+
     def check_overflow(self):
         """Synchronise; raise if any fixed-capacity bucket overflowed since the last check."""
         if bool(self.bucket_overflow.item()):
@@ -232,7 +262,7 @@ class ShardedDeepFM(nn.Module):
         The exchange writes straight into the graphs' static inputs (no staging copy)."""
         F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
         dev = self.embedding_shard.device
-        S = self.world * bucket_capacity(batch_size * F, self.world, self.bucket_slack)
+        S = self.world * self.capacity(batch_size)
         # no collective may be in flight while a capture is open (the RCCL watchdog polls events)
         torch.cuda.synchronize(dev)
         dist.barrier(group=self.group)
@@ -274,7 +304,7 @@ class ShardedDeepFM(nn.Module):
         F, D = self.offsets.shape[1], self.embedding_shard.shape[1]
         dev = self.embedding_shard.device
         world, group = self.world, self.group
-        cap = bucket_capacity(batch_size * F, world, self.bucket_slack)
+        cap = self.capacity(batch_size)
         S = world * cap
         dense = self.dense_parameters()
         recv = torch.zeros(S + 1, D + 4, device=dev).requires_grad_(True)

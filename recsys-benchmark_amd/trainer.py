@@ -147,6 +147,8 @@ def train_epoch(dataloader, model, optimizers: Union[List[torch.optim.Optimizer]
         if log_step and idx % log_step == 0:
             logger.info("Idx: %d - loss: %.4g", idx, (float(step.loss_sum) - first_sum) / (idx + 1))
             _lib.check_index_errors()        # the reference's nn.Embedding raises on the offending batch; here at the next sync
+            if hasattr(model, "check_overflow"):
+                model.check_overflow()       # row-sharded model: a peer bucket that overflowed dropped lookups
         if profiler:
             profiler.step()
         end_train = start = now()
@@ -154,6 +156,8 @@ def train_epoch(dataloader, model, optimizers: Union[List[torch.optim.Optimizer]
     n = step.steps - first_steps
     loss_dict = {"loss": (float(step.loss_sum) - first_sum) / n if n else 0.0}
     _lib.check_index_errors()
+    if hasattr(model, "check_overflow"):
+        model.check_overflow()
     logger.info("train_time: %s", train_time)
     logger.info("load_data_time: %s", load_data_time)
     logger.info("total_time: %s", now() - first_start)

@@ -242,3 +242,31 @@ def test_csr_plan_caches_never_serve_a_recycled_address():
         p = K.csr_plan(g)
         assert torch.equal(p.crow.long(), g.crow_indices()) and torch.equal(p.col.long(), g.col_indices())
         del g, p
+
+
+def test_bucket_capacity_accounts_for_fields_with_fewer_values_than_ranks():
+    """A Criteo field with 3 values sends its whole column to 3 owners: the per-field capacity must cover the most loaded
+    owner's EXPECTED load with headroom, which the plain mean n / world does not (advisor finding, round 1)."""
+    from recsys_benchmark_amd.sharded import bucket_capacity, expected_peak_load, field_bucket_capacity
+
+    criteo = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
+              27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+    B, world = 4096, 8
+    gen = torch.Generator().manual_seed(0)
+    off = torch.tensor([0] + criteo[:-1]).cumsum(0)
+    peak = expected_peak_load(criteo, B, world)
+    assert peak > B * len(criteo) / world                      # the low-cardinality fields concentrate
+    worst = 0
+    for _ in range(20):
+        rows = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in criteo], 1) + off
+        worst = max(worst, int(torch.bincount((rows % world).view(-1), minlength=world).max()))
+    cap = field_bucket_capacity(criteo, B, world, 1.25)
+    assert worst <= cap, (worst, cap)
+    assert abs(worst - peak) < 6 * peak ** 0.5 + 64            # and the estimate is the right size
+    # adversarial: every other field has ONE value and they all land on owner 0 (offsets 0, 8, 16, ...) — the old sizing
+    # would overflow, this one must not
+    tiny = [1, 7] * 8
+    rows_per_owner = expected_peak_load(tiny, B, world)
+    assert rows_per_owner > bucket_capacity(B * len(tiny), world, 1.25)
+    assert field_bucket_capacity(tiny, B, world, 1.25) >= rows_per_owner
+    assert field_bucket_capacity(tiny, B, 1, 1.25) == B * len(tiny)
