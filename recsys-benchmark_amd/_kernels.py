@@ -1025,6 +1025,58 @@ def masked_gather(idx, W, mask):
     return XformGather.apply(idx, W, None, mask, 0, 0, XF_MASK)
 
 
+class _MaskedGatherRowGrad(torch.autograd.Function):
+    """out = (W * mask)[idx] with W.grad in ROW FORM (uncoalesced COO over idx, values g * mask[idx]) — what the reference's
+    F.embedding(x, weight * mask, sparse=True) hands torch.optim.SparseAdam (src/models/embeddings/pep_embedding.py:215-221)."""
+
+    @staticmethod
+    def forward(ctx, idx, W, mask):
+        with torch.no_grad():
+            out = masked_gather(idx, W, mask)
+        ctx.save_for_backward(_i64c(idx).reshape(-1), mask)
+        ctx.wshape = tuple(W.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, mask = ctx.saved_tensors
+        D = ctx.wshape[1]
+        vals = _f32c(g).reshape(-1, D) * mask.index_select(0, flat).to(torch.float32)
+        return None, _coo(flat, vals, ctx.wshape), None
+
+
+def masked_gather_row_grad(idx, W, mask):
+    return _MaskedGatherRowGrad.apply(idx, W, mask)
+
+
+class _DualMaskedGatherRowGrad(torch.autograd.Function):
+    """out = (T1 * M1)[idx % mod1] + (T2 * M2)[idx // div2] with both gradients in row form (RetrainCerpEmbedding with
+    sparse=True, src/models/embeddings/cerp_embedding.py:329-367)."""
+
+    @staticmethod
+    def forward(ctx, idx, T1, T2, M1, M2, mod1: int, div2: int):
+        with torch.no_grad():
+            out = dual_gather(idx, T1, T2, mod1=mod1, div2=div2, op="add", M1=M1, M2=M2)
+        flat = _i64c(idx).reshape(-1)
+        ctx.save_for_backward(flat, M1, M2)
+        ctx.meta = (int(mod1), int(div2), tuple(T1.shape), tuple(T2.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, M1, M2 = ctx.saved_tensors
+        mod1, div2, s1, s2 = ctx.meta
+        g2 = _f32c(g).reshape(-1, s1[1])
+        i1, i2 = flat % mod1, torch.div(flat, div2, rounding_mode="floor")
+        g1 = _coo(i1, g2 * M1.index_select(0, i1).to(torch.float32), s1) if ctx.needs_input_grad[1] else None
+        gq = _coo(i2, g2 * M2.index_select(0, i2).to(torch.float32), s2) if ctx.needs_input_grad[2] else None
+        return None, g1, gq, None, None, None, None
+
+
+def dual_masked_gather_row_grad(idx, T1, T2, M1, M2, mod1: int, div2: int):
+    return _DualMaskedGatherRowGrad.apply(idx, T1, T2, M1, M2, mod1, div2)
+
+
 def gather_rows_quant(idx, W, scale=None, bias=None):
     """Dequantising row gather for fp16 / int8 / int16 tables (inference only)."""
     dev = _lib.require_gpu(idx, W)

@@ -179,9 +179,6 @@ class RetrainCerpEmbedding(IEmbedding):
         self._num_item = num_item
         self.q_entity_per_row = int(np.ceil(self._num_item / self._bucket_size))
         self._sparse = sparse
-        if sparse:
-            raise NotImplementedError("RetrainCerpEmbedding(sparse=True): row-form grads of the two "
-                                      "bucket tables are not built; use the dense form")
 
     def load_mask(self, weight_path: str) -> List[nn.Parameter]:
         checkpoint = torch.load(weight_path, map_location="cpu")
@@ -203,10 +200,14 @@ class RetrainCerpEmbedding(IEmbedding):
         return self(all_idxes)
 
     def forward(self, x):
-        emb = _kernels.dual_gather(
-            x, self.p_weight, self.q_weight, mod1=self._bucket_size, div2=self.q_entity_per_row,
-            op="add", M1=self.p_mask, M2=self.q_mask,
-        )
+        if self._sparse:       # row-form gradients of the two bucket tables (torch.optim.SparseAdam's input)
+            emb = _kernels.dual_masked_gather_row_grad(x, self.p_weight, self.q_weight, self.p_mask, self.q_mask,
+                                                       self._bucket_size, self.q_entity_per_row)
+        else:
+            emb = _kernels.dual_gather(
+                x, self.p_weight, self.q_weight, mod1=self._bucket_size, div2=self.q_entity_per_row,
+                op="add", M1=self.p_mask, M2=self.q_mask,
+            )
         return _kernels.bag_reduce(emb, self._mode)
 
     def get_num_params(self):

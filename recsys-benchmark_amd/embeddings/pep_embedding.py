@@ -130,9 +130,6 @@ class RetrainPepEmbedding(IEmbedding):
         sparse=False,
     ):
         super().__init__()
-        if sparse:
-            raise NotImplementedError("RetrainPepEmbedding(sparse=True): row-form grads are not built for the "
-                                      "masked table; use the dense form")
         self._sparse, self._mode = sparse, mode
         self.emb = nn.Embedding(_num_rows(field_dims), hidden_size)
         if ori_weight_dir:                      # lottery-ticket style: restart from the saved initial table
@@ -145,7 +142,8 @@ class RetrainPepEmbedding(IEmbedding):
         self.sparsity = 1 - (self._nnz / torch.prod(torch.tensor(keep.size()))).item()
 
     def forward(self, x):
-        return _kernels.bag_reduce(_kernels.masked_gather(x, self.emb.weight, self.mask), self._mode)
+        gather = _kernels.masked_gather_row_grad if self._sparse else _kernels.masked_gather
+        return _kernels.bag_reduce(gather(x, self.emb.weight, self.mask), self._mode)
 
     def get_weight(self):
         ids = torch.arange(self.emb.num_embeddings, device=self.emb.weight.device)

@@ -151,6 +151,14 @@ def test_cerp_retrain_from_checkpoint_dir(tmp_path):
     assert_close(emb.p_weight.grad, pw.grad, 1e-5, 1e-6)
     assert_close(emb.q_weight.grad, qw.grad, 1e-5, 1e-6)
     assert emb.get_num_params() == int(emb.p_mask.sum() + emb.q_mask.sum())
+    # sparse=True (torch.optim.SparseAdam's input, src/models/embeddings/cerp_embedding.py:219,230): same values, row form
+    semb = RetrainCerpEmbedding(N, D, None, str(tmp_path), "deepfm", bucket_size=bucket, sparse=True).to(DEV)
+    sout = semb(idx.to(DEV))
+    assert_close(sout, ref, 0, 0, "forward (sparse=True)")
+    (sout * G.to(DEV)).sum().backward()
+    assert semb.p_weight.grad.is_sparse and semb.q_weight.grad.is_sparse
+    assert_close(semb.p_weight.grad, pw.grad, 1e-5, 1e-6, "p grad (row form, coalesced)")
+    assert_close(semb.q_weight.grad, qw.grad, 1e-5, 1e-6, "q grad (row form, coalesced)")
 
 
 # ------------------------------------------------------------------ CSR-pruned
@@ -354,6 +362,16 @@ def test_pep_retrain_matches_reference_golden(tmp_path):
     (out * g.t("G").to(DEV)).sum().backward()
     assert_close(emb.emb.weight.grad, g.t("grad/emb.weight"), 1e-5, 1e-6)
     assert_close(emb.get_weight(), g.t("weight"), 0, 0)
+    # sparse=True (src/models/embeddings/pep_embedding.py:215-221 with sparse=self._sparse): the same gradient in row form
+    semb = get_embedding({"name": "pep_retrain", "checkpoint_weight_dir": str(tmp_path), "sparsity": 0.5, "sparse": True},
+                         g["field_dims"].tolist(), int(g["hidden"]), field_name="deepfm")
+    semb.load_state_dict(g.group("param/"), strict=True)
+    semb.to(DEV)
+    sout = semb(g.t("x").to(DEV))
+    assert_close(sout, g.t("out"), 0, 0, "out (sparse=True)")
+    (sout * g.t("G").to(DEV)).sum().backward()
+    assert semb.emb.weight.grad.is_sparse
+    assert_close(semb.emb.weight.grad, g.t("grad/emb.weight"), 1e-5, 1e-6, "row-form grad, coalesced")
 
 
 @pytest.mark.parametrize("ttype", ["global", "dimension", "feature", "feature_dim"])
