@@ -129,17 +129,9 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   const LoadAct act = make_act(a.x);
   const LoadPlain xp{a.x.Z, a.x.ld};
   const LoadPlain wp{a.W, a.ldw};
-  auto fetchR = [&](int red0) {
-    if constexpr (ACT) return kc_fetch<64>(act, m0, rows_valid, red0, a.K);
-    else return kc_fetch<64>(xp, m0, rows_valid, red0, a.K);
-  };
-  auto fetchC = [&](int red0) { return kc_fetch<BNT>(wp, n0, cols_valid, red0, a.K); };
-  auto finishR = [&](float *T, const auto &st, int) {
-    if constexpr (ACT) kc_finish<64>(T, act, st, m0, rows_valid, a.K);
-    else kc_finish<64>(T, xp, st, m0, rows_valid, a.K);
-  };
-  auto finishC = [&](float *T, const auto &st, int) { kc_finish<BNT>(T, wp, st, n0, cols_valid, a.K); };
-  main_loop<true, true>(acc, lds, 0, a.K, fetchR, fetchC, finishR, finishC);
+  const KcOperand<BNT, LoadPlain> opC{wp, n0, cols_valid, a.K};
+  if constexpr (ACT) main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadAct>{act, m0, rows_valid, a.K}, opC);
+  else main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
   // ---- epilogue.  A lane holds z[m0 + 16 wave + r][n0 + 16 s + 4 g + v] (waves 0-3); the tile goes through LDS once so
   // that ALL 8 waves store whole 448-byte row segments and the column statistics are plain column walks.
@@ -441,17 +433,9 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   const LoadDz dzl = make_dz(a.dz);
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadPlain wp{a.W, a.ldw};     // [red = n][out = k]
-  auto fetchR = [&](int red0) {
-    if constexpr (DZ) return kc_fetch<64>(dzl, m0, rows_valid, red0, a.N);
-    else return kc_fetch<64>(dyp, m0, rows_valid, red0, a.N);
-  };
-  auto fetchC = [&](int red0) { return oc_fetch<BNT>(wp, k0, cols_valid, red0, a.N); };
-  auto finishR = [&](float *T, const auto &st, int) {
-    if constexpr (DZ) kc_finish<64>(T, dzl, st, m0, rows_valid, a.N);
-    else kc_finish<64>(T, dyp, st, m0, rows_valid, a.N);
-  };
-  auto finishC = [&](float *T, const auto &st, int red0) { oc_finish<BNT, SC_OC>(T, wp, st, k0, cols_valid, red0, a.N); };
-  main_loop<true, false>(acc, lds, 0, a.N, fetchR, fetchC, finishR, finishC);
+  const OcOperand<BNT, SC_OC, LoadPlain> opC{wp, k0, cols_valid, a.N};
+  if constexpr (DZ) main_loop<true, false>(acc, lds, 0, a.N, KcOperand<64, LoadDz>{dzl, m0, rows_valid, a.N}, opC);
+  else main_loop<true, false>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
 
   // ---- epilogue through LDS (see k_tail_fwd): all 8 waves, whole row segments
   float *T = lds;
@@ -553,23 +537,12 @@ __global__ __launch_bounds__(kThreads) void k_tail_wgrad(WgradArgs a) {
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadAct act = make_act(a.prev);
   const LoadPlain xp{a.prev.Z, a.prev.ld};
-  auto fetchR = [&](int red0) {
-    if constexpr (DZ) return oc_fetch<64>(dzl, n0, nrows_valid, red0, me);
-    else return oc_fetch<64>(dyp, n0, nrows_valid, red0, me);
+  auto run = [&](const auto &opR) {
+    if constexpr (ACT) main_loop<false, false>(acc, lds, mb, me, opR, OcOperand<BNT, SC_OC, LoadAct>{act, k0, cols_valid, me});
+    else main_loop<false, false>(acc, lds, mb, me, opR, OcOperand<BNT, SC_OC, LoadPlain>{xp, k0, cols_valid, me});
   };
-  auto fetchC = [&](int red0) {
-    if constexpr (ACT) return oc_fetch<BNT>(act, k0, cols_valid, red0, me);
-    else return oc_fetch<BNT>(xp, k0, cols_valid, red0, me);
-  };
-  auto finishR = [&](float *T, const auto &st, int red0) {
-    if constexpr (DZ) oc_finish<64, SR_OC>(T, dzl, st, n0, nrows_valid, red0, me);
-    else oc_finish<64, SR_OC>(T, dyp, st, n0, nrows_valid, red0, me);
-  };
-  auto finishC = [&](float *T, const auto &st, int red0) {
-    if constexpr (ACT) oc_finish<BNT, SC_OC>(T, act, st, k0, cols_valid, red0, me);
-    else oc_finish<BNT, SC_OC>(T, xp, st, k0, cols_valid, red0, me);
-  };
-  main_loop<false, false>(acc, lds, mb, me, fetchR, fetchC, finishR, finishC);
+  if constexpr (DZ) run(OcOperand<64, SR_OC, LoadDz>{dzl, n0, nrows_valid, me});
+  else run(OcOperand<64, SR_OC, LoadPlain>{dyp, n0, nrows_valid, me});
 
   const int r = lane & 15, g = lane >> 4;
   const int n = wave < 4 ? n0 + wave * 16 + r : a.N;      // waves 4-7 were the producers

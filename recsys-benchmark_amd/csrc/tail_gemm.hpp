@@ -181,57 +181,88 @@ __device__ __forceinline__ void kc_finish(float *T, const L &ld, const KcStage<R
   }
 }
 // OC tile: 32 x WIDTH (pitch S): chunk id q -> (reduction row q / (WIDTH/4), outputs (q % (WIDTH/4)) * 4 ..).  The
-// transformed matrices of an OC operand are indexed [red = m][out = feature]: constants per chunk.  Outputs beyond
+// transformed matrices of an OC operand are indexed [red = m][out = feature], so a thread's chunks keep their COLUMNS for
+// the whole kernel: the per-column constants and the chunk coordinates are prepared ONCE (OcMap) — re-loading 12-16
+// constant vectors per stage at the LDS write put their whole latency into every producer phase.  Outputs beyond
 // out_valid re-read the last valid group; reduction rows >= red_end are zeroed at the LDS write.
+template <int WIDTH, class L>
+struct OcMap {
+  static constexpr int NV = (WIDTH * 8 + kProd - 1) / kProd;
+  typename L::Consts k[NV];
+  int rrow[NV];     // reduction row of the chunk inside a slice
+  int col[NV];      // first output column (global), clamped to the valid range
+  int lofs[NV];     // LDS offset, or -1 for a chunk that does not exist
+};
 template <int WIDTH, class L>
 struct OcStage {
   static constexpr int NV = (WIDTH * 8 + kProd - 1) / kProd;
-  typename L::Raw raw[NV];     // the per-column constants are fetched at the LDS write (small L1/L2-resident vectors; the
-                               // producers have the slack, and 4 x 16 registers per stage in flight would spill)
+  typename L::Raw raw[NV];
 };
-template <int WIDTH, class L>
-__device__ __forceinline__ OcStage<WIDTH, L> oc_fetch(const L &ld, int out0, int out_valid, int red0, int red_end) {
+template <int WIDTH, int S, class L>
+__device__ __forceinline__ OcMap<WIDTH, L> oc_prepare(const L &ld, int out0, int out_valid) {
   constexpr int CPR = WIDTH / 4;
+  OcMap<WIDTH, L> m;
+#pragma unroll
+  for (int i = 0; i < OcMap<WIDTH, L>::NV; ++i) {
+    const int q = ptid() + i * kProd;
+    const int qc = q < WIDTH * 8 ? q : WIDTH * 8 - 1;
+    const int o = (qc % CPR) << 2;
+    m.rrow[i] = qc / CPR;
+    m.col[i] = out0 + (o < out_valid ? o : out_valid - 4);
+    m.lofs[i] = q < WIDTH * 8 ? (qc / CPR) * S + o : -1;
+    m.k[i] = ld.consts(m.col[i]);
+  }
+  return m;
+}
+template <int WIDTH, class L>
+__device__ __forceinline__ OcStage<WIDTH, L> oc_fetch(const L &ld, const OcMap<WIDTH, L> &m, int red0, int red_end) {
   OcStage<WIDTH, L> st;
 #pragma unroll
   for (int i = 0; i < OcStage<WIDTH, L>::NV; ++i) {
-    int q = ptid() + i * kProd;
-    q = q < WIDTH * 8 ? q : WIDTH * 8 - 1;
-    int red = red0 + q / CPR;
+    int red = red0 + m.rrow[i];
     red = red < red_end ? red : red_end - 1;
-    int o = (q % CPR) << 2;
-    o = o < out_valid ? o : out_valid - 4;
-    st.raw[i] = ld.fetch(red, out0 + o);
+    st.raw[i] = ld.fetch(red, m.col[i]);
   }
   return st;
 }
-template <int WIDTH, int S, class L>
-__device__ __forceinline__ void oc_finish(float *T, const L &ld, const OcStage<WIDTH, L> &st, int out0, int out_valid, int red0,
+template <int WIDTH, class L>
+__device__ __forceinline__ void oc_finish(float *T, const L &ld, const OcStage<WIDTH, L> &st, const OcMap<WIDTH, L> &m, int red0,
                                           int red_end) {
-  constexpr int CPR = WIDTH / 4, NV = OcStage<WIDTH, L>::NV;
-  typename L::Consts k[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int q = ptid() + i * kProd;
-    q = q < WIDTH * 8 ? q : WIDTH * 8 - 1;
-    int o = (q % CPR) << 2;
-    o = o < out_valid ? o : out_valid - 4;
-    k[i] = ld.consts(out0 + o);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int q = ptid() + i * kProd;
-    if (q < WIDTH * 8) {
-      const int red = red0 + q / CPR;
+  for (int i = 0; i < OcStage<WIDTH, L>::NV; ++i) {
+    if (m.lofs[i] >= 0) {
+      const int red = red0 + m.rrow[i];
       const bool live = red < red_end;
-      int o = (q % CPR) << 2;
-      const int oc = o < out_valid ? o : out_valid - 4;
-      float4 v = ld.finish(st.raw[i], k[i], live ? red : red_end - 1, out0 + oc);
+      float4 v = ld.finish(st.raw[i], m.k[i], live ? red : red_end - 1, m.col[i]);
       if (!live) v = zero4();
-      vst4(T + (q / CPR) * S + o, v);
+      vst4(T + m.lofs[i], v);
     }
   }
 }
+
+// Operand adaptors for the main loop: prep() once per producer thread, fetch(prep, red0) issues the loads of a slice,
+// finish(T, stage, prep, red0) transforms and writes it.
+struct NoPrep {};
+template <int ROWS, class L>
+struct KcOperand {
+  L ld;
+  int row0, rows_valid, red_end;
+  __device__ __forceinline__ NoPrep prep() const { return NoPrep{}; }
+  __device__ __forceinline__ KcStage<ROWS, L> fetch(const NoPrep &, int red0) const { return kc_fetch<ROWS>(ld, row0, rows_valid, red0, red_end); }
+  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L> &st, const NoPrep &, int) const {
+    kc_finish<ROWS>(T, ld, st, row0, rows_valid, red_end);
+  }
+};
+template <int WIDTH, int S, class L>
+struct OcOperand {
+  L ld;
+  int out0, out_valid, red_end;
+  __device__ __forceinline__ OcMap<WIDTH, L> prep() const { return oc_prepare<WIDTH, S>(ld, out0, out_valid); }
+  __device__ __forceinline__ OcStage<WIDTH, L> fetch(const OcMap<WIDTH, L> &m, int red0) const { return oc_fetch<WIDTH>(ld, m, red0, red_end); }
+  __device__ __forceinline__ void finish(float *T, const OcStage<WIDTH, L> &st, const OcMap<WIDTH, L> &m, int red0) const {
+    oc_finish<WIDTH>(T, ld, st, m, red0, red_end);
+  }
+};
 
 // fragments of step half h (16 reduction indices): 4 values per lane = k-steps j = 0..3
 __device__ __forceinline__ float4 kc_frag(const float *T, int row, int h, int g) { return vld4(T + kc_off(row, 4 * h + g)); }
@@ -294,9 +325,9 @@ __device__ __forceinline__ void consumer_barrier() { __builtin_amdgcn_s_barrier(
 // The element work of the operand loads (BatchNorm / ReLU / dropout bit) runs on the producers' VALU slots beside the
 // consumers' MFMAs (not for free: the f32 MFMA shares the vector issue, so it is kept to a few instructions per float4).  fetchR/fetchC(red0) issue the loads of one slice, finishR/finishC(T, stage, red0)
 // transform and write it.  Fetches past the last slice re-read the last slice (never written).
-template <bool R_KC, bool C_KC, class FR, class FC, class SR, class SC>
-__device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const FR &fetchR,
-                                          const FC &fetchC, const SR &finishR, const SC &finishC) {
+template <bool R_KC, bool C_KC, class OR, class OC>
+__device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const OR &opR,
+                                          const OC &opC) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int rOff = R_KC ? kROffKC : kROffOC, cOff = C_KC ? kCOffKC : kCOffOC;
   const int nst = (red_end - red_begin + BK - 1) / BK;
@@ -305,6 +336,12 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
   auto slot = [&](int i) { return lds + (i % kRing) * kStageFloats; };
   if (wave >= 4) {
     // ---------------------------------------------------------------------------------------------- producers
+    const auto pR = opR.prep();
+    const auto pC = opC.prep();
+    auto fetchR = [&](int red0) { return opR.fetch(pR, red0); };
+    auto fetchC = [&](int red0) { return opC.fetch(pC, red0); };
+    auto finishR = [&](float *T, const auto &st, int red0) { opR.finish(T, st, pR, red0); };
+    auto finishC = [&](float *T, const auto &st, int red0) { opC.finish(T, st, pC, red0); };
     // slices 0..2 straight into their slots, slices 3..5 left in flight in the three register stages
     auto r0 = fetchR(at(0));
     auto c0 = fetchC(at(0));
