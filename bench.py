@@ -773,7 +773,7 @@ def main():
                         "fwd_bwd_pair": {"us": round(pair_us, 3),
                                          "GBps": round((fb + bb) * B / (pair_us * 1e-6) / 1e9, 1),
                                          "frac": round((fb + bb) * B / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
-        if roofline is not None and "empty" in kernels:
+        if roofline is not None and "empty" in kernels and not sharded:
             # The per-dispatch clock (what rocprofv3 --kernel-trace reports too) reads ~4 us for a launch that does nothing,
             # whatever its grid: two EMPTY kernels already take ~8.2 of the 9.17 us the 50 % target allows the pair.
             fl = kernels["empty"]["avg_us"]
@@ -782,6 +782,7 @@ def main():
                                       "net_of_floor subtracts it from each kernel of the pair")
             net = max(pair_us - fl * len(cand), 1e-3)
             roofline["fwd_bwd_pair"]["net_of_floor"] = {
+                "note": "a diagnostic, not a roofline claim: the part of the pair's time the kernels themselves add to an empty launch",
                 "us": round(net, 3), "GBps": round((fb + bb) * B / (net * 1e-6) / 1e9, 1),
                 "frac": round((fb + bb) * B / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
             if pair_wall_us is not None:
