@@ -595,6 +595,20 @@ MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, cons
                               const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *slab,
                               float *dW, int32_t M, int32_t N, int32_t K, void *stream);
 
+/* ---- §8e: the sharded lookup's collectives on the CALLER's stream (recsys-benchmark_amd/csrc/comm.hip) ------------------
+ * No reference counterpart.  The library owns its own RCCL communicator (resolved with dlopen at first use: every entry
+ * point returns MI_ERR_UNSUPPORTED when no librccl can be loaded) so that the all-to-alls and the all-reduce are enqueued
+ * on the stream the kernels run on — torch.distributed's process-group stream costs two event hand-offs per collective.
+ * mi_comm_unique_id: HOST buffer of 128 bytes, filled on one rank and distributed by the caller.  mi_comm_init is
+ * collective (every rank calls it with the same id; the current HIP device is the rank's GPU).  mi_comm_all_to_all:
+ * recv[p*bytes .. ) <- rank p's send[me*bytes .. ) for every peer p (ncclGroupStart / Send / Recv / GroupEnd).
+ * mi_comm_all_reduce_sum_f32: in place. */
+MI_API int mi_comm_unique_id(char *id128);
+MI_API int mi_comm_init(const char *id128, int32_t world, int32_t rank, void **comm_out);
+MI_API int mi_comm_destroy(void *comm);
+MI_API int mi_comm_all_to_all(void *comm, const void *send, void *recv, int64_t bytes_per_peer, void *stream);
+MI_API int mi_comm_all_reduce_sum_f32(void *comm, float *buf, int64_t count, void *stream);
+
 /* ---- profiling ring (bench.py's per-kernel HIP-event timing) ---------------
  * When enabled every launcher brackets its kernel with a hipEvent pair on the
  * launch stream.  Not for use under graph capture.

@@ -61,6 +61,85 @@ def bucket_capacity(n: int, world: int, slack: float) -> int:
     return min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
 
 
+class DirectComm:
+    """The library's own RCCL communicator (csrc/comm.hip): all-to-all / all-reduce enqueued on the CURRENT stream, i.e.
+    the one the kernels run on — no process-group stream, no event hand-offs around the collectives (≈60 us of the
+    one-rank sharded step, DESIGN.md §6).  Built collectively over `group` (an NCCL/RCCL group with one rank per GPU);
+    `create` returns None — and the caller keeps torch.distributed's collectives — when the group is not on RCCL, the
+    switch MI_DIRECT_RCCL=0 is set, or the communicator cannot be made."""
+
+    def __init__(self, handle, world):
+        self.handle, self.world = handle, world
+
+    @staticmethod
+    def create(group, device):
+        import ctypes
+        import os
+        import warnings
+
+        from . import _lib
+
+        if os.environ.get("MI_DIRECT_RCCL", "1") == "0" or dist.get_backend(group) != "nccl" or device is None:
+            return None
+        if torch.device(device).type != "cuda":
+            return None
+        lib = _lib.load()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ctypes.create_string_buffer(128)
+        ok = 1
+        if rank == 0:
+            ok = int(lib.mi_comm_unique_id(buf) == 0)
+        box = [bytes(buf.raw) if ok else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+        if box[0] is None:
+            warnings.warn("mi355x_recsys: no RCCL for the direct communicator; using torch.distributed's collectives")
+            return None
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.mi_comm_init(box[0], world, rank, ctypes.byref(handle))
+        flag = torch.tensor([int(rc == 0)], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)          # all ranks or none
+        if int(flag.item()) == 0:
+            if rc == 0:
+                lib.mi_comm_destroy(handle)
+            warnings.warn("mi355x_recsys: the direct RCCL communicator could not be created on every rank; using torch.distributed")
+            return None
+        return DirectComm(handle, world)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        from . import _lib
+
+        assert out.is_contiguous() and inp.is_contiguous() and out.numel() == inp.numel() and out.dtype == inp.dtype
+        nbytes = inp.numel() * inp.element_size()
+        assert nbytes % self.world == 0
+        _lib.check(_lib.load().mi_comm_all_to_all(self.handle, inp.data_ptr(), out.data_ptr(), nbytes // self.world,
+                                                  _lib.stream_ptr(inp.device)), "mi_comm_all_to_all")
+
+    def all_reduce_sum(self, flat: torch.Tensor):
+        from . import _lib
+
+        assert flat.is_contiguous() and flat.dtype == torch.float32
+        _lib.check(_lib.load().mi_comm_all_reduce_sum_f32(self.handle, flat.data_ptr(), flat.numel(), _lib.stream_ptr(flat.device)),
+                   "mi_comm_all_reduce_sum_f32")
+
+    def close(self):
+        from . import _lib
+
+        if self.handle is not None:
+            _lib.load().mi_comm_destroy(self.handle)
+            self.handle = None
+
+
+def _all_to_all(model, out, inp):
+    """Equal-split all-to-all of the sharded lookup: on the compute stream through the library's communicator when there
+    is one, else torch.distributed's."""
+    comm = model.__dict__.get("_comm")
+    if comm is not None:
+        comm.all_to_all(out, inp)
+    else:
+        dist.all_to_all_single(out, inp, group=model.group)
+
+
 def expected_peak_load(field_dims: List[int], batch: int, world: int) -> float:
     """Largest expected number of lookups one owner receives from a batch of `batch` samples when the ids of every field
     are uniform over that field: owner = (offset_f + id) % world, so a field with fewer values than ranks sends ALL its
@@ -105,14 +184,15 @@ class _Exchange(torch.autograd.Function):
         send_rows, slot = ops.route_buckets(x, model.offsets, world, model.num_rows, cap, model.bucket_overflow,
                                             slot_out=static[1] if use_static else None)
         local_rows = torch.empty_like(send_rows)
-        dist.all_to_all_single(local_rows, send_rows, group=group)
+        _all_to_all(model, local_rows, send_rows)
         packed = ops.gather_pack_rows(local_rows, W_local, w1_local)              # [S, D+4]
         if use_static:
             recv = static[0].detach()        # same storage (no copy into the graph), fresh autograd identity
         else:
             recv = packed.new_empty((S + 1, D + 4))
             recv[S].zero_()                  # the dump slot reads as a zero row
-        dist.all_to_all_single(recv[:S], packed, group=group)
+        _all_to_all(model, recv[:S], packed)
+        ctx.model = model
         ctx.local_rows, ctx.meta = local_rows, (S, D, world, group, tuple(W_local.shape), tuple(w1_local.shape))
         ctx.mark_non_differentiable(slot)
         return recv, slot
@@ -121,7 +201,7 @@ class _Exchange(torch.autograd.Function):
     def backward(ctx, g_recv, _g_slot):
         S, D, world, group, Wshape, w1shape = ctx.meta
         g_owner = g_recv.new_empty((S, D + 4))
-        dist.all_to_all_single(g_owner, g_recv[:S].contiguous(), group=group)
+        _all_to_all(ctx.model, g_owner, g_recv[:S].contiguous())
         inv = 1.0 / world
         idx = ctx.local_rows.view(1, -1)
         gW = gw1 = None
@@ -188,6 +268,8 @@ class ShardedDeepFM(nn.Module):
         self.register_buffer("offsets", torch.cumsum(fd[:-1], 0).unsqueeze(0).to(device))
         self.register_buffer("bucket_overflow", torch.zeros(1, dtype=torch.int32, device=device), persistent=False)
         self.sync_dense_parameters()
+        # the library's own communicator (collectives on the compute stream) when the group runs on RCCL
+        self.__dict__["_comm"] = DirectComm.create(process_group, device) if ops is None else None
 
     # ---- parameter plumbing ------------------------------------------------------------
     def dense_parameters(self):
@@ -204,7 +286,10 @@ class ShardedDeepFM(nn.Module):
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        if dist.get_backend(self.group) == "nccl":
+        if self.__dict__.get("_comm") is not None:
+            self._comm.all_reduce_sum(flat)
+            flat /= self.world
+        elif dist.get_backend(self.group) == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
             dist.all_reduce(flat, group=self.group)
@@ -350,13 +435,13 @@ class ShardedDeepFM(nn.Module):
             send_rows, _ = self.ops.route_buckets(x, self.offsets, world, self.num_rows, cap, self.bucket_overflow,
                                                   slot_out=slot)
             local_rows = torch.empty_like(send_rows)
-            dist.all_to_all_single(local_rows, send_rows, group=group)
+            _all_to_all(self, local_rows, send_rows)
             packed = self.ops.gather_pack_rows(local_rows, self.embedding_shard, self.fc_shard)
             with torch.no_grad():
-                dist.all_to_all_single(recv[:S], packed, group=group)
+                _all_to_all(self, recv[:S], packed)
                 graph.replay()
                 g_owner = torch.empty_like(packed)
-                dist.all_to_all_single(g_owner, g_recv[:S], group=group)
+                _all_to_all(self, g_owner, g_recv[:S])
                 idx = local_rows.view(1, -1)
                 # the received rows are already scaled by 1/world; COO values must be contiguous (torch's sparse
                 # kernels read strided values wrongly), so the two column blocks are copied out
@@ -364,7 +449,10 @@ class ShardedDeepFM(nn.Module):
                                                                     check_invariants=False)
                 self.fc_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, D:D + 1].contiguous(), w1shape,
                                                              check_invariants=False)
-                dist.all_reduce(flat, group=group)
+                if self.__dict__.get("_comm") is not None:
+                    self._comm.all_reduce_sum(flat)
+                else:
+                    dist.all_reduce(flat, group=group)
             for p, v in zip(dense, views):
                 p.grad = v
             return loss

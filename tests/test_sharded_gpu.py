@@ -102,6 +102,42 @@ def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphe
     pkg.check_index_errors()
 
 
+def test_direct_communicator_equals_the_process_group_collectives(one_rank_group, monkeypatch):
+    """The library's own RCCL communicator (collectives on the compute stream, csrc/comm.hip) against torch.distributed's:
+    byte-identical all-to-all and all-reduce results, and the sharded model uses it by default on an RCCL group."""
+    from recsys_benchmark_amd.sharded import DirectComm
+
+    dev = torch.device("cuda", 0)
+    comm = DirectComm.create(None, dev)
+    assert comm is not None, "an RCCL group must get the direct communicator"
+    src = torch.randn(1000, 20, device=dev)
+    out, ref = torch.empty_like(src), torch.empty_like(src)
+    comm.all_to_all(out, src)
+    dist.all_to_all_single(ref, src)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    ids = torch.randint(0, 1 << 40, (4096,), device=dev)
+    oi, ri = torch.empty_like(ids), torch.empty_like(ids)
+    comm.all_to_all(oi, ids)
+    dist.all_to_all_single(ri, ids)
+    assert torch.equal(oi, ri)                                   # int64 ids travel as bytes
+    a = torch.randn(12345, device=dev)
+    b = a.clone()
+    comm.all_reduce_sum(a)
+    dist.all_reduce(b)
+    assert torch.equal(a, b)
+    comm.close()
+    dims = [50, 7, 1000, 3]
+    sh = ShardedDeepFM(dims, 16, [32, 16], p_dropout=0.0, use_batchnorm=True, device=dev)
+    assert sh._comm is not None
+    monkeypatch.setenv("MI_DIRECT_RCCL", "0")
+    sh2 = ShardedDeepFM(dims, 16, [32, 16], p_dropout=0.0, use_batchnorm=True, device=dev)
+    assert sh2._comm is None                                     # the switch keeps torch.distributed's collectives
+    sh2.load_state_dict(sh.state_dict())
+    x = torch.stack([torch.randint(0, d, (64,)) for d in dims], 1).to(dev)
+    assert torch.equal(sh(x), sh2(x))
+
+
 def test_graphed_local_compute_matches_eager():
     """Isolated child process (see tests/_graphed_sharded_check.py for why)."""
     import subprocess
