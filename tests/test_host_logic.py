@@ -270,3 +270,38 @@ def test_bucket_capacity_accounts_for_fields_with_fewer_values_than_ranks():
     assert rows_per_owner > bucket_capacity(B * len(tiny), world, 1.25)
     assert field_bucket_capacity(tiny, B, world, 1.25) >= rows_per_owner
     assert field_bucket_capacity(tiny, B, 1, 1.25) == B * len(tiny)
+
+
+def test_dropout_bit_generator_restatement_rate_and_layout():
+    """tests/tail_helpers.py restates the fused tail's keep-bit generator (csrc/tail.hip k_tail_dropmask): deterministic in
+    (seed, salt), the right keep rate, one decision per element, salt and seed both matter."""
+    from tail_helpers import tail_keep_scale
+
+    a = tail_keep_scale(123, 7919, 512, 400, 0.5)
+    assert a.shape == (512, 400) and torch.equal(a, tail_keep_scale(123, 7919, 512, 400, 0.5))
+    assert set(a.unique().tolist()) == {0.0, 2.0}
+    assert abs(float((a > 0).float().mean()) - 0.5) < 0.01
+    assert not torch.equal(a, tail_keep_scale(124, 7919, 512, 400, 0.5))
+    assert not torch.equal(a, tail_keep_scale(123, 2 * 7919, 512, 400, 0.5))
+    b = tail_keep_scale(5, 1, 256, 64, 0.1)
+    assert abs(float((b > 0).float().mean()) - 0.9) < 0.01 and abs(float(b.max()) - 1.0 / 0.9) < 1e-6
+    assert torch.equal(tail_keep_scale(5, 1, 256, 64, 0.0), torch.ones(256, 64))
+
+
+def test_bench_cpu_baseline_protocol_on_a_small_shape():
+    """bench.py's CPU legs: 3 warm-up + up to 10 timed iterations inside a time budget, physical-core thread count, the
+    like-for-like line first and the reference-default lines after it."""
+    import bench
+
+    phys, logical = bench.physical_cores()
+    assert 1 <= phys <= logical
+    old = torch.get_num_threads()
+    try:
+        r = bench.cpu_baseline([50, 30, 2000, 10000], 16, [32, 32], 256, 0.5, budget_s=4.0)
+    finally:
+        torch.set_num_threads(old)
+    assert r["kind"] == "port" and r["cores"] == phys and r["unit"] == "samples/s" and r["value"] > 0
+    assert len(r["lines"]) == 4 and "row-form" in r["lines"][0]["what"] and "Adam" in r["lines"][2]["what"]
+    assert all(2 <= ln["timed_iters"] <= 10 for ln in r["lines"])
+    med, n = bench.timed_cpu(lambda: None, warm=1, timed=5, budget_s=1.0)
+    assert n == 5 and med >= 0
