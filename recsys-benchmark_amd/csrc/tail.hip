@@ -433,9 +433,9 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   const LoadDz dzl = make_dz(a.dz);
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadPlain wp{a.W, a.ldw};     // [red = n][out = k]
-  const OcOperand<BNT, SC_OC, LoadPlain> opC{wp, k0, cols_valid, a.N};
-  if constexpr (DZ) main_loop<true, false>(acc, lds, 0, a.N, KcOperand<64, LoadDz>{dzl, m0, rows_valid, a.N}, opC);
-  else main_loop<true, false>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
+  const OtOperand<BNT, LoadPlain> opC{wp, k0, cols_valid, a.N};     // transposed into a KC tile on the way in
+  if constexpr (DZ) main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadDz>{dzl, m0, rows_valid, a.N}, opC);
+  else main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
 
   // ---- epilogue through LDS (see k_tail_fwd): all 8 waves, whole row segments
   float *T = lds;
@@ -537,12 +537,12 @@ __global__ __launch_bounds__(kThreads) void k_tail_wgrad(WgradArgs a) {
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadAct act = make_act(a.prev);
   const LoadPlain xp{a.prev.Z, a.prev.ld};
-  auto run = [&](const auto &opR) {
-    if constexpr (ACT) main_loop<false, false>(acc, lds, mb, me, opR, OcOperand<BNT, SC_OC, LoadAct>{act, k0, cols_valid, me});
-    else main_loop<false, false>(acc, lds, mb, me, opR, OcOperand<BNT, SC_OC, LoadPlain>{xp, k0, cols_valid, me});
+  auto run = [&](const auto &opR) {       // both operands have the batch as the slow index: transposed into KC tiles
+    if constexpr (ACT) main_loop<true, true>(acc, lds, mb, me, opR, OtOperand<BNT, LoadAct>{act, k0, cols_valid, me});
+    else main_loop<true, true>(acc, lds, mb, me, opR, OtOperand<BNT, LoadPlain>{xp, k0, cols_valid, me});
   };
-  if constexpr (DZ) run(OcOperand<64, SR_OC, LoadDz>{dzl, n0, nrows_valid, me});
-  else run(OcOperand<64, SR_OC, LoadPlain>{dyp, n0, nrows_valid, me});
+  if constexpr (DZ) run(OtOperand<64, LoadDz>{dzl, n0, nrows_valid, me});
+  else run(OtOperand<64, LoadPlain>{dyp, n0, nrows_valid, me});
 
   const int r = lane & 15, g = lane >> 4;
   const int n = wave < 4 ? n0 + wave * 16 + r : a.N;      // waves 4-7 were the producers

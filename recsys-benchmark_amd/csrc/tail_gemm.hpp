@@ -240,6 +240,68 @@ __device__ __forceinline__ void oc_finish(float *T, const L &ld, const OcStage<W
   }
 }
 
+// OC source, KC tile ("transpose on the way in"): a thread owns a 4 (reduction) x 4 (output) block — four float4 loads along
+// the outputs, one per reduction row — and, after the element transform, writes it as four float4 along the REDUCTION
+// index into the KC tile (row = output, chunk = reduction / 4).  The transposition is pure register naming, the LDS gets
+// the same number of b128 writes as an OC tile would, and the consumers read conflict-free b128 fragments instead of
+// four b32 per operand and step (measured: no change in time for the weight-gradient and input-gradient products — the
+// consumers were not their limit — so this form is kept for having ONE fragment path).  Block id b = thread: output block b % (ROWS/4), reduction block b / (ROWS/4): threads
+// run along the outputs, so a wave-load covers whole 256-B / 448-B row segments.
+template <int ROWS, class L>
+struct OtMap {
+  typename L::Consts k;
+  int col;          // first output column (global), clamped
+  int ob, rb;       // output block, reduction block; ob < 0: this thread has no block
+};
+template <int ROWS, class L>
+struct OtStage {
+  typename L::Raw raw[4];
+};
+template <int ROWS, class L>
+struct OtOperand {
+  L ld;
+  int out0, out_valid, red_end;
+  __device__ __forceinline__ OtMap<ROWS, L> prep() const {
+    constexpr int OB = ROWS / 4;
+    OtMap<ROWS, L> m;
+    const int b = ptid();
+    const bool has = b < OB * 8;
+    const int bc = has ? b : OB * 8 - 1;
+    m.ob = has ? bc % OB : -1;
+    m.rb = bc / OB;
+    const int o = (bc % OB) << 2;
+    m.col = out0 + (o < out_valid ? o : out_valid - 4);
+    m.k = ld.consts(m.col);
+    return m;
+  }
+  __device__ __forceinline__ OtStage<ROWS, L> fetch(const OtMap<ROWS, L> &m, int red0) const {
+    OtStage<ROWS, L> st;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int red = red0 + 4 * m.rb + j;
+      red = red < red_end ? red : red_end - 1;
+      st.raw[j] = ld.fetch(red, m.col);
+    }
+    return st;
+  }
+  __device__ __forceinline__ void finish(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const {
+    if (m.ob < 0) return;
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int red = red0 + 4 * m.rb + j;
+      const bool live = red < red_end;
+      v[j] = ld.finish(st.raw[j], m.k, live ? red : red_end - 1, m.col);
+      if (!live) v[j] = zero4();
+    }
+    const int row = 4 * m.ob;
+    vst4(T + kc_off(row + 0, m.rb), make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    vst4(T + kc_off(row + 1, m.rb), make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+    vst4(T + kc_off(row + 2, m.rb), make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+    vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+  }
+};
+
 // Operand adaptors for the main loop: prep() once per producer thread, fetch(prep, red0) issues the loads of a slice,
 // finish(T, stage, prep, red0) transforms and writes it.
 struct NoPrep {};
