@@ -602,10 +602,12 @@ MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, cons
  * mi_comm_unique_id: HOST buffer of 128 bytes, filled on one rank and distributed by the caller.  mi_comm_init is
  * collective (every rank calls it with the same id; the current HIP device is the rank's GPU).  mi_comm_all_to_all:
  * recv[p*bytes .. ) <- rank p's send[me*bytes .. ) for every peer p (ncclGroupStart / Send / Recv / GroupEnd).
- * mi_comm_all_reduce_sum_f32: in place. */
+ * mi_comm_all_reduce_sum_f32: in place.  mi_comm_abort: for a communicator whose enqueued work does not complete
+ * (ncclCommAbort: stops its kernels, frees it without waiting); mi_comm_destroy is the orderly end. */
 MI_API int mi_comm_unique_id(char *id128);
 MI_API int mi_comm_init(const char *id128, int32_t world, int32_t rank, void **comm_out);
 MI_API int mi_comm_destroy(void *comm);
+MI_API int mi_comm_abort(void *comm);
 MI_API int mi_comm_all_to_all(void *comm, const void *send, void *recv, int64_t bytes_per_peer, void *stream);
 MI_API int mi_comm_all_reduce_sum_f32(void *comm, float *buf, int64_t count, void *stream);
 

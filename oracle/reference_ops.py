@@ -146,6 +146,23 @@ def dhe_hash(ids: torch.Tensor, slopes, bias, primes, prefix: int, m: int = 1000
     return result * 2 - 1
 
 
+def dhe_item_hash(items, primes: torch.Tensor, k: int, prefix: int, m: int = 1000000) -> torch.Tensor:
+    """_get_hash with use_universal_hash=False — src/models/embeddings/dh_embedding.py:155-196: per item the GLOBAL torch
+    generator is re-seeded with item + prefix, then k slopes, k offsets (zeros re-drawn) and k prime picks are drawn.
+    Returns [len(items), k] fp32; leaves the global generator where the last item's draws end."""
+    lo, hi = -int(1e9), int(1e9)
+    rows = []
+    for item in items:
+        torch.manual_seed(int(item) + prefix)
+        a = torch.randint(lo, hi, (k,))
+        b = torch.randint(lo, hi, (k,))
+        while int((b == 0).sum()) > 0:
+            b[b == 0] = torch.randint(lo, hi, (int((b == 0).sum()),))
+        pick = primes[torch.randint(0, len(primes), (k,))]
+        rows.append(((a * (int(item) + 1) + b) % pick % m) / (m - 1) * 2 - 1)
+    return torch.stack(rows)
+
+
 def dhe_mlp(x: torch.Tensor, p: Params, n_layers: int, use_bn: int, training: bool, prefix: str = "_seq"):
     """The Linear / BatchNorm1d / Mish stack of DHEmbedding (dh_embedding.py:99-117)."""
     i = 0

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mi_comm_unique_id": [ctypes.c_char_p],
     "mi_comm_init": [ctypes.c_char_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "mi_comm_destroy": [_p],
+    "mi_comm_abort": [_p],
     "mi_comm_all_to_all": [_p, _p, _p, _i64, _p],
     "mi_comm_all_reduce_sum_f32": [_p, _p, _i64, _p],
     "mi_prof_count": [],

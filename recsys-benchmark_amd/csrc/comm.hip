@@ -24,6 +24,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -45,13 +46,14 @@ void load_rccl() {
   SYM(GetUniqueId, ncclGetUniqueId);
   SYM(CommInitRank, ncclCommInitRank);
   SYM(CommDestroy, ncclCommDestroy);
+  SYM(CommAbort, ncclCommAbort);
   SYM(GroupStart, ncclGroupStart);
   SYM(GroupEnd, ncclGroupEnd);
   SYM(Send, ncclSend);
   SYM(Recv, ncclRecv);
   SYM(AllReduce, ncclAllReduce);
 #undef SYM
-  g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GroupStart && g_rccl.GroupEnd &&
+  g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.CommAbort && g_rccl.GroupStart && g_rccl.GroupEnd &&
               g_rccl.Send && g_rccl.Recv && g_rccl.AllReduce;
 }
 const Rccl *rccl() {
@@ -99,6 +101,18 @@ int mi_comm_destroy(void *comm) {
   if (!comm) return MI_OK;
   Comm *c = static_cast<Comm *>(comm);
   const bool ok = r->CommDestroy(c->c) == ncclSuccess;
+  delete c;
+  return ok ? MI_OK : MI_ERR_LAUNCH;
+}
+
+// gives up a communicator whose enqueued work never completes (a peer died, a link is down): RCCL stops its kernels and
+// frees it without waiting for them.  The caller's stream becomes usable again; `comm` is invalid afterwards.
+int mi_comm_abort(void *comm) {
+  const Rccl *r = rccl();
+  if (!r) return MI_ERR_UNSUPPORTED;
+  if (!comm) return MI_OK;
+  Comm *c = static_cast<Comm *>(comm);
+  const bool ok = r->CommAbort(c->c) == ncclSuccess;
   delete c;
   return ok ? MI_OK : MI_ERR_LAUNCH;
 }

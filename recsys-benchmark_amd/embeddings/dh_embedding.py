@@ -8,6 +8,11 @@ reference.  The MLP is a dense GEMM chain and stays on rocBLAS through PyTorch (
 The slopes / biases / primes are drawn exactly as the reference draws them
 (torch.Generator().manual_seed(0)); its prime asset (all 74,518 primes in (1e6, 2,059,181]) is
 regenerated here with a sieve.
+
+use_universal_hash=False (dh_embedding.py:155-196): every item gets its OWN k hash functions, drawn from torch's global
+CPU generator re-seeded with item + prefix.  That stream only exists on the host, so — exactly like the reference —
+the [N, k] feature table is built once on the host at construction (cached=True) or per unique id (cached=False, eval),
+moved to the MLP's device, and the hot path is the HIP row gather from it followed by the MLP.
 """
 from typing import Final, List, Optional, Union
 
@@ -58,10 +63,6 @@ class DHEmbedding(IEmbedding):
         use_universal_hash=True,
     ):
         super().__init__()
-        if not use_universal_hash:
-            raise NotImplementedError(
-                "use_universal_hash=False seeds torch's CPU generator per item "
-                "(dh_embedding.py:161-196); that stream cannot be reproduced on the GPU")
         if isinstance(field_dims, int):
             field_dims = [field_dims]
         if isinstance(use_bn, bool):
@@ -82,14 +83,15 @@ class DHEmbedding(IEmbedding):
         self._primes = primes
         self._inp_size = inp_size
         self._num_item = num_item
-        self._use_universal_hash = True
+        self._use_universal_hash = bool(use_universal_hash)
 
-        rng = torch.Generator()
-        rng.manual_seed(0)
-        self.register_buffer("_slopes", self._random_nonzero_int(inp_size, rng))
-        self.register_buffer("_bias", self._random_nonzero_int(inp_size, rng))
-        p_idx = torch.randint(0, len(primes), (inp_size,), generator=rng)
-        self.register_buffer("_primes_choices", self._primes[p_idx])
+        if self._use_universal_hash:     # (the per-item form registers no buffers: same state_dict keys as the reference)
+            rng = torch.Generator()
+            rng.manual_seed(0)
+            self.register_buffer("_slopes", self._random_nonzero_int(inp_size, rng))
+            self.register_buffer("_bias", self._random_nonzero_int(inp_size, rng))
+            p_idx = torch.randint(0, len(primes), (inp_size,), generator=rng)
+            self.register_buffer("_primes_choices", self._primes[p_idx])
 
         layers: List[nn.Module] = []
         if hidden_sizes is None:
@@ -114,6 +116,42 @@ class DHEmbedding(IEmbedding):
         self.compute_v2 = compute_v2
         self._mode = mode
         self._emb = None
+        # per-item hashes: the [N, k] feature table, host-built (one reseed of the global generator per item)
+        self._cache: Optional[torch.Tensor] = None
+        if not self._use_universal_hash and cached:
+            if cache_path:
+                import os
+
+                if os.path.exists(cache_path):
+                    self._cache = torch.load(cache_path)
+            if self._cache is None:
+                self._cache = self._seeded_hash_rows(range(self._num_item))
+                if cache_path:
+                    torch.save(self._cache, cache_path)
+
+    def _seeded_hash_rows(self, items) -> torch.Tensor:
+        """[len(items), k] features of the per-item hash family (dh_embedding.py:155-196).  Per item: reseed the GLOBAL
+        torch generator with item + prefix (as the reference does — the global stream is left where it leaves it), draw k
+        slopes, k non-zero offsets, k prime picks; feature = ((a*(item+1)+b) mod p mod m) / (m-1) * 2 - 1 with torch's
+        floor-mod on int64 and float32 arithmetic."""
+        k, m, primes = self._inp_size, self.m, self._primes
+        rows = []
+        for item in items:
+            item = int(item)
+            torch.manual_seed(item + self._prefix)
+            a = torch.randint(NEGATIVE_LARGE_INT, LARGE_INT, (k,))
+            b = self._random_nonzero_int(k)
+            p = primes[torch.randint(0, len(primes), (k,))]
+            h = (a * (item + 1) + b) % p % m
+            rows.append((h / (m - 1)) * 2 - 1)
+        if not rows:
+            return torch.empty((0, k), dtype=torch.float32)
+        return torch.stack(rows)
+
+    def _cache_on(self, device) -> torch.Tensor:
+        if self._cache.device != device:
+            self._cache = self._cache.to(device)       # moved once, kept (the reference re-copies every forward)
+        return self._cache
 
     def _random_nonzero_int(self, num_element, rng=None):
         b = torch.randint(NEGATIVE_LARGE_INT, LARGE_INT, (num_element,), generator=rng)
@@ -136,6 +174,21 @@ class DHEmbedding(IEmbedding):
         mode = self._mode
         if not self.training and self._emb is not None:
             return _kernels.gather_rows(inp, self._emb)
+
+        if not self._use_universal_hash:
+            device = self._seq[0].weight.device
+            if self._use_cache:
+                cache = self._cache_on(device)
+                if self.compute_v2:
+                    uniques, inverse_idx = inp.unique(return_inverse=True)
+                    x = self._forward_mlp(_kernels.gather_rows(uniques, cache))
+                    return _kernels.gather_rows(inverse_idx, x)
+                return self._forward_mlp(_kernels.bag_reduce(_kernels.gather_rows(inp, cache), mode))
+            if self.training:
+                raise NotImplementedError()  # as the reference (dh_embedding.py:325-326)
+            uniques, inverse_idx = inp.unique(return_inverse=True)
+            feats = self._seeded_hash_rows(uniques.tolist()).to(device)
+            return _kernels.gather_rows(inverse_idx, self._seq(feats))
 
         if (self.compute_v2 and self._use_cache) or not self._use_cache:
             if not self._use_cache and self.training:

@@ -67,9 +67,10 @@ def get_num_params(tt_p_shapes, tt_q_shapes, tt_ranks) -> int:
     return sum(tt_p_shapes[i] * tt_q_shapes[i] * tt_ranks[i] * tt_ranks[i + 1] for i in range(len(tt_p_shapes)))
 
 
-def _init_cores(num_embeddings, embedding_dim, tt_ranks, weight_dist, tt_cores, tt_ndim):
-    """Initialisers of the reference (tt_embedding_ops.py:818-859,989-1036); 'approx-uniform' (a
-    3-core-only sawtooth construction) is not reproduced."""
+def _init_cores(num_embeddings, embedding_dim, tt_ranks, weight_dist, tt_cores, tt_ndim, tt_p_shapes=None, tt_q_shapes=None):
+    """Initialisers of the reference (tt_embedding_ops.py:818-986,989-1036).  They draw from numpy's global generator
+    (and, for 'approx-uniform', Python's `random`) in the reference's order, so a seeded construction gives the same
+    cores."""
     assert weight_dist in ["uniform", "naive-uniform", "normal", "approx-uniform", "approx-normal"]
     if weight_dist == "uniform":
         stddev = np.sqrt(2.0 / (num_embeddings + embedding_dim))
@@ -98,7 +99,66 @@ def _init_cores(num_embeddings, embedding_dim, tt_ranks, weight_dist, tt_cores, 
                 redo = again
             c.data = torch.tensor(W.reshape(tuple(c.shape)) * scale, dtype=torch.float32, device=c.data.device)
     else:
-        raise NotImplementedError("weight_dist='approx-uniform' is not built")
+        _init_approx_uniform(num_embeddings, tt_ranks, tt_cores, tt_ndim, tt_p_shapes, tt_q_shapes)
+
+
+def _comb(count: int, teeth: int = 15, width: float = 0.7 / 30.0) -> np.ndarray:
+    """`count` draws of the reference's "flat saw tooth" density: a tooth centre j/teeth, j uniform on -(teeth-1)..teeth-1,
+    plus uniform(-width/2, width/2) (tt_embedding_ops.py:863-879; one randint call, then one rand call)."""
+    centre = np.random.randint(-(teeth - 1), teeth, count)
+    return centre * (1.0 / teeth) + (-width / 2.0 + width * np.random.rand(count))
+
+
+def _init_approx_uniform(num_embeddings, tt_ranks, tt_cores, tt_ndim, tt_p_shapes, tt_q_shapes, sigma: float = 0.01):
+    """3-core construction whose product is approximately uniform (tt_embedding_ops.py:861-986): core 0 ~ N(1/sqrt(r1),
+    sigma) ; core 1 ~ N(1/sqrt(r1), sigma) except that for every (row, column) pair one EVEN outgoing-rank slice is
+    N(0, sigma^2 sqrt(r1)) with a single saw-tooth entry (pre-divided by 1/sqrt(r1)); core 2 ~ N(0, sigma) with one
+    saw-tooth entry on an ODD incoming rank per (row, column).  All three scaled by N^(-1/6) and stored [1, p_i, r_i q_i r_i+1]
+    (rank-major slices transposed to row-major).  Draw order: numpy block, numpy comb, then per pair a Python-`random`
+    slice pick, (core 1) r1 numpy normals, a Python-`random` entry pick — the normals are one [pairs, r1] call, which is the
+    same stream."""
+    import random
+
+    if tt_ndim != 3:
+        raise AssertionError("weight_dist='approx-uniform' needs exactly 3 cores (tt_embedding_ops.py:961)")
+    amp = 1.0 / (np.sqrt(num_embeddings) ** (1.0 / 3.0))
+    dims = [(tt_ranks[i], tt_p_shapes[i], tt_q_shapes[i], tt_ranks[i + 1]) for i in range(3)]
+
+    def stored(block, i):
+        block = (block * amp).astype(np.float32)
+        return block.transpose(1, 0, 2, 3).reshape(1, tt_p_shapes[i], -1)
+
+    # core 0: around 1/sqrt(r1) so that head x mid sums to ~1
+    r0, p0, q0, r1 = dims[0]
+    head = (1.0 / np.sqrt(r1) + np.random.randn(r0 * p0 * q0 * r1) * sigma).reshape(dims[0])
+
+    # core 1
+    r1_, p1, q1, r2 = dims[1]
+    level = 1.0 / np.sqrt(r1_)
+    pairs = p1 * q1
+    mid = (level + np.random.randn(r1_ * pairs * r2) * sigma).reshape(r1_, pairs, r2)
+    teeth = _comb(pairs) / level
+    slices, entries = np.empty(pairs, dtype=np.int64), np.empty(pairs, dtype=np.int64)
+    for e in range(pairs):              # Python's generator: slice pick, entry pick, per pair, in this order
+        slices[e] = random.randrange(0, r2, 2)
+        entries[e] = random.randrange(r1_)
+    noise = np.random.randn(pairs, r1_) * (sigma * sigma / level)
+    for e in range(pairs):
+        mid[:, e, slices[e]] = noise[e]
+        mid[entries[e], e, slices[e]] = teeth[e]
+    mid = mid.reshape(dims[1])
+
+    # core 2
+    r2_, p2, q2, r3 = dims[2]
+    tail = (np.random.randn(r2_ * p2 * q2 * r3) * sigma).reshape(r2_, -1)
+    cols = tail.shape[1]
+    teeth = _comb(cols)
+    for e in range(cols):
+        tail[random.randrange(1, r2_, 2), e] = teeth[e]
+    tail = tail.reshape(dims[2])
+
+    for i, block in enumerate((head, mid, tail)):
+        tt_cores[i].data = torch.tensor(stored(block, i), dtype=torch.float32, device=tt_cores[i].data.device)
 
 
 class TTRecTorch(IEmbedding):
@@ -134,7 +194,8 @@ class TTRecTorch(IEmbedding):
             self.tt_cores.append(nn.Parameter(torch.empty(
                 [self.num_tables, self.tt_p_shapes[i],
                  self.tt_ranks[i] * self.tt_q_shapes[i] * self.tt_ranks[i + 1]], dtype=torch.float32)))
-        _init_cores(self.num_embeddings, self.embedding_dim, self.tt_ranks, weight_dist, self.tt_cores, self.tt_ndim)
+        _init_cores(self.num_embeddings, self.embedding_dim, self.tt_ranks, weight_dist, self.tt_cores, self.tt_ndim,
+                    self.tt_p_shapes, self.tt_q_shapes)
 
     def get_num_params(self):
         return get_num_params(self.tt_p_shapes, self.tt_q_shapes, self.tt_ranks)

@@ -97,14 +97,51 @@ class DirectComm:
         handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             rc = lib.mi_comm_init(box[0], world, rank, ctypes.byref(handle))
-        flag = torch.tensor([int(rc == 0)], device=device)
+        comm = DirectComm(handle, world) if rc == 0 else None
+        ok = comm is not None and comm._self_test(rank, device)
+        flag = torch.tensor([int(ok)], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)          # all ranks or none
         if int(flag.item()) == 0:
-            if rc == 0:
-                lib.mi_comm_destroy(handle)
-            warnings.warn("mi355x_recsys: the direct RCCL communicator could not be created on every rank; using torch.distributed")
+            if comm is not None and comm.handle is not None:
+                comm.close()
+            warnings.warn("mi355x_recsys: the direct RCCL communicator did not come up on every rank; using torch.distributed")
             return None
-        return DirectComm(handle, world)
+        return comm
+
+    def _self_test(self, rank: int, device, deadline_s: float = 60.0) -> bool:
+        """One all-to-all and one all-reduce with known answers on a side stream, waited for with a deadline: a
+        communicator whose first collectives do not finish (or deliver the wrong peer's bytes) is aborted here, at
+        start-up, rather than hanging the first training step."""
+        import time
+
+        from . import _lib
+
+        w = self.world
+        side = torch.cuda.Stream(device=device)
+        done = torch.cuda.Event()
+        with torch.cuda.device(device), torch.cuda.stream(side):
+            send = (torch.arange(w, device=device, dtype=torch.int32) + rank * w).repeat_interleave(16).contiguous()
+            recv = torch.full_like(send, -1)
+            ones = torch.ones(256, dtype=torch.float32, device=device)
+            try:
+                self.all_to_all(recv, send)
+                self.all_reduce_sum(ones)
+            except RuntimeError:
+                self.close()
+                return False
+            done.record(side)
+        t_end = time.monotonic() + deadline_s
+        while not done.query():
+            if time.monotonic() > t_end:
+                _lib.load().mi_comm_abort(self.handle)
+                self.handle = None
+                return False
+            time.sleep(0.002)
+        want = (torch.arange(w, device=device, dtype=torch.int32) * w + rank).repeat_interleave(16)
+        good = bool(torch.equal(recv, want)) and bool((ones == float(w)).all())
+        if not good:
+            self.close()
+        return good
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
         from . import _lib

@@ -335,6 +335,30 @@ def gen_dhe():
              prefix=np.array(emb._prefix), slopes=emb._slopes, bias=emb._bias,
              primes=emb._primes_choices, ids=ids, hash=h, big_ids=big, big_hash=hbig,
              out=out, x2=x2, out2=out2, **params_of(emb._seq, "param/_seq."))
+    # per-item hash family (use_universal_hash=False): the host-built [N, k] feature table and both lookup flows
+    DHEmbedding.COUNTER = 3
+    set_seed(2023)
+    dims, k, hidden, D = [7, 9], 16, [8], 4
+    emb = DHEmbedding(dims, D, None, k, list(hidden), cached=True, use_universal_hash=False)
+    after_init = torch.randint(0, 2**31 - 1, (4,))          # where the constructor leaves the global generator
+    cache = emb._cache.cpu() if isinstance(emb._cache, torch.Tensor) else torch.stack(emb._cache)
+    randomize_bn(emb, gen)
+    emb.eval()
+    N = sum(dims)
+    ids = torch.cat([torch.tensor([0, 1, N - 1]), torch.randint(0, N, (13,), generator=gen)])
+    x2 = ids[:12].reshape(4, 3)
+    with torch.no_grad():
+        out, out2 = emb(ids), emb(x2)
+    DHEmbedding.COUNTER = 3
+    set_seed(2023)
+    lazy = DHEmbedding(dims, D, None, k, list(hidden), cached=False, use_universal_hash=False)
+    lazy.load_state_dict(emb.state_dict())
+    lazy.eval()
+    with torch.no_grad():
+        out_lazy = lazy(x2)
+    save("dhe_peritem", field_dims=np.array(dims), k=np.array(k), hidden=np.array(hidden), D=np.array(D),
+         prefix=np.array(emb._prefix), cache=cache, after_init=after_init, ids=ids, out=out, x2=x2, out2=out2,
+         out_lazy=out_lazy, **params_of(emb._seq, "param/_seq."))
     DHEmbedding.COUNTER = 0
 
 
@@ -365,6 +389,24 @@ def gen_tt():
         save(name, num_item=np.array(N), hidden=np.array(D), tt_ranks=np.array(emb.tt_ranks),
              tt_p_shapes=np.array(emb.tt_p_shapes), tt_q_shapes=np.array(emb.tt_q_shapes),
              weight=emb.get_weight(), **params_of(emb), **out)
+
+
+def gen_tt_init():
+    """weight_dist='approx-uniform': the seeded construction itself is the fixture (numpy + Python `random` streams)."""
+    gen = torch.Generator().manual_seed(171)
+    for name, N, D, ranks, p_shapes, q_shapes in [
+        ("ttinit_approx_uniform_r4x6", 512, 16, [4, 6], None, None),
+        ("ttinit_approx_uniform_r2x3", 90, 8, [2, 3], [3, 5, 6], [2, 2, 2]),
+    ]:
+        set_seed(2023)
+        cfg = {"name": "tt_emb_torch", "tt_ranks": list(ranks), "weight_dist": "approx-uniform"}
+        if p_shapes is not None:
+            cfg["tt_p_shapes"], cfg["tt_q_shapes"] = list(p_shapes), list(q_shapes)
+        emb = get_embedding(cfg, N, D)
+        x = torch.randint(0, N, (6, 3), generator=gen)
+        save(name, num_item=np.array(N), hidden=np.array(D), tt_ranks=np.array(emb.tt_ranks),
+             tt_p_shapes=np.array(emb.tt_p_shapes), tt_q_shapes=np.array(emb.tt_q_shapes), x=x, out=emb(x),
+             weight=emb.get_weight(), **params_of(emb))
 
 
 # ------------------------------------------------------------------ G6: DCN
@@ -528,7 +570,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "dcn", "lightgcn", "csr_pruned", "losses", "metrics"]
+    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "tt_init", "dcn", "lightgcn", "csr_pruned", "losses", "metrics"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()

@@ -196,7 +196,7 @@ def test_pruned_embedding_like_reference_test():
 
 
 # ------------------------------------------------------------------ DHE
-@pytest.mark.parametrize("name", golden_names("dhe_"))
+@pytest.mark.parametrize("name", golden_names("dhe_k"))
 def test_dhe_matches_reference_golden(name):
     g = load_golden(name)
     DHEmbedding.COUNTER = int(g["prefix"])
@@ -217,6 +217,34 @@ def test_dhe_matches_reference_golden(name):
         assert_close(emb(g.t("x2").to(DEV)), g.t("out2"), 1e-4, 1e-5, "on-the-fly == cached path")
         emb.compute_v2 = True
         assert_close(emb(g.t("x2").to(DEV)), g.t("out2"), 1e-4, 1e-5, "compute_v2")
+
+
+def test_dhe_per_item_hash_family_matches_reference_golden():
+    """use_universal_hash=False (dh_embedding.py:155-196): the host-built feature table is bit-exact, the lookups are the
+    HIP row gather + MLP, cached and per-unique-id flows agree with the reference's outputs."""
+    g = load_golden("dhe_peritem")
+    kw = dict(use_universal_hash=False)
+    DHEmbedding.COUNTER = int(g["prefix"])
+    emb = DHEmbedding(g["field_dims"].tolist(), int(g["D"]), None, int(g["k"]), g["hidden"].tolist(), cached=True, **kw)
+    assert torch.equal(emb._cache, g.t("cache"))
+    assert not any(k.startswith("_slopes") or k.startswith("_bias") for k in emb.state_dict())
+    emb._seq.load_state_dict(g.group("param/_seq."), strict=True)
+    emb.to(DEV).eval()
+    DHEmbedding.COUNTER = int(g["prefix"])
+    lazy = DHEmbedding(g["field_dims"].tolist(), int(g["D"]), None, int(g["k"]), g["hidden"].tolist(), cached=False, **kw)
+    DHEmbedding.COUNTER = 0
+    lazy._seq.load_state_dict(g.group("param/_seq."), strict=True)
+    lazy.to(DEV).eval()
+    with torch.no_grad():
+        assert_close(emb(g.t("ids").to(DEV)), g.t("out"), 1e-4, 1e-5, "cached, 1-d ids")
+        assert_close(emb(g.t("x2").to(DEV)), g.t("out2"), 1e-4, 1e-5, "cached, 2-d ids")
+        assert_close(lazy(g.t("x2").to(DEV)), g.t("out_lazy"), 1e-4, 1e-5, "per unique id (cached=False, eval)")
+        emb.compute_v2 = True
+        assert_close(emb(g.t("x2").to(DEV)), g.t("out2"), 1e-4, 1e-5, "compute_v2")
+    assert emb._cache.is_cuda, "the feature table lives on the MLP's device after the first lookup"
+    lazy.train()
+    with pytest.raises(NotImplementedError):
+        lazy(g.t("x2").to(DEV))
 
 
 def test_dhe_hash_full_scale_bit_exact():
@@ -301,6 +329,27 @@ def test_tt_matches_reference_golden(name):
             assert_close(emb.tt_cores[i].grad, g.t(f"grad_{tag}/tt_cores.{i}"), 1e-4, 1e-6, f"grad core {i}")
     assert_close(emb.get_weight(), g.t("weight"), 1e-5, 1e-6, "get_weight")
     assert emb.get_num_params() == sum(p * q * a * b for p, q, a, b in zip(ps, qs, rs[:-1], rs[1:]))
+
+
+@pytest.mark.parametrize("name", golden_names("ttinit_"))
+def test_tt_approx_uniform_construction_then_lookup(name):
+    """weight_dist='approx-uniform' (tt_embedding_ops.py:861-986): seeded like the reference's set_seed, the three cores
+    come out bit-identical; the HIP lookup of that table equals the reference's rows."""
+    import random
+
+    from recsys_benchmark_amd.embeddings import TTRecTorch
+
+    g = load_golden(name)
+    ps, qs, rs = g["tt_p_shapes"].tolist(), g["tt_q_shapes"].tolist(), g["tt_ranks"].tolist()
+    np.random.seed(2023), torch.manual_seed(2023), random.seed(2023)
+    explicit = name.endswith("r2x3")
+    emb = TTRecTorch(int(g["num_item"]), int(g["hidden"]), rs[1:-1], tt_p_shapes=ps if explicit else None,
+                     tt_q_shapes=qs if explicit else None, weight_dist="approx-uniform")
+    for i, c in enumerate(emb.tt_cores):
+        assert torch.equal(c.data, g.t(f"param/tt_cores.{i}")), f"core {i}"
+    emb.to(DEV)
+    assert_close(emb(g.t("x").to(DEV)), g.t("out"), 1e-5, 1e-6, "lookup")
+    assert_close(emb.get_weight(), g.t("weight"), 1e-5, 1e-6, "get_weight")
 
 
 def test_tt_reference_ranks_vs_oracle():

@@ -96,8 +96,6 @@ def test_dhe_seeded_constants_and_counter():
     DHEmbedding.COUNTER = 0
     assert torch.equal(emb._slopes, g.t("slopes")) and torch.equal(emb._primes_choices, g.t("primes"))
     assert emb.get_extra_state() == {"_prefix": int(g["prefix"])}
-    with pytest.raises(NotImplementedError):
-        DHEmbedding(10, 8, use_universal_hash=False)
 
 
 def test_cerp_threshold_init_and_entity_per_row():
@@ -305,3 +303,45 @@ def test_bench_cpu_baseline_protocol_on_a_small_shape():
     assert all(2 <= ln["timed_iters"] <= 10 for ln in r["lines"])
     med, n = bench.timed_cpu(lambda: None, warm=1, timed=5, budget_s=1.0)
     assert n == 5 and med >= 0
+
+
+def test_dhe_per_item_hash_table_is_the_references():
+    """Host logic of use_universal_hash=False (dh_embedding.py:155-196): the [N, k] feature table built at construction is
+    bit-identical to the reference's, and the constructor leaves torch's global generator where the reference leaves it."""
+    g = load_golden("dhe_peritem")
+    c0 = DHEmbedding.COUNTER
+    try:
+        DHEmbedding.COUNTER = int(g["prefix"])
+        torch.manual_seed(2023)
+        emb = DHEmbedding(g["field_dims"].tolist(), int(g["D"]), None, int(g["k"]), g["hidden"].tolist(), cached=True,
+                          use_universal_hash=False)
+        after = torch.randint(0, 2**31 - 1, (4,))
+    finally:
+        DHEmbedding.COUNTER = c0
+    assert torch.equal(emb._cache, g.t("cache"))
+    assert torch.equal(after, g.t("after_init"))
+    assert emb._cache.min() >= -1 and emb._cache.max() <= 1
+    assert sorted(emb.state_dict().keys()) == sorted(["_extra_state"] + ["_seq." + k for k in g.group("param/_seq.")])
+
+
+@pytest.mark.parametrize("name", ["ttinit_approx_uniform_r4x6", "ttinit_approx_uniform_r2x3"])
+def test_tt_approx_uniform_cores_are_the_references(name):
+    """Host logic of weight_dist='approx-uniform' (tt_embedding_ops.py:861-986): same numpy / `random` draw order, so the
+    seeded cores are bit-identical; two cores is refused like the reference's assert."""
+    import random
+
+    import numpy as np
+
+    from recsys_benchmark_amd.embeddings import TTRecTorch
+
+    g = load_golden(name)
+    ps, qs, rs = g["tt_p_shapes"].tolist(), g["tt_q_shapes"].tolist(), g["tt_ranks"].tolist()
+    np.random.seed(2023), torch.manual_seed(2023), random.seed(2023)
+    explicit = name.endswith("r2x3")
+    emb = TTRecTorch(int(g["num_item"]), int(g["hidden"]), rs[1:-1], tt_p_shapes=ps if explicit else None,
+                     tt_q_shapes=qs if explicit else None, weight_dist="approx-uniform")
+    assert emb.tt_p_shapes == ps and emb.tt_q_shapes == qs
+    for i, c in enumerate(emb.tt_cores):
+        assert c.dtype == torch.float32 and torch.equal(c.data, g.t(f"param/tt_cores.{i}")), f"core {i}"
+    with pytest.raises(AssertionError):
+        TTRecTorch(100, 8, [4], tt_p_shapes=[10, 10], tt_q_shapes=[2, 4], weight_dist="approx-uniform")
