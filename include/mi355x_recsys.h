@@ -370,11 +370,6 @@ MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate
  * 1-output Linear (the tail's last layer), computed on the fly instead of being written and read back twice.
  * dgamma_dbeta fp32[2,N] (zeroed by the caller) receives dgamma then dbeta;
  * dZ = gamma*rstd*(dyh - dbeta/M - zh*dgamma/M) in training.
- * sync (nullable; training BatchNorm): 4 bytes, ZEROED by the caller like `stats` / `dgamma_dbeta` (and distinct per
- * call in flight) — selects the single-launch form: statistics and apply in ONE cooperative launch of <= 256 resident
- * workgroups that keep their rows in registers across a grid-wide barrier counted in that word (N % 4 == 0, N <= 1024
- * and M*N <= 256 workgroups x 8 row steps; any other shape, or sync == NULL, takes the two-launch form).  Same results
- * up to the order of the column sums; same dropout mask.
  */
 MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N,
                                   int32_t has_bn, int32_t training, const float *gamma,
@@ -382,13 +377,13 @@ MI_API int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_
                                   float momentum, float eps, float p, int64_t *seed,
                                   int64_t salt, int32_t bump_seed, int64_t *num_batches_tracked,
                                   float *stats, const float *mean_offset, float *Y, uint8_t *keep,
-                                  float *save_mean, float *save_rstd, int32_t *sync, void *stream);
+                                  float *save_mean, float *save_rstd, void *stream);
 MI_API int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M,
                                   int32_t N, int32_t has_bn, int32_t training,
                                   const uint8_t *keep, float p, const float *gamma,
                                   const float *beta, const float *save_mean,
                                   const float *save_rstd, float *dgamma_dbeta, float *dZ,
-                                  const float *gvec, const float *wvec, int32_t *sync, void *stream);
+                                  const float *gvec, const float *wvec, void *stream);
 
 /* ---- §8f rank 3: the contrastive loss of the LightGCN step ------------------------------------
  * Reference: info_nce (src/losses.py:25-47) as called by the trainer (src/trainer/lightgcn.py:215-229).

@@ -51,9 +51,9 @@ SIGNATURES = {
     "mi_tt_fwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_tt_bwd": [_p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_bn_relu_dropout_fwd": [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float,
-                               ctypes.c_float, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+                               ctypes.c_float, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p],
     "mi_bn_relu_dropout_bwd": [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p, _p,
-                               _p, _p],
+                               _p],
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
                               ctypes.c_double, ctypes.c_float, _p],
     "mi_coalesce_rows_sorted": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p],

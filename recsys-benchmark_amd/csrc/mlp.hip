@@ -435,225 +435,6 @@ __global__ __launch_bounds__(kBlock) void k_bn_bwd_apply(BnBwdArgs a) {
   }
 }
 
-// ---- single-launch forms (training BatchNorm): statistics AND apply in one cooperative launch ----------------------
-// At [4096, 400] the activation is 6.5 MB = 25.6 KB per CU: every workgroup keeps its rows IN REGISTERS between the
-// reduction and the apply, so a pass reads the activation once and costs one launch instead of two.  Geometry: a thread
-// owns one float4 column group (tpr = N/4 threads cover a row, rpp = 256/tpr rows per step) and up to PASSES rows of its
-// workgroup's R consecutive rows; G = ceil(M/R) <= 256 workgroups.  The column sums meet in LDS, then one device-scope
-// float atomic per column and workgroup; ONE grid-wide barrier (a counter in caller-zeroed memory: arrive with a
-// device-scope atomic once the workgroup's atomics are acknowledged, spin on device-scope loads — no __threadfence, which
-// on gfx950 is an L2 write-back per workgroup); the totals come back as device-scope loads.  All G workgroups are resident
-// at once (256 threads, < 128 VGPRs: >= 4 fit per CU), which the spin needs.
-struct CoopGeom {
-  int tpr, rpp, R, G, passes;
-};
-inline bool coop_geom(int M, int N, CoopGeom &g) {
-  if (N % 4 != 0 || N / 4 > kBlock || M < 1) return false;
-  g.tpr = N / 4;
-  g.rpp = kBlock / g.tpr;
-  int G = (M + g.rpp - 1) / g.rpp;
-  if (G > 256) G = 256;
-  g.R = (M + G - 1) / G;
-  g.G = (M + g.R - 1) / g.R;
-  g.passes = (g.R + g.rpp - 1) / g.rpp;
-  return g.passes <= 8;
-}
-
-__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned G) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's atomics are acknowledged at the coherence point
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ float4 coherent_ld4(const float *p) {
-  return make_float4(read_partial(p), read_partial(p + 1), read_partial(p + 2), read_partial(p + 3));
-}
-// column sums of the workgroup: the rpp row lanes of a column group meet in LDS, lane 0 of each adds 2 x 4 floats globally
-__device__ __forceinline__ void flush_columns(float4 (*red)[kBlock], float4 u, float4 v, int tpr, int rpp, bool active,
-                                              int rin, int c4, float *t1, float *t2) {
-  red[0][threadIdx.x] = u;
-  red[1][threadIdx.x] = v;
-  __syncthreads();
-  if (active && rin == 0) {
-    for (int r = 1; r < rpp; ++r) {
-      const float4 x = red[0][r * tpr + c4], y = red[1][r * tpr + c4];
-      u.x += x.x; u.y += x.y; u.z += x.z; u.w += x.w;
-      v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
-    }
-    float *q1 = t1 + c4 * 4, *q2 = t2 + c4 * 4;
-    atomicAdd(q1, u.x); atomicAdd(q1 + 1, u.y); atomicAdd(q1 + 2, u.z); atomicAdd(q1 + 3, u.w);
-    atomicAdd(q2, v.x); atomicAdd(q2 + 1, v.y); atomicAdd(q2 + 2, v.z); atomicAdd(q2 + 3, v.w);
-  }
-}
-
-template <int PASSES>
-__global__ __launch_bounds__(kBlock) void k_bn_fwd_coop(BnArgs a, float *s1, float *s2, unsigned *sync, int64_t *bump,
-                                                        int tpr, int rpp, int R) {
-  __shared__ float4 red[2][kBlock];
-  const int tid = threadIdx.x, rin = tid / tpr, c4 = tid - rin * tpr, n0 = c4 * 4;
-  const bool active = rin < rpp;
-  const int row0 = blockIdx.x * R, row_end = min(a.M, row0 + R);
-  if (bump && blockIdx.x == 0 && tid == 0)   // seen by every workgroup after the barrier (device-scope both sides)
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(bump), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float4 z[PASSES];
-  bool ok[PASSES];
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 sh = active ? ld4(a.Z + n0) : zero;
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    const int m = row0 + k * rpp + rin;
-    ok[k] = active && m < row_end;
-    z[k] = ok[k] ? ld4(a.Z + (int64_t)m * a.ld + n0) : sh;
-  }
-  float4 u = zero, v = zero;
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    if (!ok[k]) continue;
-    const float dx = z[k].x - sh.x, dy = z[k].y - sh.y, dz = z[k].z - sh.z, dw = z[k].w - sh.w;
-    u.x += dx; u.y += dy; u.z += dz; u.w += dw;
-    v.x += dx * dx; v.y += dy * dy; v.z += dz * dz; v.w += dw * dw;
-  }
-  flush_columns(red, u, v, tpr, rpp, active, rin, c4, s1, s2);
-  grid_barrier(sync, gridDim.x);
-  if (!active) return;
-  const float invM = 1.f / (float)a.M;
-  const float4 t1 = coherent_ld4(s1 + n0), t2 = coherent_ld4(s2 + n0);
-  const float s1v[4] = {t1.x, t1.y, t1.z, t1.w}, s2v[4] = {t2.x, t2.y, t2.z, t2.w}, cv[4] = {sh.x, sh.y, sh.z, sh.w};
-  float mean[4], rstd[4], var[4], g[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float d1 = s1v[j] * invM;
-    mean[j] = cv[j] + d1;
-    var[j] = fmaxf(s2v[j] * invM - d1 * d1, 0.f);
-    rstd[j] = rsqrtf(var[j] + a.eps);
-  }
-  if (a.gamma) { const float4 t = ld4(a.gamma + n0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
-  if (a.beta) { const float4 t = ld4(a.beta + n0); b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w; }
-  if (blockIdx.x == 0 && rin == 0) {   // one thread per column group owns the bookkeeping
-    if (tid == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
-    st4(a.save_mean + n0, make_float4(mean[0], mean[1], mean[2], mean[3]));
-    st4(a.save_rstd + n0, make_float4(rstd[0], rstd[1], rstd[2], rstd[3]));
-    if (a.running_mean) {
-      const float ub = a.M > 1 ? (float)a.M / (float)(a.M - 1) : 1.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float mo = a.mean_offset ? a.mean_offset[n0 + j] : 0.f;
-        a.running_mean[n0 + j] = (1.f - a.momentum) * a.running_mean[n0 + j] + a.momentum * (mean[j] + mo);
-        a.running_var[n0 + j] = (1.f - a.momentum) * a.running_var[n0 + j] + a.momentum * var[j] * ub;
-      }
-    }
-  }
-  const bool drop = a.p > 0.f;
-  const float keep_scale = drop ? 1.f / (1.f - a.p) : 1.f;
-  const uint32_t thresh = drop ? (uint32_t)((double)a.p * 4294967296.0) : 0u;
-  uint64_t seed = 0ull;
-  if (drop)
-    seed = (uint64_t)((int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seed), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT) + a.salt);
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    if (!ok[k]) continue;
-    const int m = row0 + k * rpp + rin;
-    const int64_t e0 = (int64_t)m * a.N + n0;
-    const float zz[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
-    float y[4];
-    uint8_t kv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float t = g[j] * (zz[j] - mean[j]) * rstd[j] + b[j];
-      t = t > 0.f ? t : 0.f;
-      kv[j] = 1;
-      if (drop) {
-        const bool kp = rng32(seed, (uint64_t)(e0 + j)) >= thresh;
-        kv[j] = kp ? 1 : 0;
-        t = kp ? t * keep_scale : 0.f;
-      }
-      y[j] = t;
-    }
-    st4(a.Y + e0, make_float4(y[0], y[1], y[2], y[3]));
-    if (drop) *reinterpret_cast<uchar4 *>(a.keep + e0) = make_uchar4(kv[0], kv[1], kv[2], kv[3]);
-  }
-}
-
-template <int PASSES, bool RANK1>
-__global__ __launch_bounds__(kBlock) void k_bn_bwd_coop(BnBwdArgs a, unsigned *sync, int tpr, int rpp, int R) {
-  __shared__ float4 red[2][kBlock];
-  const int tid = threadIdx.x, rin = tid / tpr, c4 = tid - rin * tpr, n0 = c4 * 4;
-  const bool active = rin < rpp;
-  const int row0 = blockIdx.x * R, row_end = min(a.M, row0 + R);
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 z[PASSES], dy[PASSES];
-  uchar4 k4[PASSES];
-  bool ok[PASSES];
-  float4 w4 = zero;
-  if constexpr (RANK1) w4 = active ? ld4(a.wvec + n0) : zero;
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    const int m = row0 + k * rpp + rin;
-    ok[k] = active && m < row_end;
-    const int64_t mr = ok[k] ? m : 0;
-    const int nn = active ? n0 : 0;
-    z[k] = ld4(a.Z + mr * a.ld + nn);
-    if constexpr (!RANK1) {
-      dy[k] = ld4(a.dY + mr * a.N + nn);
-    } else {
-      const float gm = a.gvec[mr];
-      dy[k] = make_float4(gm * w4.x, gm * w4.y, gm * w4.z, gm * w4.w);
-    }
-    k4[k] = a.keep ? *reinterpret_cast<const uchar4 *>(a.keep + mr * a.N + nn) : make_uchar4(1, 1, 1, 1);
-  }
-  float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f}, g[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    const float4 m4 = ld4(a.save_mean + n0), r4 = ld4(a.save_rstd + n0);
-    mean[0] = m4.x; mean[1] = m4.y; mean[2] = m4.z; mean[3] = m4.w;
-    rstd[0] = r4.x; rstd[1] = r4.y; rstd[2] = r4.z; rstd[3] = r4.w;
-    if (a.gamma) { const float4 t = ld4(a.gamma + n0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
-    if (a.beta) { const float4 t = ld4(a.beta + n0); bt[0] = t.x; bt[1] = t.y; bt[2] = t.z; bt[3] = t.w; }
-  }
-  const float ks = a.keep ? 1.f / (1.f - a.p) : 1.f;
-  float accb[4] = {0.f, 0.f, 0.f, 0.f}, accg[4] = {0.f, 0.f, 0.f, 0.f};
-  // z[k] <- zh, dy[k] <- masked upstream gradient: what the apply needs after the barrier
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    float zz[4] = {z[k].x, z[k].y, z[k].z, z[k].w}, dd[4] = {dy[k].x, dy[k].y, dy[k].z, dy[k].w};
-    const unsigned char kk[4] = {k4[k].x, k4[k].y, k4[k].z, k4[k].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float zh = (zz[j] - mean[j]) * rstd[j];
-      float d = kk[j] ? dd[j] * ks : 0.f;
-      d = (g[j] * zh + bt[j]) > 0.f ? d : 0.f;
-      d = ok[k] ? d : 0.f;
-      accb[j] += d;
-      accg[j] += d * zh;
-      zz[j] = zh;
-      dd[j] = d;
-    }
-    z[k] = make_float4(zz[0], zz[1], zz[2], zz[3]);
-    dy[k] = make_float4(dd[0], dd[1], dd[2], dd[3]);
-  }
-  flush_columns(red, make_float4(accb[0], accb[1], accb[2], accb[3]), make_float4(accg[0], accg[1], accg[2], accg[3]), tpr, rpp,
-                active, rin, c4, a.dbeta, a.dgamma);
-  grid_barrier(sync, gridDim.x);
-  if (!active) return;
-  const float invM = 1.f / (float)a.M;
-  const float4 db4 = coherent_ld4(a.dbeta + n0), dg4 = coherent_ld4(a.dgamma + n0);
-  const float db[4] = {db4.x * invM, db4.y * invM, db4.z * invM, db4.w * invM};
-  const float dg[4] = {dg4.x * invM, dg4.y * invM, dg4.z * invM, dg4.w * invM};
-#pragma unroll
-  for (int k = 0; k < PASSES; ++k) {
-    if (!ok[k]) continue;
-    const int m = row0 + k * rpp + rin;
-    const float zh[4] = {z[k].x, z[k].y, z[k].z, z[k].w}, d[4] = {dy[k].x, dy[k].y, dy[k].z, dy[k].w};
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = g[j] * rstd[j] * (d[j] - db[j] - zh[j] * dg[j]);
-    st4(a.dZ + (int64_t)m * a.N + n0, make_float4(o[0], o[1], o[2], o[3]));
-  }
-}
-
 inline int grid_for_elems(int64_t total) {
   int64_t g = (total + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
@@ -687,7 +468,7 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
                            float momentum, float eps, float p, int64_t *seed, int64_t salt, int32_t bump_seed,
                            int64_t *num_batches_tracked,
                            float *stats /*[2,N] caller-zeroed; training BN only*/, const float *mean_offset,
-                           float *Y, uint8_t *keep, float *save_mean, float *save_rstd, int32_t *sync, void *stream) {
+                           float *Y, uint8_t *keep, float *save_mean, float *save_rstd, void *stream) {
   if (M < 0 || N < 0 || p < 0.f || p >= 1.f) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
   if (!Z || !Y) return MI_ERR_INVALID_ARG;
@@ -697,28 +478,6 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
   if (has_bn && training && !stats) return MI_ERR_INVALID_ARG;
   if (has_bn && !training && (!running_mean || !running_var)) return MI_ERR_INVALID_ARG;
   if (bump_seed && !(has_bn && training)) return MI_ERR_INVALID_ARG;  // only the statistics launch can bump
-  CoopGeom cg;
-  if (has_bn && training && sync && coop_geom(M, N, cg) && ldz % 4 == 0 && aligned16(Z) && aligned16(Y) && aligned16(stats) &&
-      (!drop || ((uintptr_t)keep & 3) == 0) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)) &&
-      aligned16(save_mean) && aligned16(save_rstd)) {
-    BnArgs a;
-    a.Z = Z; a.ld = ldz; a.M = M; a.N = N; a.has_bn = 1; a.training = 1;
-    a.s1 = stats; a.s2 = stats + N; a.mean_offset = mean_offset;
-    a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
-    a.momentum = momentum; a.eps = eps; a.p = drop ? p : 0.f; a.seed = seed; a.salt = salt;
-    a.Y = Y; a.keep = drop ? keep : nullptr; a.save_mean = save_mean; a.save_rstd = save_rstd;
-    a.num_batches_tracked = num_batches_tracked;
-    int64_t *bump = bump_seed ? seed : nullptr;
-    unsigned *sy = reinterpret_cast<unsigned *>(sync);
-#define MI_BN_FWD_COOP(P) \
-  MI_LAUNCH("bn_fwd_coop", k_bn_fwd_coop<P>, cg.G, kBlock, stream, a, stats, stats + N, sy, bump, cg.tpr, cg.rpp, cg.R)
-    if (cg.passes <= 1) MI_BN_FWD_COOP(1);
-    else if (cg.passes <= 2) MI_BN_FWD_COOP(2);
-    else if (cg.passes <= 4) MI_BN_FWD_COOP(4);
-    else MI_BN_FWD_COOP(8);
-#undef MI_BN_FWD_COOP
-    return launch_status();
-  }
   if (has_bn && training) {
     int64_t *bump = bump_seed ? seed : nullptr;
     if (N % 4 == 0 && ldz % 4 == 0 && aligned16(Z) && aligned16(stats))
@@ -746,7 +505,7 @@ int mi_bn_relu_dropout_fwd(const float *Z, int32_t ldz, int32_t M, int32_t N, in
 int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t M, int32_t N, int32_t has_bn,
                            int32_t training, const uint8_t *keep, float p, const float *gamma, const float *beta,
                            const float *save_mean, const float *save_rstd, float *dgamma_dbeta /*[2,N] zeroed*/,
-                           float *dZ, const float *gvec, const float *wvec, int32_t *sync, void *stream) {
+                           float *dZ, const float *gvec, const float *wvec, void *stream) {
   if (M < 0 || N < 0 || p < 0.f || p >= 1.f) return MI_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MI_OK;
   if (!Z || !dZ || (!dY && (!gvec || !wvec))) return MI_ERR_INVALID_ARG;
@@ -756,23 +515,6 @@ int mi_bn_relu_dropout_bwd(const float *dY, const float *Z, int32_t ldz, int32_t
   a.keep = keep; a.p = p; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_rstd = save_rstd;
   a.dgamma = dgamma_dbeta; a.dbeta = dgamma_dbeta ? dgamma_dbeta + N : nullptr;
   a.dZ = dZ;
-  CoopGeom cg;
-  if (has_bn && training && sync && coop_geom(M, N, cg) && ldz % 4 == 0 && aligned16(Z) && aligned16(dZ) &&
-      (dY ? aligned16(dY) : aligned16(wvec)) && (!keep || ((uintptr_t)keep & 3) == 0) && aligned16(save_mean) &&
-      aligned16(save_rstd) && aligned16(dgamma_dbeta) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta))) {
-    unsigned *sy = reinterpret_cast<unsigned *>(sync);
-#define MI_BN_BWD_COOP(P)                                                                                              \
-  do {                                                                                                                 \
-    if (dY) MI_LAUNCH("bn_bwd_coop", (k_bn_bwd_coop<P, false>), cg.G, kBlock, stream, a, sy, cg.tpr, cg.rpp, cg.R);      \
-    else MI_LAUNCH("bn_bwd_coop", (k_bn_bwd_coop<P, true>), cg.G, kBlock, stream, a, sy, cg.tpr, cg.rpp, cg.R);          \
-  } while (0)
-    if (cg.passes <= 1) MI_BN_BWD_COOP(1);
-    else if (cg.passes <= 2) MI_BN_BWD_COOP(2);
-    else if (cg.passes <= 4) MI_BN_BWD_COOP(4);
-    else MI_BN_BWD_COOP(8);
-#undef MI_BN_BWD_COOP
-    return launch_status();
-  }
   if (has_bn) {
     const bool v4r = (N % 4 == 0) && (ldz % 4 == 0) && aligned16(Z) && (dY ? aligned16(dY) : aligned16(wvec)) && (!keep || ((uintptr_t)keep & 3) == 0) &&
                      aligned16(save_mean) && aligned16(save_rstd) && aligned16(dgamma_dbeta) && (!gamma || aligned16(gamma)) &&

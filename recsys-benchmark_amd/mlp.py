@@ -73,18 +73,6 @@ def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
-# The single-launch BatchNorm passes (csrc/mlp.hip, "single-launch forms") count their grid-wide barrier in one zeroed
-# 32-bit word: it rides behind the 2N reduction targets of the same zero-filled slice.  COOPERATIVE_BN = False keeps the
-# two-launch forms.
-COOPERATIVE_BN = True
-
-
-def _sync_word(buf: Optional[torch.Tensor], N: int) -> Optional[int]:
-    if buf is None or not COOPERATIVE_BN or buf.numel() < 2 * N + 1:
-        return None
-    return buf.data_ptr() + 8 * N
-
-
 class _LinearFn(torch.autograd.Function):
     """z = x W^T + b on rocBLAS/hipBLASLt.  db: the library's column sum into `db_buf` (a zeroed
     workspace slice), or — zero_db — that zeroed slice itself when z feeds a training BatchNorm."""
@@ -181,7 +169,7 @@ class _BNReLUDropFn(torch.autograd.Function):
         y = torch.empty_like(z)
         keep = torch.empty((M, N), dtype=torch.uint8, device=dev) if drop else None
         if bn_train and stats is None:
-            stats = torch.zeros((2 * N + 4,), dtype=torch.float32, device=dev)
+            stats = torch.zeros((2 * N,), dtype=torch.float32, device=dev)
         save = torch.empty((2, N), dtype=torch.float32, device=dev) if has_bn else None
         _lib.check(
             _lib.load().mi_bn_relu_dropout_fwd(
@@ -190,8 +178,7 @@ class _BNReLUDropFn(torch.autograd.Function):
                 _lib.ptr(seed), int(salt), int(bool(bump_seed and bn_train)), _lib.ptr(nbt) if bn_train else None,
                 _lib.ptr(stats) if bn_train else None, _lib.ptr(mean_offset) if bn_train else None, y.data_ptr(),
                 _lib.ptr(keep),
-                save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None,
-                _sync_word(stats, N) if bn_train else None, _lib.stream_ptr(dev)),
+                save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None, _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_fwd",
         )
         ctx.meta = (M, N, bool(has_bn), bool(training), float(p if drop else 0.0))
@@ -239,13 +226,12 @@ class _BNReLUDropFn(torch.autograd.Function):
             dy_ptr = dy.data_ptr()
         dz = torch.empty_like(z)
         if has_bn and dgb is None:
-            dgb = torch.zeros((2 * N + 4,), dtype=torch.float32, device=dev)
+            dgb = torch.zeros((2 * N,), dtype=torch.float32, device=dev)
         _lib.check(
             lib.mi_bn_relu_dropout_bwd(
                 dy_ptr, z.data_ptr(), N, M, N, int(has_bn), int(training), _lib.ptr(keep), p, _lib.ptr(gamma),
                 _lib.ptr(beta), save[0].data_ptr() if has_bn else None, save[1].data_ptr() if has_bn else None,
-                _lib.ptr(dgb), dz.data_ptr(), _lib.ptr(gvec), _lib.ptr(W1),
-                _sync_word(dgb, N) if (has_bn and training) else None, _lib.stream_ptr(dev)),
+                _lib.ptr(dgb), dz.data_ptr(), _lib.ptr(gvec), _lib.ptr(W1), _lib.stream_ptr(dev)),
             "mi_bn_relu_dropout_bwd",
         )
         dgamma = dgb[:N] if (has_bn and gamma is not None and ctx.needs_input_grad[1]) else None
@@ -296,7 +282,7 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
     for grp in groups:
         lin = grp[1]
         if isinstance(lin, nn.Linear):
-            need += _pad4(lin.out_features) * (5 if grp[0] == "fused" else 1) + (8 if grp[0] == "fused" else 0)
+            need += _pad4(lin.out_features) * (5 if grp[0] == "fused" else 1)
             if grp[0] == "plain" and lin.out_features == 1:
                 need += _pad4(lin.in_features + 1)       # the rank-1 layer's backward column sums
     ws = torch.zeros((need,), dtype=torch.float32, device=dev) if (need and torch.is_grad_enabled()) else None
@@ -335,7 +321,7 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         p = dp.p if (dp is not None and dp.training) else 0.0
         skip_bias = bool(training_bn and lin.bias is not None)
         z = _LinearFn.apply(x, lin.weight, lin.bias, take(N), bool(training_bn), skip_bias)
-        stats, dgb = take(2 * N + 4), take(2 * N + 4)      # + the barrier word of the single-launch pass
+        stats, dgb = take(2 * N), take(2 * N)
         bump_in_kernel = False
         if p > 0.0 and need_bump:
             if training_bn:

@@ -97,81 +97,6 @@ def test_fused_bn_relu_vs_cpu_modules(M, N, bn, training):
         assert_close(rv, ref_bn.running_var, 1e-5, 1e-6, "running_var")
 
 
-@pytest.mark.parametrize("M,N", [(4096, 400), (4096, 352), (200, 40), (67, 8), (1, 4), (513, 1024), (4100, 400), (3000, 128)])
-@pytest.mark.parametrize("rank1", [False, True])
-def test_single_launch_bn_passes_equal_the_two_launch_passes(M, N, rank1, monkeypatch):
-    """The cooperative (one launch, rows kept in registers across a grid barrier) BatchNorm+ReLU+Dropout passes against the
-    two-launch passes on the same input: identical dropout mask and seed/num_batches_tracked bookkeeping (integer work:
-    exact), values equal up to the order of the column sums.  (513, 1024) and (4100, 400) exceed the register geometry and
-    must quietly take the two-launch form either way."""
-    from recsys_benchmark_amd import mlp as _mlp
-    from recsys_benchmark_amd.mlp import _BNReLUDropFn, _seed_word
-
-    dev = torch.device(DEV, 0)
-    torch.manual_seed(M * 7 + N)
-    Z = (torch.randn(M, N) * 2 + 0.7).to(DEV)
-    G = torch.randn(M, N, device=DEV)
-    gv, W1 = torch.randn(M, 1, device=DEV), torch.randn(1, N, device=DEV)
-    gamma0, beta0 = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.3
-    moff = torch.randn(N, device=DEV) * 0.1
-    out = {}
-    for coop in (True, False):
-        monkeypatch.setattr(_mlp, "COOPERATIVE_BN", coop)
-        seed = _seed_word(dev)
-        seed.fill_(1234)
-        gamma, beta = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
-        rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
-        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
-        z = Z.clone().requires_grad_(True)
-        lin1 = (W1.clone().requires_grad_(True), None, None, None) if rank1 else ()
-        y = _BNReLUDropFn.apply(z, gamma, beta, rm, rv, nbt, True, True, 0.1, 1e-5, 0.5, seed, 77, True, None, None, moff, *lin1)
-        if rank1:
-            (y * gv).sum().backward()
-        else:
-            (y * G).sum().backward()
-        out[coop] = (y.detach(), z.grad, gamma.grad, beta.grad, rm, rv, int(nbt), int(seed))
-    a, b = out[True], out[False]
-    assert a[6] == b[6] == 1 and a[7] == b[7] == 1235
-    if not rank1:
-        assert torch.equal(a[0] != 0, b[0] != 0) or float(((a[0] != 0) != (b[0] != 0)).float().mean()) < 1e-5   # mask (+ReLU kinks)
-    scale = lambda t: float(t.abs().max().clamp_min(1e-6))          # noqa: E731
-    for name, i, tol in (("y", 0, 2e-5), ("dz", 1, 2e-4), ("dgamma", 2, 4e-4), ("dbeta", 3, 4e-4), ("running_mean", 4, 1e-5),
-                         ("running_var", 5, 1e-5)):
-        bad = ((a[i] - b[i]).abs() > tol * scale(b[i])).float().mean()
-        assert float(bad) <= (2.0 / N if name in ("dgamma", "dbeta") and M * N >= 100000 else 1e-5 if name in ("y", "dz") else 0.0), \
-            f"{name}: {float((a[i] - b[i]).abs().max()):.3e} vs scale {scale(b[i]):.3e}"
-
-
-def test_single_launch_bn_pass_is_graph_capturable_and_rereads_the_seed():
-    """Captured into a hipGraph with its zero-filled workspace: every replay takes a fresh dropout stream (seed bump inside
-    the launch) and leaves the barrier word reusable."""
-    from recsys_benchmark_amd.mlp import _seed_word
-
-    torch.manual_seed(5)
-    seq = _seq(64, [400, 400], True, 0.5).to(DEV).train()
-    x = torch.randn(4096, 64, device=DEV)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            run_tail(seq, x).sum().backward()
-    torch.cuda.current_stream().wait_stream(side)
-    seq.zero_grad(set_to_none=True)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        out = run_tail(seq, x)
-        out.sum().backward()
-    seed0 = int(_seed_word(torch.device(DEV, 0)))
-    outs = []
-    for _ in range(3):
-        g.replay()
-        torch.cuda.synchronize()
-        outs.append(out.clone())
-    assert int(_seed_word(torch.device(DEV, 0))) == seed0 + 3
-    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])   # a new mask per replay
-    assert all(torch.isfinite(o).all() for o in outs)
-
-
 def test_linear_fn_vs_cpu():
     from recsys_benchmark_amd.mlp import _LinearFn
 
