@@ -327,6 +327,23 @@ MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int3
                        int32_t nrs, float *C2, int32_t ldc2, int64_t sC2, int32_t splitk,
                        void *stream);
 
+/* Several independent products of ONE operand layout in a single launch — the weight gradients of a CrossNet backward
+ * (src/models/layer_dcn.py:27-115 through autograd: dU, dC, dV, dG of every layer are each a few 64x64 tiles with a
+ * B-long reduction; one at a time none fills the chip).  Problem j: C_j[batch] (+)= opA(A_j) opB(B_j), batch strides
+ * sA/sB/sC, `splitk` K-slices that meet in float atomics (then C_j must be zeroed by the caller, or accumulate != 0).
+ * n <= 16; transA/transB as in mi_gemm_f32 and common to all problems.  `probs` is a HOST array read during the call. */
+typedef struct mi_gemm_problem {
+  const float *A, *B;
+  float *C;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t batch;
+  int64_t sA, sB, sC;
+  int32_t splitk;
+  int32_t accumulate;
+} mi_gemm_problem;
+MI_API int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream);
+
 /* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
  *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
  *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients);

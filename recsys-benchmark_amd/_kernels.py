@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns the device buffers and the stream; every
 arithmetic step of the hot path runs in libmi355x_recsys.so.
 """
 import collections
+import ctypes as _ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -674,6 +675,50 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, s
         "mi_gemm_f32",
     )
     return C
+
+
+class _GemmProblem(_ctypes.Structure):      # mi_gemm_problem (include/mi355x_recsys.h)
+    _fields_ = [("A", _ctypes.c_void_p), ("B", _ctypes.c_void_p), ("C", _ctypes.c_void_p),
+                ("M", _ctypes.c_int32), ("N", _ctypes.c_int32), ("K", _ctypes.c_int32),
+                ("lda", _ctypes.c_int32), ("ldb", _ctypes.c_int32), ("ldc", _ctypes.c_int32), ("batch", _ctypes.c_int32),
+                ("sA", _ctypes.c_int64), ("sB", _ctypes.c_int64), ("sC", _ctypes.c_int64),
+                ("splitk", _ctypes.c_int32), ("accumulate", _ctypes.c_int32)]
+
+
+MAX_GEMM_PROBLEMS = 16
+
+
+def auto_splitk(M, N, K, batch=1):
+    """K-slices that fill the 256 CUs when the output is only a few 64x64 tiles (1 in deterministic mode: the slices meet
+    in float atomics)."""
+    tiles = -(-M // 64) * -(-N // 64) * batch
+    ksteps = -(-K // 32)
+    if tiles < 256 and ksteps >= 16 and not DETERMINISTIC:
+        return max(1, min(ksteps // 4, -(-512 // tiles), 65535 // max(batch, 1)))
+    return 1
+
+
+def gemm_multi(problems, transA=False, transB=False):
+    """problems: dicts with A, B, C (torch buffers / views), M, N, K, lda, ldb, ldc and optionally batch, sA, sB, sC, splitk
+    (0 = automatic), accumulate — all the same operand layout, independent of each other: ONE launch per 16 problems
+    (mi_gemm_f32_multi).  C of a split problem must be zero (or accumulate): the caller allocates them zero-filled."""
+    if not problems:
+        return
+    dev = _lib.require_gpu(*[q[k] for q in problems for k in ("A", "B", "C")])
+    lib, stream = _lib.load(), _lib.stream_ptr(dev)
+    for i in range(0, len(problems), MAX_GEMM_PROBLEMS):
+        chunk = problems[i:i + MAX_GEMM_PROBLEMS]
+        arr = (_GemmProblem * len(chunk))()
+        for d, q in zip(arr, chunk):
+            batch = q.get("batch", 1)
+            sk = q.get("splitk", 0) or auto_splitk(q["M"], q["N"], q["K"], batch)
+            d.A, d.B, d.C = q["A"].data_ptr(), q["B"].data_ptr(), q["C"].data_ptr()
+            d.M, d.N, d.K = q["M"], q["N"], q["K"]
+            d.lda, d.ldb, d.ldc, d.batch = q["lda"], q["ldb"], q["ldc"], batch
+            d.sA, d.sB, d.sC = q.get("sA", 0), q.get("sB", 0), q.get("sC", 0)
+            d.splitk, d.accumulate = sk, int(bool(q.get("accumulate", False)))
+        _lib.check(lib.mi_gemm_f32_multi(_ctypes.addressof(arr), len(chunk), int(transA), int(transB), stream),
+                   "mi_gemm_f32_multi")
 
 
 def _zero_strided(C, M, N, ldc, batch, sC):

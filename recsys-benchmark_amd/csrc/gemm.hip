@@ -215,24 +215,26 @@ __device__ __forceinline__ void mma_tile(floatx16 (&acc)[RB], float (*As)[LDSS],
 }
 
 // TA: A is [k][m] in memory; BT: B is staged transposed, i.e. B is [k][n] in memory (transB == 0)
+// One workgroup's tile of one problem.  (wx, wy, wz) is the workgroup's place in that problem's (gx, gy, .) grid — the
+// launch's own blockIdx for a single problem, a slice of the linear id for a multi-problem launch.
 template <int TA, int BT, int BMT>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+__device__ __forceinline__ void gemm_workgroup(GemmArgs a, const int wx, const int wy, const int wz, const int gx, const int gy) {
   constexpr int BM = BMT, RB = BMT / 64, WROWS = BMT / 2;   // rows per workgroup tile / 32-row blocks and rows per wave
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDSS];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDSS];
-  const int z = blockIdx.z / a.splitk;
-  const int slice = blockIdx.z % a.splitk;
+  const int z = wz / a.splitk;
+  const int slice = wz % a.splitk;
   // Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2: with the natural
   // order the 7 column tiles of one row tile land on 7 different XCDs and every L2 fetches that A tile again.  The
   // remap gives XCD x the contiguous range of tiles [x * total/8, ...): neighbours in (row tile, column tile) order
   // share an L2.
-  int bx = blockIdx.x, by = blockIdx.y;
+  int bx = wx, by = wy;
   if (a.xcd_swizzle) {
-    const int total = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+    const int total = gx * gy, id = by * gx + bx;
     const int x = id & 7, slot = id >> 3, chunk = total >> 3, rem = total & 7;
     const int logical = x * chunk + (x < rem ? x : rem) + slot;
-    bx = logical % gridDim.x;
-    by = logical / gridDim.x;
+    bx = logical % gx;
+    by = logical / gx;
   }
   const int m0 = by * BM, n0 = bx * BN;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   const float *B = a.B + z * a.sB;
   long long cslice = z;
   if (a.mtile_b) {                       // row-grouped: this tile's rows all multiply the same B slice
-    const int g = a.mtile_b[blockIdx.y];
+    const int g = a.mtile_b[wy];
     if (g < 0) return;
     B = a.B + (long long)g * a.sB;
   }
@@ -417,6 +419,53 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
   }
 }
 
+template <int TA, int BT, int BMT>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+  gemm_workgroup<TA, BT, BMT>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// Several INDEPENDENT problems of one operand layout in one launch (the weight gradients of a CrossNet backward: each
+// is a handful of 64x64 tiles with a 4096-long reduction — alone, none fills the chip even with split-K).  The launch is
+// one-dimensional; problem j owns the workgroup ids [end[j-1], end[j]).
+constexpr int kMaxProblems = 16;
+struct SlimProblem {      // what varies between the problems of one launch; the rest of GemmArgs is a plain product
+  const float *A, *B;
+  float *C;
+  int M, N, K, lda, ldb, ldc;
+  long long sA, sB, sC;
+  int splitk, epi, alignedA, alignedB, gx, gy, end, pad_;
+};
+struct MultiArgs {
+  int n;
+  SlimProblem p[kMaxProblems];
+};
+template <int TA, int BT>
+__global__ __launch_bounds__(256) void k_gemm_f32_multi(MultiArgs m) {
+  const int id = blockIdx.x;
+  int j = 0;
+  while (j + 1 < m.n && id >= m.p[j].end) ++j;
+  const SlimProblem q = m.p[j];
+  const int local = id - (j ? m.p[j - 1].end : 0);
+  const int per = q.gx * q.gy;
+  const int wz = local / per, rem = local - wz * per;
+  GemmArgs a;
+  a.A = q.A; a.B = q.B; a.C = q.C;
+  a.M = q.M; a.N = q.N; a.K = q.K;
+  a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
+  a.transA = TA; a.transB = !BT;
+  a.sA = q.sA; a.sB = q.sB; a.sC = q.sC;
+  a.kgroups = 1; a.gA = 0; a.gB = 0;
+  a.epi = q.epi; a.bias = nullptr;
+  a.R1 = a.R2 = nullptr; a.ldr1 = a.ldr2 = 0; a.sR1 = a.sR2 = 0;
+  a.rowscale = nullptr; a.nrs = 0;
+  a.C2 = nullptr; a.ldc2 = 0; a.sC2 = 0;
+  a.alignedA = q.alignedA; a.alignedB = q.alignedB;
+  a.splitk = q.splitk;
+  a.mtile_b = nullptr; a.kseg = nullptr;
+  a.xcd_swizzle = 0;
+  gemm_workgroup<TA, BT, 64>(a, rem % q.gx, rem / q.gx, wz, q.gx, q.gy);
+}
+
 }  // namespace
 
 extern "C" {
@@ -510,6 +559,53 @@ static void plain_args(GemmArgs &a, const float *A, const float *B, float *C, in
   a.C2 = nullptr; a.ldc2 = 0; a.sC2 = 0;
   a.mtile_b = nullptr; a.kseg = nullptr;
   a.xcd_swizzle = 0;
+}
+
+// n <= 16 independent problems C_j = opA(A_j) opB(B_j) (+ C_j when accumulate), all with the same transposes, in ONE launch.
+// split-K slices meet in float atomics: a problem with splitk > 1 needs its C zeroed by the caller (or accumulate).
+int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream) {
+  if (n < 0 || n > kMaxProblems) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!probs) return MI_ERR_INVALID_ARG;
+  MultiArgs m;
+  m.n = 0;
+  long long wgs = 0;
+  for (int j = 0; j < n; ++j) {
+    const mi_gemm_problem &q = probs[j];
+    if (q.M < 0 || q.N < 0 || q.K < 0 || q.batch < 0 || q.splitk < 1) return MI_ERR_INVALID_ARG;
+    if (q.M == 0 || q.N == 0 || q.batch == 0) continue;
+    if (!q.A || !q.B || !q.C) return MI_ERR_INVALID_ARG;
+    SlimProblem &a = m.p[m.n];
+    a.A = q.A; a.B = q.B; a.C = q.C;
+    a.M = q.M; a.N = q.N; a.K = q.K;
+    a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
+    a.sA = q.sA; a.sB = q.sB; a.sC = q.sC;
+    a.splitk = q.splitk;
+    a.epi = q.accumulate ? EPI_ACCUM : EPI_NONE;
+    a.alignedA = aligned16(q.A) && (q.lda % 4 == 0) && (q.sA % 4 == 0);
+    a.alignedB = aligned16(q.B) && (q.ldb % 4 == 0) && (q.sB % 4 == 0);
+    a.gx = (q.N + BN - 1) / BN;
+    a.gy = (q.M + 63) / 64;
+    a.pad_ = 0;
+    wgs += (long long)a.gx * a.gy * q.batch * q.splitk;
+    if (wgs > 0x7fffffffLL) return MI_ERR_UNSUPPORTED;
+    a.end = (int)wgs;
+    ++m.n;
+  }
+  if (m.n == 0) return MI_OK;
+  for (int j = m.n; j < kMaxProblems; ++j) m.p[j] = m.p[m.n - 1];
+  hipEvent_t ea, eb;
+  const bool prof = mi::prof_acquire("gemm_f32_multi", &ea, &eb);
+  const dim3 grid((unsigned)wgs);
+#define GO(TA, BT)                                                                                            \
+  do {                                                                                                        \
+    if (prof) hipExtLaunchKernelGGL((k_gemm_f32_multi<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, m); \
+    else hipLaunchKernelGGL((k_gemm_f32_multi<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, m);            \
+  } while (0)
+  if (transA) { if (transB) GO(1, 0); else GO(1, 1); }
+  else { if (transB) GO(0, 0); else GO(0, 1); }
+#undef GO
+  return launch_status();
 }
 
 int mi_gemm_f32_row_groups(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K,

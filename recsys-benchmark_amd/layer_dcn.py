@@ -58,19 +58,23 @@ class _DCNHeadFn(torch.autograd.Function):
         x0 = xs[0]
         dx0 = _new((M, d), dev)
         grads = [None] * (2 * L)
+        # every weight / bias gradient of the head in ONE zero-filled buffer: the L weight-gradient products (each only
+        # (d/64)^2 tiles with an M-long reduction) wait until the chain is done and go out as one launch (gemm_multi)
+        flat = torch.zeros((L * (d * d + d),), dtype=torch.float32, device=dev)
+        dWs, dbs = flat[:L * d * d].view(L, d, d), flat[L * d * d:].view(L, d)
+        later = []
         for l in range(L - 1, -1, -1):
             dlin = _new((M, d), dev)
             _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), lins[l].data_ptr(), dlin.data_ptr(),
                                             dx0.data_ptr(), M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
-            db = torch.zeros((d,), dtype=torch.float32, device=dev)
-            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, db.data_ptr(), None, M, d, s), "mi_colsum")
-            dW = _new((d, d), dev)
-            gemm(dlin, xs[l], dW, d, d, M, d, d, d, transA=True)                 # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
+            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, dbs[l].data_ptr(), None, M, d, s), "mi_colsum")
+            later.append(dict(A=dlin, B=xs[l], C=dWs[l], M=d, N=d, K=M, lda=d, ldb=d, ldc=d))   # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
             gn = _new((M, d), dev)
             gemm(dlin, Ws[l], gn, M, d, d, d, d, d, epi="add", R1=g, ldr1=d,     # dx_l = g + dlin W  (+ dx0 at l=0)
                  R2=dx0 if l == 0 else None, ldr2=d)
-            grads[2 * l], grads[2 * l + 1] = dW, db
+            grads[2 * l], grads[2 * l + 1] = dWs[l], dbs[l]
             g = gn
+        _kernels.gemm_multi(later, transA=True)
         return (g, *grads)
 
 
@@ -137,39 +141,55 @@ class _DCNMixFn(torch.autograd.Function):
         s = _lib.stream_ptr(dev)
         x0 = xs[0]
         dx0 = _new((M, d), dev)
-        dG = torch.zeros((E, d), dtype=torch.float32, device=dev)
         grads = [None] * (4 * L)
+        # All parameter gradients of the head live in ONE zero-filled buffer, and the 4L weight-gradient products (dU, dC,
+        # dV and the gate's share per layer: a few 64x64 tiles each, reduction length M) are collected while the chain
+        # runs and go out as ONE launch at the end (gemm_multi) instead of 4L launches + their zero fills.
+        per = Er * d + E * r * r + E * d * r + d + E * d
+        flat = torch.zeros((L * per,), dtype=torch.float32, device=dev)
+
+        def part(l, off, shape):
+            n = 1
+            for k in shape:
+                n *= k
+            return flat[l * per + off: l * per + off + n].view(shape)
+
+        later = []
+        dGs = [part(l, Er * d + E * r * r + E * d * r + d, (E, d)) for l in range(L)]
         for l in range(L - 1, -1, -1):
             gate, H1, H2, H2g, T = sv[5 * l: 5 * l + 5]
             xl = xs[l]
             dT = _new((M, d), dev)
             _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), T.data_ptr(), dT.data_ptr(), dx0.data_ptr(),
                                             M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
-            db = torch.zeros((1, d), dtype=torch.float32, device=dev)
+            dU, dC, dV = part(l, 0, (E, r, d)), part(l, Er * d, (E, r, r)), part(l, Er * d + E * r * r, (E, d, r))
+            db = part(l, Er * d + E * r * r + E * d * r, (1, d))
             _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), None, M, d, s), "mi_colsum")
             dgsum = _new((M,), dev)
             _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), None, None, dgsum.data_ptr(), M, d, s), "mi_rowdot")
             dH2g = _new((M, Er), dev)
             gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)                             # dT U^T
-            dU = _new((E, r, d), dev)
-            gemm(H2g, dT, dU, Er, d, M, Er, d, d, transA=True)                                 # H2g^T dT
+            later.append(dict(A=H2g, B=dT, C=dU, M=Er, N=d, K=M, lda=Er, ldb=d, ldc=d))          # dU = H2g^T dT
             dgate, dZ2 = _new((M, E), dev), _new((M, Er), dev)
             _lib.check(lib.mi_mix_gate_bwd(dH2g.data_ptr(), H2.data_ptr(), gate.data_ptr(), dgsum.data_ptr(),
                                            dgate.data_ptr(), dZ2.data_ptr(), M, E, r, s), "mi_mix_gate_bwd")
-            dC = _new((E, r, r), dev)
-            gemm(H1, dZ2, dC, r, r, M, Er, Er, r, transA=True, batch=E, sA=r, sB=r, sC=r * r)   # H1_e^T dZ2_e
+            later.append(dict(A=H1, B=dZ2, C=dC, M=r, N=r, K=M, lda=Er, ldb=Er, ldc=r, batch=E, sA=r, sB=r,
+                              sC=r * r))                                                       # dC_e = H1_e^T dZ2_e
             dZ1 = _new((M, Er), dev)
             gemm(dZ2, Cs[l], dZ1, M, r, r, Er, r, Er, transB=True, batch=E, sA=r, sB=r * r, sC=r,
                  epi="mul_dtanh", R1=H1, ldr1=Er, sR1=r)                                       # (dZ2_e C_e^T) * tanh'
-            dV = _new((E, d, r), dev)
-            gemm(xl, dZ1, dV, d, r, M, d, Er, r, transA=True, batch=E, sB=r, sC=d * r)          # x_l^T dZ1_e
+            later.append(dict(A=xl, B=dZ1, C=dV, M=d, N=r, K=M, lda=d, ldb=Er, ldc=r, batch=E, sB=r,
+                              sC=d * r))                                                       # dV_e = x_l^T dZ1_e
             gn = _new((M, d), dev)
             gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,      # g + sum_e dZ1_e V_e^T
                  epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d)
             gemm(dgate, G, gn, M, d, E, E, d, d, epi="accum")                                   # + dgate G
-            gemm(dgate, xl, dG, E, d, M, E, d, d, transA=True, epi="accum")                     # dG += dgate^T x_l
+            later.append(dict(A=dgate, B=xl, C=dGs[l], M=E, N=d, K=M, lda=E, ldb=d, ldc=d))     # layer l's share of dG
             grads[4 * l: 4 * l + 4] = [dU, dC, dV, db]
             g = gn
+        _kernels.gemm_multi(later, transA=True)
+        # the layers' shares, summed in a fixed order (one strided view of the flat buffer: a single reduction launch)
+        dG = torch.as_strided(flat, (L, E, d), (per, d, 1), Er * d + E * r * r + E * d * r + d).sum(0)
         return (g, dG.view(E, d, 1), *grads)
 
 

@@ -80,3 +80,56 @@ def test_batched_column_slices_kgroups_and_gate():
     out = torch.empty(M, d_, device=DEV)
     _kernels.gemm(H1, dv(V), out, M, d_, r, E * r, r, d_, transB=True, kgroups=E, gA=r, gB=d_ * r)
     assert_close(out, sum(ref[:, e * r:(e + 1) * r] @ V[e].t() for e in range(E)), 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("tA,tB", [(True, False), (False, True), (False, False), (True, True)])
+def test_multi_problem_launch_equals_one_launch_per_problem(tA, tB):
+    """mi_gemm_f32_multi: independent problems of one operand layout in one launch — mixed sizes (ragged tiles, a single
+    row), batched column slices, split-K into zero-filled views of ONE flat buffer, accumulate; integer-valued data, so
+    every result is exact whatever the split; 19 problems = two launches."""
+    gen = torch.Generator().manual_seed(11 + 2 * tA + tB)
+    shapes = [(256, 352, 4096), (64, 64, 4096), (352, 64, 1024), (4, 352, 4096), (100, 70, 45), (33, 5, 7), (1, 130, 300)]
+    shapes = shapes + shapes[:6] + shapes[1:7]
+    probs, refs = [], []
+    total = sum(M * N for M, N, _ in shapes) + 2 * 3 * 64 * 48
+    flat = torch.zeros(total, device=DEV)
+    off = 0
+    for i, (M, N, K) in enumerate(shapes):
+        A = _mk((K, M) if tA else (M, K), gen)
+        B = _mk((N, K) if tB else (K, N), gen)
+        C = flat[off:off + M * N].view(M, N)
+        off += M * N
+        ref = (A.t() if tA else A) @ (B.t() if tB else B)
+        acc = i % 5 == 4
+        if acc:
+            C.copy_(_mk((M, N), gen))
+            ref = ref + C.cpu()
+        probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N,
+                          accumulate=acc, splitk=0 if i % 3 else 1))
+        refs.append(ref)
+    # batched: 3 slices of wide operands (weight-gradient form only: column slices of [K, 3*64] and [K, 3*48])
+    if tA and not tB:
+        for _ in range(2):
+            A, B = _mk((512, 3 * 64), gen), _mk((512, 3 * 48), gen)
+            C = flat[off:off + 3 * 64 * 48].view(3, 64, 48)
+            off += 3 * 64 * 48
+            probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=64, N=48, K=512, lda=192, ldb=144, ldc=48, batch=3, sA=64,
+                              sB=48, sC=64 * 48))
+            refs.append(torch.stack([A[:, 64 * e:64 * e + 64].t() @ B[:, 48 * e:48 * e + 48] for e in range(3)]))
+    _kernels.gemm_multi(probs, transA=tA, transB=tB)
+    for q, ref in zip(probs, refs):
+        assert torch.equal(q["C"].cpu(), ref), (q["M"], q["N"], q["K"])
+    assert torch.equal(flat[off:], torch.zeros_like(flat[off:])), "nothing written past the last problem"
+
+
+def test_multi_problem_launch_argument_checks():
+    from recsys_benchmark_amd import _lib
+
+    z = torch.zeros(64, 64, device=DEV)
+    ok = dict(A=z, B=z, C=z.clone(), M=64, N=64, K=64, lda=64, ldb=64, ldc=64)
+    _kernels.gemm_multi([], transA=True)                                # nothing to do
+    _kernels.gemm_multi([dict(ok, M=0)], transA=True)                   # empty problem: skipped
+    with pytest.raises(_lib.MI355XLibraryError):
+        _kernels.gemm_multi([dict(ok, K=-1)], transA=True)
+    with pytest.raises(_lib.MI355XLibraryError):
+        _kernels.gemm_multi([dict(ok, splitk=-2)], transA=True)
