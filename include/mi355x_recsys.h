@@ -313,7 +313,8 @@ MI_API int mi_gemm_f32_k_groups(const float *A, const float *B, float *C, int32_
  *      3 lin=acc+bias[n]*rs(m); C=R1+R2*lin; C2(opt)=lin   rs(m)=sum_{e<nrs} rowscale[m*nrs+e] (1 if null)
  *        -> DCNHead `x_l + x_0*(W x_l + b)` (src/models/layer_dcn.py:137-139) and the DCN_MixHead
  *           output `x_l + x_0 * sum_e g_e (U_e h_e + b)` (:102-113) with K = E*rank
- *      4 C=R1+acc(+R2) | 5 C=acc*(1-R1^2) (tanh') | 6 h=tanh(acc); C=h; C2=h*rowscale[m*nrs+z] | 7 C+=acc
+ *      4 C=R1+acc(+R2)(+sum_{e<nrs} rowscale[m*nrs+e]*bias[e*N+n] when rowscale and bias are given: the gate's share
+ *        dgate.G of dx_l, layer_dcn.py:100-113 differentiated) | 5 C=acc*(1-R1^2) (tanh') | 6 h=tanh(acc); C=h; C2=h*rowscale[m*nrs+z] | 7 C+=acc
  * splitk > 1 (epi 0 or 7 only; for epi 0 the caller zeroes C): the K loop is cut into `splitk` slices
  * on separate workgroups that add into C with float atomics — for the weight-gradient products
  * whose M x N is a handful of tiles while K is the batch (dW = dlin^T x_l, K = 4096).
@@ -370,6 +371,16 @@ MI_API int mi_outer(const float *g, const float *w, float *out, int32_t M, int32
 MI_API int mi_mix_gate_bwd(const float *dH2g, const float *H2, const float *gate,
                            const float *dgsum, float *dgate, float *dZ2, int32_t M, int32_t E,
                            int32_t r, void *stream);
+/*   mi_rowdot_multi:  out[m,e] = sum_n X[m,n]*W[e,n], e < E <= 8 — the DCN_MixHead gate g_e = x_l . G_e
+ *                     (layer_dcn.py:100-103) as one pass over the row (N % 4 == 0, 16-B aligned; else MI_ERR_UNSUPPORTED).
+ *   mi_cross_bwd_head: mi_cross_bwd_pre + the bias gradient db[n] += sum_m dlin[m,n]*rs(m) (rs = sum_e gate[m,e], 1 when
+ *                     gate is NULL; db caller-zeroed) + dgs[m] = sum_n dlin[m,n]*b[n] (nullable) in ONE pass over the rows
+ *                     (N % 4 == 0, N <= 1024, 16-B aligned; else MI_ERR_UNSUPPORTED and the caller uses the three calls). */
+MI_API int mi_rowdot_multi(const float *X, int32_t ldx, const float *W, float *out, int32_t M,
+                           int32_t N, int32_t E, void *stream);
+MI_API int mi_cross_bwd_head(const float *g, const float *x0, const float *lin, const float *gate,
+                             int32_t E, const float *b, float *dlin, float *dx0, int32_t accumulate,
+                             float *db, float *dgs, int32_t M, int32_t N, void *stream);
 
 /* ---- a5 (memory-bound part): BatchNorm1d + ReLU + Dropout around the MLP's Linears ---------
  * src/models/deepfm.py:53-66 / src/models/dcn.py:56-66.  Z fp32[M,N] (row stride ldz) is a Linear's

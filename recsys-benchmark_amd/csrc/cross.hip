@@ -79,6 +79,109 @@ __global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ X, 
   }
 }
 
+// out[m,e] = sum_n X[m,n] * W[e,n], e < E <= 8: the DCN_MixHead gate (g_e = x_l . G_e) — E dot products per row in one pass
+// over the row instead of a GEMM launch with a 4-column output.  One wave per row, float4 columns.
+template <int E>
+__global__ __launch_bounds__(kBlock) void k_rowdot_multi(const float *__restrict__ X, int ldx, const float *__restrict__ W,
+                                                         float *__restrict__ out, int M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int m = wave0; m < M; m += nwaves) {
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    for (int n = lane * 4; n < N; n += kWave * 4) {
+      const float4 x = ld4(X + (int64_t)m * ldx + n);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += dot4(x, ld4(W + (int64_t)e * N + n));
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = wave_sum(s[e]);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) out[(int64_t)m * E + e] = s[e];
+    }
+  }
+}
+
+// The head of a CrossNet layer's backward in ONE pass over the row (x_{l+1} = x_l + x_0 * lin, lin = ... + b * rs):
+//   dlin[m,:] = g[m,:] * x0[m,:]            dx0[m,:] (+)= g[m,:] * lin[m,:]
+//   db[n]    += sum_m dlin[m,n] * rs(m)     rs(m) = sum_e gate[m,e]  (1 without a gate: DCNHead)
+//   dgs[m]    = sum_n dlin[m,n] * b[n]      (DCN_MixHead only: the bias' share of the gate gradient)
+// One wave per row, NJ float4 column groups per lane (N <= 1024 * NJ / 4 ... see the launcher); the column sums stay in
+// registers over the wave's rows, meet in LDS and leave as one float atomic per column and workgroup.
+template <int NJ>
+__global__ __launch_bounds__(kBlock) void k_cross_bwd_head(const float *__restrict__ g, const float *__restrict__ x0,
+                                                           const float *__restrict__ lin, const float *__restrict__ gate,
+                                                           int E, const float *__restrict__ b, float *__restrict__ dlin,
+                                                           float *__restrict__ dx0, int accumulate, float *__restrict__ db,
+                                                           float *__restrict__ dgs, int M, int N) {
+  __shared__ float4 part[kWavesPerBlock][NJ * kWave];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave0 = blockIdx.x * kWavesPerBlock + w;
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 col[NJ], bv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    col[j] = zero;
+    const int n = (j * kWave + lane) * 4;
+    bv[j] = (b && n < N) ? ld4(b + n) : zero;
+  }
+  constexpr int R = 2;                       // rows in flight per wave: 2 x NJ x (3..4) float4 loads before the first use
+  for (int m0 = wave0; m0 < M; m0 += R * nwaves) {
+    float4 gv[R][NJ], xv[R][NJ], lv[R][NJ], dv[R][NJ];
+    float gt[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int m = m0 + u * nwaves;
+      const int64_t row = (int64_t)(m < M ? m : m0) * N;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = (j * kWave + lane) * 4;
+        const int64_t o = row + (n < N ? n : 0);
+        gv[u][j] = ld4(g + o); xv[u][j] = ld4(x0 + o); lv[u][j] = ld4(lin + o);
+        dv[u][j] = accumulate ? ld4(dx0 + o) : zero;
+      }
+      gt[u] = (gate && lane < E) ? gate[(int64_t)(m < M ? m : m0) * E + lane] : 0.f;   // lane e holds gate[m,e]
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int m = m0 + u * nwaves;
+      if (m >= M) continue;                  // wave-uniform
+      const float rs = gate ? wave_sum(gt[u]) : 1.f;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = (j * kWave + lane) * 4;
+        if (n >= N) continue;
+        const int64_t o = (int64_t)m * N + n;
+        const float4 gg = gv[u][j], xx = xv[u][j], ll = lv[u][j], dd = dv[u][j];
+        const float4 d = make_float4(gg.x * xx.x, gg.y * xx.y, gg.z * xx.z, gg.w * xx.w);
+        st4(dlin + o, d);
+        st4(dx0 + o, make_float4(dd.x + gg.x * ll.x, dd.y + gg.y * ll.y, dd.z + gg.z * ll.z, dd.w + gg.w * ll.w));
+        col[j].x += d.x * rs; col[j].y += d.y * rs; col[j].z += d.z * rs; col[j].w += d.w * rs;
+        s += dot4(d, bv[j]);
+      }
+      if (dgs) {
+        s = wave_sum(s);
+        if (lane == 0) dgs[m] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) part[w][j * kWave + lane] = col[j];
+  __syncthreads();
+  const float *q = reinterpret_cast<const float *>(&part[0][0]);
+  for (int n = threadIdx.x; n < N; n += kBlock) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < kWavesPerBlock; ++u) t += q[u * NJ * kWave * 4 + n];
+    atomicAdd(db + n, t);
+  }
+}
+
 // out[m,n] = g[m] * w[n]   (backward of a 1-output Linear w.r.t. its input)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_outer(const float *__restrict__ g, const float *__restrict__ w,
@@ -200,6 +303,39 @@ int mi_rowdot(const float *X, int32_t ldx, const float *v, const float *bias, co
   if (M == 0) return MI_OK;
   if (!X || !v || !out) return MI_ERR_INVALID_ARG;
   MI_LAUNCH("rowdot", k_rowdot, grid_for_waves(M), kBlock, stream, X, ldx, v, bias, addend, out, M, N);
+  return launch_status();
+}
+
+int mi_rowdot_multi(const float *X, int32_t ldx, const float *W, float *out, int32_t M, int32_t N, int32_t E, void *stream) {
+  if (M < 0 || N < 0 || E < 1 || E > 8) return MI_ERR_INVALID_ARG;
+  if (M == 0) return MI_OK;
+  if (!X || !W || !out) return MI_ERR_INVALID_ARG;
+  if (N % 4 != 0 || ldx % 4 != 0 || !aligned16(X) || !aligned16(W)) return MI_ERR_UNSUPPORTED;
+#define MI_RDM(EE) case EE: MI_LAUNCH("rowdot_multi", k_rowdot_multi<EE>, grid_for_waves(M), kBlock, stream, X, ldx, W, out, M, N); break
+  switch (E) { MI_RDM(1); MI_RDM(2); MI_RDM(3); MI_RDM(4); MI_RDM(5); MI_RDM(6); MI_RDM(7); MI_RDM(8); }
+#undef MI_RDM
+  return launch_status();
+}
+
+int mi_cross_bwd_head(const float *g, const float *x0, const float *lin, const float *gate, int32_t E, const float *b,
+                      float *dlin, float *dx0, int32_t accumulate, float *db, float *dgs, int32_t M, int32_t N,
+                      void *stream) {
+  if (M < 0 || N < 0 || (gate && (E < 1 || E > kWave))) return MI_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MI_OK;
+  if (!g || !x0 || !lin || !dlin || !dx0 || !db || (dgs && !b)) return MI_ERR_INVALID_ARG;
+  if (N % 4 != 0 || N > 1024 || !aligned16(g) || !aligned16(x0) || !aligned16(lin) || !aligned16(dlin) || !aligned16(dx0) ||
+      (b && !aligned16(b)))
+    return MI_ERR_UNSUPPORTED;
+  int grid = (M + 15) / 16;                 // ~4 rows per wave, two in flight: the column partials amortise over them
+  if (grid > 512) grid = 512;
+  if (grid < 1) grid = 1;
+  const int nj = (N / 4 + kWave - 1) / kWave;
+#define MI_CBH(J) MI_LAUNCH("cross_bwd_head", k_cross_bwd_head<J>, grid, kBlock, stream, g, x0, lin, gate, E, b, dlin, dx0, accumulate, db, dgs, M, N)
+  if (nj <= 1) MI_CBH(1);
+  else if (nj == 2) MI_CBH(2);
+  else if (nj == 3) MI_CBH(3);
+  else MI_CBH(4);
+#undef MI_CBH
   return launch_status();
 }
 

@@ -24,7 +24,7 @@ enum {
   EPI_BIAS = 1,       // C = acc + bias[n]
   EPI_TANH = 2,       // C = tanh(acc)
   EPI_CROSS = 3,      // lin = acc + bias[n]*rs(m); C = R1 + R2*lin; C2 (opt) = lin     rs(m) = sum_e rowscale[m*nrs+e] or 1
-  EPI_ADD = 4,        // C = R1 + acc (+ R2 when given)
+  EPI_ADD = 4,        // C = R1 + acc (+ R2 when given) (+ sum_e rowscale[m*nrs+e] * bias[e*N+n] when both given)
   EPI_MUL_DTANH = 5,  // C = acc * (1 - R1^2)
   EPI_TANH_GATE = 6,  // h = tanh(acc); C = h; C2 = h * rowscale[m*nrs + z]
   EPI_ACCUM = 7,      // C = C + acc
@@ -400,9 +400,13 @@ __device__ __forceinline__ void gemm_workgroup(GemmArgs a, const int wx, const i
         if (C2) C2[(long long)m * a.ldc2 + n] = lin;
         break;
       }
-      case EPI_ADD:
-        C[co] = R1[(long long)m * a.ldr1 + n] + v + (R2 ? R2[(long long)m * a.ldr2 + n] : 0.f);
+      case EPI_ADD: {
+        float t = R1[(long long)m * a.ldr1 + n] + v + (R2 ? R2[(long long)m * a.ldr2 + n] : 0.f);
+        if (a.rowscale && a.bias)   // + a rank-nrs term: sum_e rowscale[m,e] * bias[e,n]  (the gate's share of dx_l)
+          for (int e = 0; e < a.nrs; ++e) t += a.rowscale[(long long)m * a.nrs + e] * a.bias[(long long)e * a.N + n];
+        C[co] = t;
         break;
+      }
       case EPI_MUL_DTANH: {
         const float h = R1[(long long)m * a.ldr1 + n];
         C[co] = v * (1.f - h * h);

@@ -23,6 +23,24 @@ def _new(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+def _bwd_head(g, x0, lin, gate, E, b, dlin, dx0, accumulate, db, dgs, M, d, s):
+    """dlin = g*x0, dx0 (+)= g*lin, db += sum_m dlin*rs(m), dgs[m] = dlin[m,:].b in one launch (mi_cross_bwd_head);
+    shapes it does not cover (d % 4, d > 1024) take the three separate passes."""
+    lib = _lib.load()
+    ok = d % 4 == 0 and d <= 1024
+    if ok:
+        _lib.check(lib.mi_cross_bwd_head(g.data_ptr(), x0.data_ptr(), lin.data_ptr(), _lib.ptr(gate), E, _lib.ptr(b),
+                                         dlin.data_ptr(), dx0.data_ptr(), int(accumulate), db.data_ptr(), _lib.ptr(dgs), M, d, s),
+                   "mi_cross_bwd_head")
+        return
+    _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), lin.data_ptr(), dlin.data_ptr(), dx0.data_ptr(), M * d,
+                                    int(accumulate), s), "mi_cross_bwd_pre")
+    _lib.check(lib.mi_colsum(dlin.data_ptr(), d, _lib.ptr(gate), E if gate is not None else 0, db.data_ptr(), None, M, d, s),
+               "mi_colsum")
+    if dgs is not None:
+        _lib.check(lib.mi_rowdot(dlin.data_ptr(), d, b.data_ptr(), None, None, dgs.data_ptr(), M, d, s), "mi_rowdot")
+
+
 class _DCNHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, *wb):
@@ -65,9 +83,7 @@ class _DCNHeadFn(torch.autograd.Function):
         later = []
         for l in range(L - 1, -1, -1):
             dlin = _new((M, d), dev)
-            _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), lins[l].data_ptr(), dlin.data_ptr(),
-                                            dx0.data_ptr(), M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
-            _lib.check(lib.mi_colsum(dlin.data_ptr(), d, None, 0, dbs[l].data_ptr(), None, M, d, s), "mi_colsum")
+            _bwd_head(g, x0, lins[l], None, 0, None, dlin, dx0, l != L - 1, dbs[l], None, M, d, s)
             later.append(dict(A=dlin, B=xs[l], C=dWs[l], M=d, N=d, K=M, lda=d, ldb=d, ldc=d))   # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
             gn = _new((M, d), dev)
             gemm(dlin, Ws[l], gn, M, d, d, d, d, d, epi="add", R1=g, ldr1=d,     # dx_l = g + dlin W  (+ dx0 at l=0)
@@ -111,7 +127,11 @@ class _DCNMixFn(torch.autograd.Function):
         for l in range(L):
             xl = xs[-1]
             gate = _new((M, E), dev)
-            gemm(xl, G, gate, M, E, d, d, d, E, transB=True)                                   # g_e = x_l . G_e
+            if d % 4 == 0 and E <= 8:                                                          # g_e = x_l . G_e
+                _lib.check(_lib.load().mi_rowdot_multi(xl.data_ptr(), d, G.data_ptr(), gate.data_ptr(), M, d, E,
+                                                       _lib.stream_ptr(dev)), "mi_rowdot_multi")
+            else:
+                gemm(xl, G, gate, M, E, d, d, d, E, transB=True)
             H1, H2, H2g = _new((M, Er), dev), _new((M, Er), dev), _new((M, Er), dev)
             gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")        # tanh(x_l V_e)
             gemm(H1, Cs[l], H2, M, r, r, Er, r, Er, batch=E, sA=r, sB=r * r, sC=r, epi="tanh_gate",
@@ -160,13 +180,10 @@ class _DCNMixFn(torch.autograd.Function):
             gate, H1, H2, H2g, T = sv[5 * l: 5 * l + 5]
             xl = xs[l]
             dT = _new((M, d), dev)
-            _lib.check(lib.mi_cross_bwd_pre(g.data_ptr(), x0.data_ptr(), T.data_ptr(), dT.data_ptr(), dx0.data_ptr(),
-                                            M * d, int(l != L - 1), s), "mi_cross_bwd_pre")
             dU, dC, dV = part(l, 0, (E, r, d)), part(l, Er * d, (E, r, r)), part(l, Er * d + E * r * r, (E, d, r))
             db = part(l, Er * d + E * r * r + E * d * r, (1, d))
-            _lib.check(lib.mi_colsum(dT.data_ptr(), d, gate.data_ptr(), E, db.data_ptr(), None, M, d, s), "mi_colsum")
             dgsum = _new((M,), dev)
-            _lib.check(lib.mi_rowdot(dT.data_ptr(), d, bs[l].data_ptr(), None, None, dgsum.data_ptr(), M, d, s), "mi_rowdot")
+            _bwd_head(g, x0, T, gate, E, bs[l], dT, dx0, l != L - 1, db, dgsum, M, d, s)
             dH2g = _new((M, Er), dev)
             gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)                             # dT U^T
             later.append(dict(A=H2g, B=dT, C=dU, M=Er, N=d, K=M, lda=Er, ldb=d, ldc=d))          # dU = H2g^T dT
@@ -182,8 +199,8 @@ class _DCNMixFn(torch.autograd.Function):
                               sC=d * r))                                                       # dV_e = x_l^T dZ1_e
             gn = _new((M, d), dev)
             gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,      # g + sum_e dZ1_e V_e^T
-                 epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d)
-            gemm(dgate, G, gn, M, d, E, E, d, d, epi="accum")                                   # + dgate G
+                 epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d,
+                 rowscale=dgate, nrs=E, bias=G)                                                 # + dgate G in the epilogue
             later.append(dict(A=dgate, B=xl, C=dGs[l], M=E, N=d, K=M, lda=E, ldb=d, ldc=d))     # layer l's share of dG
             grads[4 * l: 4 * l + 4] = [dU, dC, dV, db]
             g = gn

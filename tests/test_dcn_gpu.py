@@ -117,3 +117,50 @@ def test_dcn_models_match_reference_golden(name):
     for k, ref in g.group("grad/").items():
         assert_close(named[k].grad, ref, 5e-4, 2e-5, k)
     pkg.check_index_errors()
+
+
+@pytest.mark.parametrize("M,N,E", [(4096, 352, 4), (37, 8, 1), (130, 416, 8), (5, 1024, 3)])
+def test_rowdot_multi_is_the_gate_product(M, N, E):
+    import ctypes  # noqa: F401
+
+    from recsys_benchmark_amd import _lib
+
+    gen = torch.Generator().manual_seed(M + N + E)
+    X, W = torch.randint(-3, 4, (M, N), generator=gen).float(), torch.randint(-3, 4, (E, N), generator=gen).float()
+    out = torch.empty(M, E, device=DEV)
+    Xd, Wd = X.to(DEV), W.to(DEV)
+    _lib.check(_lib.load().mi_rowdot_multi(Xd.data_ptr(), N, Wd.data_ptr(), out.data_ptr(), M, N, E,
+                                           _lib.stream_ptr(out.device)), "mi_rowdot_multi")
+    assert torch.equal(out.cpu(), X @ W.t())          # integer-valued: exact
+    with pytest.raises(_lib.MI355XLibraryError):      # N % 4 != 0 is outside the kernel: the caller takes the GEMM
+        _lib.check(_lib.load().mi_rowdot_multi(Xd.data_ptr(), N, Wd.data_ptr(), out.data_ptr(), M, N - 1, E,
+                                               _lib.stream_ptr(out.device)), "mi_rowdot_multi")
+
+
+@pytest.mark.parametrize("M,N", [(4096, 352), (4096, 416), (33, 8), (257, 260), (70, 1024), (1, 4)])
+@pytest.mark.parametrize("mix", [True, False])
+def test_cross_bwd_head_equals_its_three_passes(M, N, mix):
+    """mi_cross_bwd_head (one pass over the rows) against dlin = g*x0, dx0 (+)= g*lin, db = sum_m dlin*rs, dgs = dlin.b
+    written out in torch; integer-valued data, so also the float-atomic column sums are exact."""
+    from recsys_benchmark_amd import _lib
+
+    gen = torch.Generator().manual_seed(M * 3 + N + mix)
+    mk = lambda *s: torch.randint(-3, 4, s, generator=gen).float()          # noqa: E731
+    g, x0, lin, b, gate, dx_prev = mk(M, N), mk(M, N), mk(M, N), mk(N), mk(M, 4), mk(M, N)
+    lib = _lib.load()
+    for accumulate in (0, 1):
+        d = lambda t: t.to(DEV)                                             # noqa: E731
+        dlin, dx0 = torch.empty(M, N, device=DEV), d(dx_prev).clone()
+        db, dgs = torch.zeros(N, device=DEV), torch.empty(M, device=DEV)
+        gd, xd, ld, bd, gtd = d(g), d(x0), d(lin), d(b), d(gate)
+        _lib.check(lib.mi_cross_bwd_head(gd.data_ptr(), xd.data_ptr(), ld.data_ptr(), gtd.data_ptr() if mix else None, 4,
+                                         bd.data_ptr() if mix else None, dlin.data_ptr(), dx0.data_ptr(), accumulate,
+                                         db.data_ptr(), dgs.data_ptr() if mix else None, M, N, _lib.stream_ptr(dlin.device)),
+                   "mi_cross_bwd_head")
+        ref_dlin = g * x0
+        rs = gate.sum(1, keepdim=True) if mix else torch.ones(M, 1)
+        assert torch.equal(dlin.cpu(), ref_dlin)
+        assert torch.equal(dx0.cpu(), (dx_prev if accumulate else 0) + g * lin)
+        assert torch.equal(db.cpu(), (ref_dlin * rs).sum(0))
+        if mix:
+            assert torch.equal(dgs.cpu(), ref_dlin @ b)

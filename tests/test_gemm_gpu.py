@@ -133,3 +133,20 @@ def test_multi_problem_launch_argument_checks():
         _kernels.gemm_multi([dict(ok, K=-1)], transA=True)
     with pytest.raises(_lib.MI355XLibraryError):
         _kernels.gemm_multi([dict(ok, splitk=-2)], transA=True)
+
+
+def test_add_epilogue_with_rank_term():
+    """epi 'add' + (rowscale, bias): C = R1 + A.B (+ R2) + rowscale[M,E] . bias[E,N] — the gate's share of a DCN-Mix
+    layer's input gradient folded into the product that precedes it."""
+    gen = torch.Generator().manual_seed(21)
+    for M, N, K, E in [(200, 96, 80, 4), (4096, 352, 64, 4), (70, 20, 33, 1), (65, 130, 40, 8)]:
+        A, W = _mk((M, K), gen), _mk((N, K), gen)
+        R1, R2 = _mk((M, N), gen), _mk((M, N), gen)
+        rs, G = _mk((M, E), gen), _mk((E, N), gen)
+        d = lambda t: t.to(DEV)                                                    # noqa: E731
+        C = torch.empty(M, N, device=DEV)
+        kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, transB=True)
+        _kernels.gemm(d(A), d(W), C, epi="add", R1=d(R1), ldr1=N, R2=d(R2), ldr2=N, rowscale=d(rs), nrs=E, bias=d(G), **kw)
+        assert torch.equal(C.cpu(), R1 + A @ W.t() + R2 + rs @ G)
+        _kernels.gemm(d(A), d(W), C, epi="add", R1=d(R1), ldr1=N, rowscale=d(rs), nrs=E, bias=d(G), **kw)
+        assert torch.equal(C.cpu(), R1 + A @ W.t() + rs @ G)
