@@ -343,13 +343,14 @@ def bench_c3(args, real_stdout):
     kernels = kernel_table(kt)
     flops_step = 3.0 * nl * (E * (2 * d * r + 2 * r * r + 2 * r * d) + 2 * E * d) * B
     g = kernels.get("gemm_f32")
-    gm = kernels.get("gemm_f32_multi")       # the head's weight gradients: one multi-problem launch per backward
+    # + the head's weight gradients (one multi-problem launch per backward) and its four large products per layer (panels)
+    others = [kernels[k] for k in ("gemm_f32_multi", "gemm_f32_panel") if k in kernels]
     roofline = None
     if g:
-        launches = g["launches"] + (gm["launches"] if gm else 0)
-        per_step_us = (g["avg_us"] * g["launches"] + (gm["avg_us"] * gm["launches"] if gm else 0.0)) / n_prof
+        launches = g["launches"] + sum(o["launches"] for o in others)
+        per_step_us = (g["avg_us"] * g["launches"] + sum(o["avg_us"] * o["launches"] for o in others)) / n_prof
         ach = flops_step / (per_step_us * 1e-6) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f32 + gemm_f32_multi (all CrossNet products of a step)", "achieved": round(ach, 2),
+        roofline = {"bound": "mfma", "kernel": "gemm_f32 + gemm_f32_panel + gemm_f32_multi (all CrossNet products of a step)", "achieved": round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": launches / n_prof, "us_per_step": round(per_step_us, 2),
                     "alg_flops_per_step": flops_step, "floor_us": kernels.get("empty", {}).get("avg_us")}

@@ -345,6 +345,19 @@ typedef struct mi_gemm_problem {
 } mi_gemm_problem;
 MI_API int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream);
 
+/* The same contraction on a second tiling, for the large products of a DCN_MixHead layer (layer_dcn.py:90-115 and their
+ * gradients): C[M,N] = epi(A[M,K] . B), A row-major.  A workgroup owns a 64-row panel of A by one of nt equal column ranges
+ * (<= 112 columns), nt chosen so that the grid is whole rounds of 256 workgroups (N = 352: 4 x 88) — where 64 x 64 tiles
+ * leave half of the second round empty.  B: b_layout 0: B(k,n) = B[(k/gw)*gstride + n*ldb + k%gw] (nn.Linear layout;
+ * grouped: the experts' V_e^T side by side along k), b_layout 1: B(k,n) = B[(n/gw)*gstride + k*ldb + n%gw]; gw = the
+ * whole extent and gstride = 0 for an ungrouped B.  epi: 0, 2, 3, 4 of mi_gemm_f32 (R1, R2, C2 share C's row pitch ldc;
+ * epi 3/4 take bias / rowscale / nrs as there).  Everything 16-B aligned and N, K, gw, the pitches multiples of 4, else
+ * MI_ERR_UNSUPPORTED (the caller keeps mi_gemm_f32). */
+MI_API int mi_gemm_f32_panel(const float *A, int32_t lda, const float *B, int32_t ldb, int32_t b_layout,
+                             int32_t gw, int64_t gstride, float *C, int32_t ldc, int32_t M, int32_t N,
+                             int32_t K, int32_t epi, const float *bias, const float *R1, const float *R2,
+                             const float *rowscale, int32_t nrs, float *C2, void *stream);
+
 /* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
  *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
  *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients);

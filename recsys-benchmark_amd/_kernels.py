@@ -721,6 +721,26 @@ def gemm_multi(problems, transA=False, transB=False):
                    "mi_gemm_f32_multi")
 
 
+PANEL_GEMM = True        # False: every product stays on the 64x64-tile kernel (mi_gemm_f32)
+
+
+def gemm_panel(A, lda, B, ldb, b_layout, C, ldc, M, N, K, gw=None, gstride=0, epi="none", bias=None, R1=None, R2=None,
+               rowscale=None, nrs=0, C2=None) -> bool:
+    """mi_gemm_f32_panel over torch buffers; returns False — nothing launched — when the shape / alignment is outside that
+    kernel, so the caller issues its mi_gemm_f32 form instead."""
+    if gw is None:
+        gw = K if b_layout == 0 else N
+    if not PANEL_GEMM or M == 0 or any(v % 4 for v in (lda, ldb, ldc, N, K, gw, gstride)) or epi not in ("none", "tanh", "cross", "add"):
+        return False
+    if any(t is not None and t.data_ptr() % 16 for t in (A, B, C, bias, R1, R2, C2)):
+        return False
+    dev = _lib.require_gpu(A, B, C)
+    _lib.check(_lib.load().mi_gemm_f32_panel(A.data_ptr(), lda, B.data_ptr(), ldb, b_layout, gw, gstride, C.data_ptr(), ldc, M, N,
+                                             K, EPI[epi], _lib.ptr(bias), _lib.ptr(R1), _lib.ptr(R2), _lib.ptr(rowscale), nrs,
+                                             _lib.ptr(C2), _lib.stream_ptr(dev)), "mi_gemm_f32_panel")
+    return True
+
+
 def _zero_strided(C, M, N, ldc, batch, sC):
     for z in range(batch):
         torch.as_strided(C, (M, N), (ldc, 1), C.storage_offset() + z * sC).zero_()

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
                            _i32, _i32, _p],
     "mi_gemm_f32_multi": [_p, _i32, _i32, _i32, _p],
+    "mi_gemm_f32_panel": [_p, _i32, _p, _i32, _i32, _i32, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p],
     "mi_rowdot_multi": [_p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_cross_bwd_head": [_p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p],
     "mi_comm_unique_id": [ctypes.c_char_p],

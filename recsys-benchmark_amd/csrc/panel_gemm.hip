@@ -1,0 +1,185 @@
+// panel_gemm.hip — the four large products of a DCN_MixHead layer (src/models/layer_dcn.py:90-115 and its hand-written
+// backward, recsys-benchmark_amd/layer_dcn.py) on tail_gemm.hpp's main loop:
+//
+//   C[M,N] = epi( A[M,K] . B ),   A row-major (an activation),  M = batch, N and K a few hundred
+//
+// Why a second tiling beside gemm.hip.  gemm.hip cuts the output into 64 x 64 tiles: at M = 4096, N = 352 that is 384
+// workgroups for 256 CUs — two rounds, the second half empty (27 us for 0.74 GFLOP) — and its epilogue stores one float
+// per lane and instruction.  Here a workgroup owns a 64-row PANEL of A by one of `nt` equal column ranges of <= 112
+// columns, nt chosen so that the grid is a whole number of rounds of 256 (N = 352: 4 x 88, N = 256: 4 x 64): one
+// workgroup per CU, producers / consumers split by wave, a 4-slot LDS ring (all of it tail_gemm.hpp), and the epilogue
+// goes through an LDS tile so that every global access is a float4 of a whole row segment.
+//
+// B comes in the two layouts the head's parameters have, each optionally GROUPED (the expert dimension):
+//   layout 0 "reduction contiguous":  B(k, n) = Bp[(k / gw) * gstride + n * ldb + k % gw]
+//       dH2g = dT U^T        (U as [E*r, d]: gw = K, i.e. ungrouped)
+//       gn   = dZ1 . V^T     (V[e] is [d, r]: n-major rows of r, gw = r, gstride = d * r)
+//   layout 1 "output contiguous":     B(k, n) = Bp[(n / gw) * gstride + k * ldb + n % gw]
+//       out  = H2g . U       (U as [E*r, d]: gw = N, ungrouped)
+//       H1   = x_l . V       (V[e] is [d, r]: gw = r, gstride = d * r, ldb = r)
+// Epilogues (codes of mi_gemm_f32): 0 store | 2 tanh | 3 cross (lin = acc + bias[n]*rs(m), C = R1 + R2*lin, C2 = lin)
+// | 4 add (C = R1 + acc (+ R2) (+ sum_e rowscale[m,e] * bias[e*N+n])).
+#include "common.hpp"
+#include "tail_gemm.hpp"
+
+namespace {
+using namespace mi;
+using namespace tg;
+
+// (m, c): row and first of 4 consecutive "contiguous-side" indices; the contiguous side is cut into groups of gw.
+struct LoadGrouped {
+  const float *P;
+  int ld, gw;
+  long long gstride;
+  struct Raw { float4 a; };
+  typedef NoConsts Consts;
+  __device__ __forceinline__ Raw fetch(int m, int c) const {
+    const int grp = c / gw;
+    return Raw{vld4(P + grp * gstride + (long long)m * ld + (c - grp * gw))};
+  }
+  __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
+  __device__ __forceinline__ float4 finish(const Raw &r, const Consts &, int, int) const { return r.a; }
+};
+
+struct PanelArgs {
+  const float *A;
+  int lda;
+  LoadGrouped B;
+  float *C;
+  int ldc;
+  int M, N, K;
+  int ncols, ntn;
+  const float *bias, *R1, *R2, *rowscale;
+  int nrs;
+  float *C2;
+};
+
+constexpr int kTilePitch = BNT + 4;
+constexpr int kRowChunks = BNT / 4;      // float4 per tile row
+
+template <bool B_KC, int EPI>
+__global__ __launch_bounds__(kThreads) void k_panel_gemm(PanelArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  const int mt_total = (a.M + BM - 1) / BM;
+  const int tile = xcd_logical(blockIdx.x, mt_total * a.ntn);
+  if (tile < 0) return;
+  const int mt = tile / a.ntn, nt = tile % a.ntn;
+  const int m0 = mt * BM, n0 = nt * a.ncols;
+  const int rows_valid = min(BM, a.M - m0), cols_valid = min(a.ncols, a.N - n0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  floatx4 acc[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const KcOperand<64, LoadPlain> opR{LoadPlain{a.A, a.lda}, m0, rows_valid, a.K};
+  if constexpr (B_KC) main_loop<true, true>(acc, lds, 0, a.K, opR, KcOperand<BNT, LoadGrouped>{a.B, n0, cols_valid, a.K});
+  else main_loop<true, true>(acc, lds, 0, a.K, opR, OtOperand<BNT, LoadGrouped>{a.B, n0, cols_valid, a.K});
+
+  // ---- epilogue through an LDS tile: thread -> (row, float4 of columns); whole row segments per wave-instruction
+  float *T = lds;
+  if (wave < 4) {
+    const int r = lane & 15, g = lane >> 4;
+    float *row = T + (wave * 16 + r) * kTilePitch + 4 * g;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) vst4(row + 16 * s, make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]));
+  }
+  __syncthreads();
+  constexpr int PER = (64 * kRowChunks + kThreads - 1) / kThreads;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * kThreads, row = i / kRowChunks, c = (i % kRowChunks) * 4;
+    if (i >= 64 * kRowChunks || row >= rows_valid || c >= cols_valid) continue;
+    const int m = m0 + row, n = n0 + c;
+    const long long o = (long long)m * a.ldc + n;
+    float4 v = vld4(T + row * kTilePitch + c);
+    if constexpr (EPI == 2) {
+      v = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+    } else if constexpr (EPI == 3) {
+      float rs = 1.f;
+      if (a.rowscale) {
+        rs = 0.f;
+        for (int e = 0; e < a.nrs; ++e) rs += a.rowscale[(long long)m * a.nrs + e];
+      }
+      const float4 b = a.bias ? vld4(a.bias + n) : zero4();
+      const float4 lin = make_float4(v.x + b.x * rs, v.y + b.y * rs, v.z + b.z * rs, v.w + b.w * rs);
+      const float4 r1 = vld4(a.R1 + o), r2 = vld4(a.R2 + o);
+      if (a.C2) vst4(a.C2 + o, lin);
+      v = make_float4(r1.x + r2.x * lin.x, r1.y + r2.y * lin.y, r1.z + r2.z * lin.z, r1.w + r2.w * lin.w);
+    } else if constexpr (EPI == 4) {
+      const float4 r1 = vld4(a.R1 + o);
+      v = make_float4(v.x + r1.x, v.y + r1.y, v.z + r1.z, v.w + r1.w);
+      if (a.R2) {
+        const float4 r2 = vld4(a.R2 + o);
+        v = make_float4(v.x + r2.x, v.y + r2.y, v.z + r2.z, v.w + r2.w);
+      }
+      if (a.rowscale && a.bias) {
+        for (int e = 0; e < a.nrs; ++e) {
+          const float s = a.rowscale[(long long)m * a.nrs + e];
+          const float4 gq = vld4(a.bias + (long long)e * a.N + n);
+          v = make_float4(v.x + s * gq.x, v.y + s * gq.y, v.z + s * gq.z, v.w + s * gq.w);
+        }
+      }
+    }
+    vst4(a.C + o, v);
+  }
+}
+
+// the number of column ranges: the fewest that fit the 112-column tile, one or two more when that fills the last round of
+// 256 workgroups better (cost model: a workgroup pays ~60 columns' worth of fixed work beside its own columns)
+int panel_cols(int M, int N, int *ntiles) {
+  const int mt = (M + BM - 1) / BM;
+  const int lo = (N + BNT - 1) / BNT;
+  int best_nt = lo, best_nc = 0;
+  long long best = -1;
+  for (int nt = lo; nt <= lo + 2; ++nt) {
+    const int nc = ((N + nt - 1) / nt + 3) / 4 * 4;
+    const int real = (N + nc - 1) / nc;
+    const long long rounds = ((long long)mt * real + 255) / 256;
+    const long long cost = rounds * (60 + nc);
+    if (best < 0 || cost < best) { best = cost; best_nt = real; best_nc = nc; }
+  }
+  *ntiles = best_nt;
+  return best_nc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_gemm_f32_panel(const float *A, int32_t lda, const float *B, int32_t ldb, int32_t b_layout, int32_t gw, int64_t gstride,
+                      float *C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, const float *bias, const float *R1,
+                      const float *R2, const float *rowscale, int32_t nrs, float *C2, void *stream) {
+  if (M < 0 || N <= 0 || K <= 0 || (b_layout != 0 && b_layout != 1) || gw <= 0) return MI_ERR_INVALID_ARG;
+  if (M == 0) return MI_OK;
+  if (!A || !B || !C) return MI_ERR_INVALID_ARG;
+  if (epi != 0 && epi != 2 && epi != 3 && epi != 4) return MI_ERR_UNSUPPORTED;
+  if ((epi == 3 && (!R1 || !R2)) || (epi == 4 && !R1) || (rowscale && nrs < 1)) return MI_ERR_INVALID_ARG;
+  const bool al = aligned16(A) && aligned16(B) && aligned16(C) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && N % 4 == 0 &&
+                  K % 4 == 0 && gw % 4 == 0 && gstride % 4 == 0 && (!bias || aligned16(bias)) && (!R1 || aligned16(R1)) &&
+                  (!R2 || aligned16(R2)) && (!C2 || aligned16(C2));
+  if (!al) return MI_ERR_UNSUPPORTED;
+  PanelArgs a;
+  a.A = A; a.lda = lda;
+  a.B = LoadGrouped{B, ldb, gw, gstride};
+  a.C = C; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K;
+  a.ncols = panel_cols(M, N, &a.ntn);
+  a.bias = bias; a.R1 = R1; a.R2 = R2; a.rowscale = rowscale; a.nrs = nrs; a.C2 = C2;
+  const int tiles = ((M + BM - 1) / BM) * a.ntn;
+  const int grid = (tiles + 7) / 8 * 8;
+#define GO(KC, E) MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E>), grid, kThreads, stream, a)
+#define GO_E(KC)               \
+  do {                         \
+    if (epi == 0) GO(KC, 0);   \
+    else if (epi == 2) GO(KC, 2); \
+    else if (epi == 3) GO(KC, 3); \
+    else GO(KC, 4);            \
+  } while (0)
+  if (b_layout == 0) GO_E(true);
+  else GO_E(false);
+#undef GO_E
+#undef GO
+  return launch_status();
+}
+
+}  // extern "C"

@@ -53,8 +53,10 @@ class _DCNHeadFn(torch.autograd.Function):
         xs, lins = [x0], []
         for l in range(L):
             out, lin = _new((M, d), dev), _new((M, d), dev)
-            gemm(xs[-1], Ws[l], out, M, d, d, d, d, d, transB=True, epi="cross", bias=bs[l],
-                 R1=xs[-1], ldr1=d, R2=x0, ldr2=d, C2=lin, ldc2=d)
+            if not _kernels.gemm_panel(xs[-1], d, Ws[l], d, 0, out, d, M, d, d, epi="cross", bias=bs[l], R1=xs[-1], R2=x0,
+                                       C2=lin):
+                gemm(xs[-1], Ws[l], out, M, d, d, d, d, d, transB=True, epi="cross", bias=bs[l],
+                     R1=xs[-1], ldr1=d, R2=x0, ldr2=d, C2=lin, ldc2=d)
             xs.append(out)
             lins.append(lin)
         ctx.save_for_backward(*xs[:-1], *lins, *Ws)
@@ -86,8 +88,9 @@ class _DCNHeadFn(torch.autograd.Function):
             _bwd_head(g, x0, lins[l], None, 0, None, dlin, dx0, l != L - 1, dbs[l], None, M, d, s)
             later.append(dict(A=dlin, B=xs[l], C=dWs[l], M=d, N=d, K=M, lda=d, ldb=d, ldc=d))   # dW[o,i] = sum_m dlin[m,o] x_l[m,i]
             gn = _new((M, d), dev)
-            gemm(dlin, Ws[l], gn, M, d, d, d, d, d, epi="add", R1=g, ldr1=d,     # dx_l = g + dlin W  (+ dx0 at l=0)
-                 R2=dx0 if l == 0 else None, ldr2=d)
+            # dx_l = g + dlin W  (+ dx0 at l=0)
+            if not _kernels.gemm_panel(dlin, d, Ws[l], d, 1, gn, d, M, d, d, epi="add", R1=g, R2=dx0 if l == 0 else None):
+                gemm(dlin, Ws[l], gn, M, d, d, d, d, d, epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d)
             grads[2 * l], grads[2 * l + 1] = dWs[l], dbs[l]
             g = gn
         _kernels.gemm_multi(later, transA=True)
@@ -133,12 +136,15 @@ class _DCNMixFn(torch.autograd.Function):
             else:
                 gemm(xl, G, gate, M, E, d, d, d, E, transB=True)
             H1, H2, H2g = _new((M, Er), dev), _new((M, Er), dev), _new((M, Er), dev)
-            gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")        # tanh(x_l V_e)
+            if not _kernels.gemm_panel(xl, d, Vs[l], r, 1, H1, Er, M, Er, d, gw=r, gstride=d * r, epi="tanh"):
+                gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")    # tanh(x_l V_e)
             gemm(H1, Cs[l], H2, M, r, r, Er, r, Er, batch=E, sA=r, sB=r * r, sC=r, epi="tanh_gate",
                  rowscale=gate, nrs=E, C2=H2g, ldc2=Er, sC2=r)                                 # tanh(. C_e), * g_e
             out, T = _new((M, d), dev), _new((M, d), dev)
-            gemm(H2g, Us[l], out, M, d, Er, Er, d, d, epi="cross", bias=bs[l], rowscale=gate, nrs=E,
-                 R1=xl, ldr1=d, R2=x0, ldr2=d, C2=T, ldc2=d)                                   # sum over experts: K = E*r
+            if not _kernels.gemm_panel(H2g, Er, Us[l], d, 1, out, d, M, d, Er, epi="cross", bias=bs[l], rowscale=gate,
+                                       nrs=E, R1=xl, R2=x0, C2=T):
+                gemm(H2g, Us[l], out, M, d, Er, Er, d, d, epi="cross", bias=bs[l], rowscale=gate, nrs=E,
+                     R1=xl, ldr1=d, R2=x0, ldr2=d, C2=T, ldc2=d)                               # sum over experts: K = E*r
             xs.append(out)
             saved += [gate, H1, H2, H2g, T]
         ctx.save_for_backward(G, *xs[:-1], *saved, *Us, *Cs, *Vs, *bs)
@@ -185,7 +191,8 @@ class _DCNMixFn(torch.autograd.Function):
             dgsum = _new((M,), dev)
             _bwd_head(g, x0, T, gate, E, bs[l], dT, dx0, l != L - 1, db, dgsum, M, d, s)
             dH2g = _new((M, Er), dev)
-            gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)                             # dT U^T
+            if not _kernels.gemm_panel(dT, d, Us[l], d, 0, dH2g, Er, M, Er, d):                # dT U^T
+                gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)
             later.append(dict(A=H2g, B=dT, C=dU, M=Er, N=d, K=M, lda=Er, ldb=d, ldc=d))          # dU = H2g^T dT
             dgate, dZ2 = _new((M, E), dev), _new((M, Er), dev)
             _lib.check(lib.mi_mix_gate_bwd(dH2g.data_ptr(), H2.data_ptr(), gate.data_ptr(), dgsum.data_ptr(),
@@ -198,9 +205,11 @@ class _DCNMixFn(torch.autograd.Function):
             later.append(dict(A=xl, B=dZ1, C=dV, M=d, N=r, K=M, lda=d, ldb=Er, ldc=r, batch=E, sB=r,
                               sC=d * r))                                                       # dV_e = x_l^T dZ1_e
             gn = _new((M, d), dev)
-            gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,      # g + sum_e dZ1_e V_e^T
-                 epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d,
-                 rowscale=dgate, nrs=E, bias=G)                                                 # + dgate G in the epilogue
+            # g + sum_e dZ1_e V_e^T (+ dx0 at the first layer) + dgate G (a rank-E term of the epilogue)
+            if not _kernels.gemm_panel(dZ1, Er, Vs[l], r, 0, gn, d, M, d, Er, gw=r, gstride=d * r, epi="add", R1=g,
+                                       R2=dx0 if l == 0 else None, rowscale=dgate, nrs=E, bias=G):
+                gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,
+                     epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d, rowscale=dgate, nrs=E, bias=G)
             later.append(dict(A=dgate, B=xl, C=dGs[l], M=E, N=d, K=M, lda=E, ldb=d, ldc=d))     # layer l's share of dG
             grads[4 * l: 4 * l + 4] = [dU, dC, dV, db]
             g = gn

@@ -150,3 +150,53 @@ def test_add_epilogue_with_rank_term():
         assert torch.equal(C.cpu(), R1 + A @ W.t() + R2 + rs @ G)
         _kernels.gemm(d(A), d(W), C, epi="add", R1=d(R1), ldr1=N, rowscale=d(rs), nrs=E, bias=d(G), **kw)
         assert torch.equal(C.cpu(), R1 + A @ W.t() + rs @ G)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 352, 256), (4096, 256, 352), (200, 40, 48), (67, 8, 4), (1000, 416, 416), (130, 460, 64)])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_panel_gemm_layouts_groups_and_epilogues(M, N, K, layout):
+    """mi_gemm_f32_panel (64-row panels x column ranges, one workgroup per CU) against torch on integer-valued data (exact):
+    both B layouts, ungrouped and grouped along B's contiguous side (the experts), every epilogue it has."""
+    gen = torch.Generator().manual_seed(M + 3 * N + 7 * K + layout)
+    d = lambda t: t.to(DEV)                                                         # noqa: E731
+    A = _mk((M, K), gen)
+    # ungrouped
+    Bm = _mk((N, K) if layout == 0 else (K, N), gen)
+    prod = A @ (Bm.t() if layout == 0 else Bm)
+    C = torch.empty(M, N, device=DEV)
+    assert _kernels.gemm_panel(d(A), K, d(Bm), Bm.shape[1], layout, C, N, M, N, K)
+    assert torch.equal(C.cpu(), prod)
+    b, R1, R2, rs = _mk((N,), gen), _mk((M, N), gen), _mk((M, N), gen), _mk((M, 3), gen)
+    C2 = torch.empty(M, N, device=DEV)
+    assert _kernels.gemm_panel(d(A), K, d(Bm), Bm.shape[1], layout, C, N, M, N, K, epi="cross", bias=d(b), R1=d(R1), R2=d(R2),
+                               rowscale=d(rs), nrs=3, C2=C2)
+    lin = prod + b[None] * rs.sum(1, keepdim=True)
+    assert torch.equal(C2.cpu(), lin) and torch.equal(C.cpu(), R1 + R2 * lin)
+    assert _kernels.gemm_panel(d(A), K, d(Bm), Bm.shape[1], layout, C, N, M, N, K, epi="cross", bias=d(b), R1=d(R1), R2=d(R2))
+    assert torch.equal(C.cpu(), R1 + R2 * (prod + b))
+    G = _mk((3, N), gen)
+    assert _kernels.gemm_panel(d(A), K, d(Bm), Bm.shape[1], layout, C, N, M, N, K, epi="add", R1=d(R1), R2=d(R2), rowscale=d(rs),
+                               nrs=3, bias=d(G))
+    assert torch.equal(C.cpu(), R1 + prod + R2 + rs @ G)
+    assert _kernels.gemm_panel(d(A), K, d(Bm), Bm.shape[1], layout, C, N, M, N, K, epi="add", R1=d(R1))
+    assert torch.equal(C.cpu(), R1 + prod)
+    assert _kernels.gemm_panel(d(A), K, d(Bm * 0.25), Bm.shape[1], layout, C, N, M, N, K, epi="tanh")
+    assert_close(C, torch.tanh(prod * 0.25), 1e-6, 1e-6)
+    # grouped: the contiguous side of B in groups of gw (K for layout 0, N for layout 1), groups gstride apart
+    side = K if layout == 0 else N
+    for gw in (4, 8, 16, 64):
+        if side % gw or side // gw < 2:
+            continue
+        ng, other = side // gw, (N if layout == 0 else K)
+        Bg = _mk((ng, other, gw), gen)                         # group e: [other, gw], like V[e] = [d, r]
+        full = Bg.permute(1, 0, 2).reshape(other, side)        # [other, side]: row o = the groups' rows side by side
+        ref = A @ (full.t() if layout == 0 else full)
+        assert _kernels.gemm_panel(d(A), K, d(Bg), gw, layout, C, N, M, N, K, gw=gw, gstride=other * gw)
+        assert torch.equal(C.cpu(), ref), gw
+
+
+def test_panel_gemm_declines_what_it_does_not_cover():
+    A, B, C = torch.zeros(8, 6, device=DEV), torch.zeros(8, 6, device=DEV), torch.zeros(8, 8, device=DEV)
+    assert not _kernels.gemm_panel(A, 6, B, 6, 0, C, 8, 8, 8, 6)                   # K % 4
+    assert not _kernels.gemm_panel(A, 6, B, 6, 0, C, 8, 8, 8, 4, epi="mul_dtanh")   # an epilogue it does not have
+    assert not _kernels.gemm_panel(A[:, 1:], 6, B, 6, 0, C, 8, 8, 8, 4)             # misaligned operand
