@@ -342,16 +342,17 @@ def bench_c3(args, real_stdout):
         return
     kernels = kernel_table(kt)
     flops_step = 3.0 * nl * (E * (2 * d * r + 2 * r * r + 2 * r * d) + 2 * E * d) * B
-    g = kernels.get("gemm_f32")
-    # + the head's weight gradients (one multi-problem launch per backward) and its four large products per layer (panels)
-    others = [kernels[k] for k in ("gemm_f32_multi", "gemm_f32_panel") if k in kernels]
+    # every launch that carries CrossNet products: 64x64-tile GEMMs, the head's weight gradients (one multi-problem launch
+    # per backward), the layer products on 64-row panels and the per-expert kernels with the r x r product in their epilogue
+    prods = [kernels[k] for k in ("gemm_f32", "gemm_f32_multi", "gemm_f32_panel", "mix_expert_fwd", "mix_expert_bwd") if k in kernels]
     roofline = None
-    if g:
-        launches = g["launches"] + sum(o["launches"] for o in others)
-        per_step_us = (g["avg_us"] * g["launches"] + sum(o["avg_us"] * o["launches"] for o in others)) / n_prof
+    if prods:
+        launches = sum(o["launches"] for o in prods)
+        per_step_us = sum(o["avg_us"] * o["launches"] for o in prods) / n_prof
         ach = flops_step / (per_step_us * 1e-6) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f32 + gemm_f32_panel + gemm_f32_multi (all CrossNet products of a step)", "achieved": round(ach, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+        roofline = {"bound": "mfma", "kernel": "all CrossNet products of a step (gemm_f32 / _panel / _multi, mix_expert_fwd / _bwd)",
+                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": launches / n_prof, "us_per_step": round(per_step_us, 2),
                     "alg_flops_per_step": flops_step, "floor_us": kernels.get("empty", {}).get("avg_us")}
     out = {"metric": "samples/sec fwd+bwd, Avazu-22field DCN-Mix (QR divider 2) b=4096; MFMA TFLOP/s vs roofline",

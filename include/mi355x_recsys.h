@@ -358,6 +358,19 @@ MI_API int mi_gemm_f32_panel(const float *A, int32_t lda, const float *B, int32_
                              int32_t K, int32_t epi, const float *bias, const float *R1, const float *R2,
                              const float *rowscale, int32_t nrs, float *C2, void *stream);
 
+/* The per-expert middle of a DCN_MixHead layer (layer_dcn.py:96-108) with the r x r product in the epilogue of the d-long
+ * one; a workgroup owns 64 rows and one expert e.  V fp32[E,d,r], C fp32[E,r,r], U fp32[E,r,d], gate fp32[M,E], the H / dZ
+ * matrices fp32[M,E*r].
+ *   mi_mix_expert_fwd: H1_e = tanh(x V_e); H2_e = tanh(H1_e C_e); H2g_e = H2_e * gate[m,e]
+ *   mi_mix_expert_bwd: dH = dT U_e^T (never stored); dgate[m,e] = sum_k dH*H2_e + dgs[m];
+ *                      dZ2_e = dH * gate[m,e] * (1 - H2_e^2); dZ1_e = (dZ2_e C_e^T) * (1 - H1_e^2)
+ * r in {16, 32, 64}, d % 4 == 0, 16-B aligned; else MI_ERR_UNSUPPORTED (the caller keeps the separate products). */
+MI_API int mi_mix_expert_fwd(const float *x, const float *V, const float *C, const float *gate, float *H1,
+                             float *H2, float *H2g, int32_t M, int32_t d, int32_t E, int32_t r, void *stream);
+MI_API int mi_mix_expert_bwd(const float *dT, const float *U, const float *C, const float *gate,
+                             const float *H1, const float *H2, const float *dgs, float *dgate, float *dZ2,
+                             float *dZ1, int32_t M, int32_t d, int32_t E, int32_t r, void *stream);
+
 /* Elementwise / reduction pieces of the CrossNet backward (layer_dcn.py:90-140 differentiated):
  *   mi_cross_bwd_pre: dlin = g*x0; dx0 (+)= g*lin          (n elements)
  *   mi_colsum:        out[n] += sum_m X[m,n]*rs(m)          (out caller-zeroed; bias gradients);

@@ -109,6 +109,8 @@ SIGNATURES = {
                            _i32, _i32, _p],
     "mi_gemm_f32_multi": [_p, _i32, _i32, _i32, _p],
     "mi_gemm_f32_panel": [_p, _i32, _p, _i32, _i32, _i32, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p],
+    "mi_mix_expert_fwd": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "mi_mix_expert_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "mi_rowdot_multi": [_p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_cross_bwd_head": [_p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p],
     "mi_comm_unique_id": [ctypes.c_char_p],

@@ -57,7 +57,8 @@ struct PanelArgs {
 constexpr int kTilePitch = BNT + 4;
 constexpr int kRowChunks = BNT / 4;      // float4 per tile row
 
-template <bool B_KC, int EPI>
+// NS: 16-column sub-tiles a workgroup computes (ncols <= 16 NS): 4 for a 64-column range instead of all 7
+template <bool B_KC, int EPI, int NS>
 __global__ __launch_bounds__(kThreads) void k_panel_gemm(PanelArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   const int mt_total = (a.M + BM - 1) / BM;
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(kThreads) void k_panel_gemm(PanelArgs a) {
   for (int s = 0; s < NSUB; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   const KcOperand<64, LoadPlain> opR{LoadPlain{a.A, a.lda}, m0, rows_valid, a.K};
-  if constexpr (B_KC) main_loop<true, true>(acc, lds, 0, a.K, opR, KcOperand<BNT, LoadGrouped>{a.B, n0, cols_valid, a.K});
-  else main_loop<true, true>(acc, lds, 0, a.K, opR, OtOperand<BNT, LoadGrouped>{a.B, n0, cols_valid, a.K});
+  if constexpr (B_KC) main_loop<true, true, NS>(acc, lds, 0, a.K, opR, KcOperand<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
+  else main_loop<true, true, NS>(acc, lds, 0, a.K, opR, OtOperand<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
 
   // ---- epilogue through an LDS tile: thread -> (row, float4 of columns); whole row segments per wave-instruction
   float *T = lds;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void k_panel_gemm(PanelArgs a) {
     const int r = lane & 15, g = lane >> 4;
     float *row = T + (wave * 16 + r) * kTilePitch + 4 * g;
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) vst4(row + 16 * s, make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]));
+    for (int s = 0; s < NS; ++s) vst4(row + 16 * s, make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]));
   }
   __syncthreads();
   constexpr int PER = (64 * kRowChunks + kThreads - 1) / kThreads;
@@ -167,7 +168,14 @@ int mi_gemm_f32_panel(const float *A, int32_t lda, const float *B, int32_t ldb, 
   a.bias = bias; a.R1 = R1; a.R2 = R2; a.rowscale = rowscale; a.nrs = nrs; a.C2 = C2;
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
   const int grid = (tiles + 7) / 8 * 8;
-#define GO(KC, E) MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E>), grid, kThreads, stream, a)
+  const int ns = (a.ncols + 15) / 16;
+#define GO(KC, E)                                                                                   \
+  do {                                                                                              \
+    if (ns <= 4) MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E, 4>), grid, kThreads, stream, a);      \
+    else if (ns == 5) MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E, 5>), grid, kThreads, stream, a); \
+    else if (ns == 6) MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E, 6>), grid, kThreads, stream, a); \
+    else MI_LAUNCH("gemm_f32_panel", (k_panel_gemm<KC, E, 7>), grid, kThreads, stream, a);              \
+  } while (0)
 #define GO_E(KC)               \
   do {                         \
     if (epi == 0) GO(KC, 0);   \

@@ -336,27 +336,31 @@ __device__ __forceinline__ float4 oc_frag(const float *T, int col, int h, int g)
 
 // Fragment registers of one half-slice (16 reduction indices) for a consumer wave: its 16 rows of R and the 7 sub-tiles
 // of Cc.
+// NS <= NSUB: the sub-tiles a kernel actually needs (a 64-column range needs 4 of the 7: the others would be MFMAs on
+// columns that are masked anyway).
+template <int NS>
 struct Frags {
-  float4 b, a[NSUB];
+  float4 b, a[NS];
 };
-template <bool R_KC, bool C_KC>
-__device__ __forceinline__ void read_frags(Frags &f, const float *Rt, const float *Ct, int wave, int lane, int h) {
+template <bool R_KC, bool C_KC, int NS>
+__device__ __forceinline__ void read_frags(Frags<NS> &f, const float *Rt, const float *Ct, int wave, int lane, int h) {
   const int r = lane & 15, g = lane >> 4;
   f.b = R_KC ? kc_frag(Rt, wave * 16 + r, h, g) : oc_frag<SR_OC>(Rt, wave * 16 + r, h, g);
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) f.a[s] = C_KC ? kc_frag(Ct, s * 16 + r, h, g) : oc_frag<SC_OC>(Ct, s * 16 + r, h, g);
+  for (int s = 0; s < NS; ++s) f.a[s] = C_KC ? kc_frag(Ct, s * 16 + r, h, g) : oc_frag<SC_OC>(Ct, s * 16 + r, h, g);
 }
-// 28 MFMAs, j-major: consecutive ones hit different accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an
+// 4 NS MFMAs, j-major: consecutive ones hit different accumulators (a dependent v_mfma_f32_16x16x4_f32 needs 40 cycles, an
 // independent one issues every 32).
-__device__ __forceinline__ void mma_half(floatx4 (&acc)[NSUB], const Frags &f) {
+template <int NS>
+__device__ __forceinline__ void mma_half(floatx4 (&acc)[NSUB], const Frags<NS> &f) {
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].x, f.b.x, acc[s], 0, 0, 0);
+  for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].x, f.b.x, acc[s], 0, 0, 0);
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].y, f.b.y, acc[s], 0, 0, 0);
+  for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].y, f.b.y, acc[s], 0, 0, 0);
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].z, f.b.z, acc[s], 0, 0, 0);
+  for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].z, f.b.z, acc[s], 0, 0, 0);
 #pragma unroll
-  for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].w, f.b.w, acc[s], 0, 0, 0);
+  for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s].w, f.b.w, acc[s], 0, 0, 0);
 }
 
 constexpr int kStageFloats = 64 * BK + BNT * BK > 32 * SR_OC + 32 * SC_OC ? 64 * BK + BNT * BK : 32 * SR_OC + 32 * SC_OC;
@@ -387,7 +391,7 @@ __device__ __forceinline__ void consumer_barrier() { __builtin_amdgcn_s_barrier(
 // The element work of the operand loads (BatchNorm / ReLU / dropout bit) runs on the producers' VALU slots beside the
 // consumers' MFMAs (not for free: the f32 MFMA shares the vector issue, so it is kept to a few instructions per float4).  fetchR/fetchC(red0) issue the loads of one slice, finishR/finishC(T, stage, red0)
 // transform and write it.  Fetches past the last slice re-read the last slice (never written).
-template <bool R_KC, bool C_KC, class OR, class OC>
+template <bool R_KC, bool C_KC, int NS = NSUB, class OR, class OC>
 __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const OR &opR,
                                           const OC &opC) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -456,17 +460,17 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
     }
   } else {
     // ---------------------------------------------------------------------------------------------- consumers
-    Frags f0, f1;
+    Frags<NS> f0, f1;
     __builtin_amdgcn_s_setprio(3);     // the matrix pipe's wave wins the issue arbitration against the producer beside it
     consumer_barrier();
-    read_frags<R_KC, C_KC>(f0, slot(0) + rOff, slot(0) + cOff, wave, lane, 0);
+    read_frags<R_KC, C_KC, NS>(f0, slot(0) + rOff, slot(0) + cOff, wave, lane, 0);
     for (int i = 0; i < nst; ++i) {
       const float *T = slot(i), *Tn = slot(i + 1);
-      read_frags<R_KC, C_KC>(f1, T + rOff, T + cOff, wave, lane, 1);
+      read_frags<R_KC, C_KC, NS>(f1, T + rOff, T + cOff, wave, lane, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_half(acc, f0);
       __builtin_amdgcn_sched_barrier(0);
-      if (i + 1 < nst) read_frags<R_KC, C_KC>(f0, Tn + rOff, Tn + cOff, wave, lane, 0);
+      if (i + 1 < nst) read_frags<R_KC, C_KC, NS>(f0, Tn + rOff, Tn + cOff, wave, lane, 0);
       __builtin_amdgcn_sched_barrier(0);
       mma_half(acc, f1);
       __builtin_amdgcn_sched_barrier(0);

@@ -23,6 +23,11 @@ def _new(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+def _expert_fused(r: int, d: int) -> bool:
+    """mi_mix_expert_fwd/bwd cover ranks 16 / 32 / 64 (the reference's configs use 64) and d % 4 == 0."""
+    return _kernels.PANEL_GEMM and r in (16, 32, 64) and d % 4 == 0
+
+
 def _bwd_head(g, x0, lin, gate, E, b, dlin, dx0, accumulate, db, dgs, M, d, s):
     """dlin = g*x0, dx0 (+)= g*lin, db += sum_m dlin*rs(m), dgs[m] = dlin[m,:].b in one launch (mi_cross_bwd_head);
     shapes it does not cover (d % 4, d > 1024) take the three separate passes."""
@@ -136,10 +141,15 @@ class _DCNMixFn(torch.autograd.Function):
             else:
                 gemm(xl, G, gate, M, E, d, d, d, E, transB=True)
             H1, H2, H2g = _new((M, Er), dev), _new((M, Er), dev), _new((M, Er), dev)
-            if not _kernels.gemm_panel(xl, d, Vs[l], r, 1, H1, Er, M, Er, d, gw=r, gstride=d * r, epi="tanh"):
-                gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")    # tanh(x_l V_e)
-            gemm(H1, Cs[l], H2, M, r, r, Er, r, Er, batch=E, sA=r, sB=r * r, sC=r, epi="tanh_gate",
-                 rowscale=gate, nrs=E, C2=H2g, ldc2=Er, sC2=r)                                 # tanh(. C_e), * g_e
+            if _expert_fused(r, d):          # tanh(x_l V_e), tanh(. C_e), * g_e in one launch
+                _lib.check(_lib.load().mi_mix_expert_fwd(xl.data_ptr(), Vs[l].data_ptr(), Cs[l].data_ptr(), gate.data_ptr(),
+                                                         H1.data_ptr(), H2.data_ptr(), H2g.data_ptr(), M, d, E, r,
+                                                         _lib.stream_ptr(dev)), "mi_mix_expert_fwd")
+            else:
+                if not _kernels.gemm_panel(xl, d, Vs[l], r, 1, H1, Er, M, Er, d, gw=r, gstride=d * r, epi="tanh"):
+                    gemm(xl, Vs[l], H1, M, r, d, d, r, Er, batch=E, sB=d * r, sC=r, epi="tanh")    # tanh(x_l V_e)
+                gemm(H1, Cs[l], H2, M, r, r, Er, r, Er, batch=E, sA=r, sB=r * r, sC=r, epi="tanh_gate",
+                     rowscale=gate, nrs=E, C2=H2g, ldc2=Er, sC2=r)                                 # tanh(. C_e), * g_e
             out, T = _new((M, d), dev), _new((M, d), dev)
             if not _kernels.gemm_panel(H2g, Er, Us[l], d, 1, out, d, M, d, Er, epi="cross", bias=bs[l], rowscale=gate,
                                        nrs=E, R1=xl, R2=x0, C2=T):
@@ -190,18 +200,22 @@ class _DCNMixFn(torch.autograd.Function):
             db = part(l, Er * d + E * r * r + E * d * r, (1, d))
             dgsum = _new((M,), dev)
             _bwd_head(g, x0, T, gate, E, bs[l], dT, dx0, l != L - 1, db, dgsum, M, d, s)
-            dH2g = _new((M, Er), dev)
-            if not _kernels.gemm_panel(dT, d, Us[l], d, 0, dH2g, Er, M, Er, d):                # dT U^T
-                gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)
             later.append(dict(A=H2g, B=dT, C=dU, M=Er, N=d, K=M, lda=Er, ldb=d, ldc=d))          # dU = H2g^T dT
-            dgate, dZ2 = _new((M, E), dev), _new((M, Er), dev)
-            _lib.check(lib.mi_mix_gate_bwd(dH2g.data_ptr(), H2.data_ptr(), gate.data_ptr(), dgsum.data_ptr(),
-                                           dgate.data_ptr(), dZ2.data_ptr(), M, E, r, s), "mi_mix_gate_bwd")
+            dgate, dZ2, dZ1 = _new((M, E), dev), _new((M, Er), dev), _new((M, Er), dev)
+            if _expert_fused(r, d):          # dT U^T, the gate / tanh backward and (dZ2_e C_e^T) * tanh' in one launch
+                _lib.check(lib.mi_mix_expert_bwd(dT.data_ptr(), Us[l].data_ptr(), Cs[l].data_ptr(), gate.data_ptr(),
+                                                 H1.data_ptr(), H2.data_ptr(), dgsum.data_ptr(), dgate.data_ptr(),
+                                                 dZ2.data_ptr(), dZ1.data_ptr(), M, d, E, r, s), "mi_mix_expert_bwd")
+            else:
+                dH2g = _new((M, Er), dev)
+                if not _kernels.gemm_panel(dT, d, Us[l], d, 0, dH2g, Er, M, Er, d):            # dT U^T
+                    gemm(dT, Us[l], dH2g, M, Er, d, d, d, Er, transB=True)
+                _lib.check(lib.mi_mix_gate_bwd(dH2g.data_ptr(), H2.data_ptr(), gate.data_ptr(), dgsum.data_ptr(),
+                                               dgate.data_ptr(), dZ2.data_ptr(), M, E, r, s), "mi_mix_gate_bwd")
+                gemm(dZ2, Cs[l], dZ1, M, r, r, Er, r, Er, transB=True, batch=E, sA=r, sB=r * r, sC=r,
+                     epi="mul_dtanh", R1=H1, ldr1=Er, sR1=r)                                   # (dZ2_e C_e^T) * tanh'
             later.append(dict(A=H1, B=dZ2, C=dC, M=r, N=r, K=M, lda=Er, ldb=Er, ldc=r, batch=E, sA=r, sB=r,
                               sC=r * r))                                                       # dC_e = H1_e^T dZ2_e
-            dZ1 = _new((M, Er), dev)
-            gemm(dZ2, Cs[l], dZ1, M, r, r, Er, r, Er, transB=True, batch=E, sA=r, sB=r * r, sC=r,
-                 epi="mul_dtanh", R1=H1, ldr1=Er, sR1=r)                                       # (dZ2_e C_e^T) * tanh'
             later.append(dict(A=xl, B=dZ1, C=dV, M=d, N=r, K=M, lda=d, ldb=Er, ldc=r, batch=E, sB=r,
                               sC=d * r))                                                       # dV_e = x_l^T dZ1_e
             gn = _new((M, d), dev)

@@ -164,3 +164,42 @@ def test_cross_bwd_head_equals_its_three_passes(M, N, mix):
         assert torch.equal(db.cpu(), (ref_dlin * rs).sum(0))
         if mix:
             assert torch.equal(dgs.cpu(), ref_dlin @ b)
+
+
+@pytest.mark.parametrize("M,d,E,r", [(4096, 352, 4, 64), (200, 40, 3, 16), (67, 8, 1, 32), (130, 416, 2, 64), (1, 4, 4, 16)])
+def test_mix_expert_kernels_vs_float64(M, d, E, r):
+    """mi_mix_expert_fwd / _bwd (the r x r product in the epilogue of the d-long one) against the same chain written out in
+    float64: H1 = tanh(x V_e), H2 = tanh(H1 C_e), H2g = H2 g_e;  dH = dT U_e^T, dgate = sum dH*H2 + dgs,
+    dZ2 = dH g_e (1 - H2^2), dZ1 = (dZ2 C_e^T)(1 - H1^2)."""
+    from recsys_benchmark_amd import _lib
+
+    gen = torch.Generator().manual_seed(M + d + E + r)
+    R = lambda *s: torch.randn(*s, generator=gen)                                  # noqa: E731
+    x, dT, gate, dgs = R(M, d) * 0.5, R(M, d), R(M, E), R(M)
+    V, C, U = R(E, d, r) / d ** 0.5, R(E, r, r) / r ** 0.5, R(E, r, d) / r ** 0.5
+    dev = torch.device(DEV, 0)
+    g = lambda t: t.to(DEV)                                                        # noqa: E731
+    xd, dTd, gd, dgsd, Vd, Cd, Ud = g(x), g(dT), g(gate), g(dgs), g(V), g(C), g(U)
+    H1, H2, H2g = (torch.empty(M, E * r, device=DEV) for _ in range(3))
+    lib, st = _lib.load(), _lib.stream_ptr(dev)
+    _lib.check(lib.mi_mix_expert_fwd(xd.data_ptr(), Vd.data_ptr(), Cd.data_ptr(), gd.data_ptr(), H1.data_ptr(), H2.data_ptr(),
+                                     H2g.data_ptr(), M, d, E, r, st), "fwd")
+    x64, V64, C64, U64 = x.double(), V.double(), C.double(), U.double()
+    h1 = torch.tanh(torch.einsum("md,edr->mer", x64, V64))
+    h2 = torch.tanh(torch.einsum("mek,ekc->mec", h1, C64))
+    assert_close(H1.view(M, E, r), h1, 2e-5, 2e-6, "H1")
+    assert_close(H2.view(M, E, r), h2, 2e-5, 2e-6, "H2")
+    assert_close(H2g.view(M, E, r), h2 * gate.double()[:, :, None], 2e-5, 2e-6, "H2g")
+    dgate, dZ2, dZ1 = torch.empty(M, E, device=DEV), torch.empty(M, E * r, device=DEV), torch.empty(M, E * r, device=DEV)
+    _lib.check(lib.mi_mix_expert_bwd(dTd.data_ptr(), Ud.data_ptr(), Cd.data_ptr(), gd.data_ptr(), H1.data_ptr(), H2.data_ptr(),
+                                     dgsd.data_ptr(), dgate.data_ptr(), dZ2.data_ptr(), dZ1.data_ptr(), M, d, E, r, st), "bwd")
+    h1f, h2f = H1.view(M, E, r).double().cpu(), H2.view(M, E, r).double().cpu()      # the saved fp32 activations, as the kernel reads them
+    dh = torch.einsum("md,erd->mer", dT.double(), U64)
+    assert_close(dgate, (dh * h2f).sum(2) + dgs.double()[:, None], 1e-4, 1e-5 * d ** 0.5, "dgate")
+    dz2 = dh * gate.double()[:, :, None] * (1 - h2f * h2f)
+    assert_close(dZ2.view(M, E, r), dz2, 1e-4, 1e-5, "dZ2")
+    dz1 = torch.einsum("mek,eck->mec", dz2, C64) * (1 - h1f * h1f)
+    assert_close(dZ1.view(M, E, r), dz1, 1e-4, 1e-5, "dZ1")
+    with pytest.raises(_lib.MI355XLibraryError):          # rank 48 is outside the fused form: the caller keeps the separate products
+        _lib.check(lib.mi_mix_expert_fwd(xd.data_ptr(), Vd.data_ptr(), Cd.data_ptr(), gd.data_ptr(), H1.data_ptr(), H2.data_ptr(),
+                                         H2g.data_ptr(), M, d, E, 48, st), "fwd")
