@@ -13,7 +13,7 @@ from oracle import int_ops
 from oracle import reference_ops as ro
 
 import recsys_benchmark_amd as pkg
-from recsys_benchmark_amd import _lib
+from recsys_benchmark_amd import _kernels, _lib
 from recsys_benchmark_amd.embeddings import (CerpEmbedding, DHEmbedding, PrunedEmbedding, QRHashingEmbedding,
                                              RetrainCerpEmbedding, get_embedding)
 
@@ -598,3 +598,26 @@ def test_optembed_feature_thresholds_and_own_sampling():
     assert bool((a[kept] == full[kept]).all()) and bool(kept[..., 0].all()), "kept entries are the table's, dim 0 always kept"
     assert bool((kept[..., :-1] >= kept[..., 1:]).all()), "prefix masks"
     assert not torch.equal(a, b), "a new draw every forward"
+
+
+@pytest.mark.parametrize("op", ["mult", "add"])
+@pytest.mark.parametrize("div2", [2, 7, 2 ** 33])
+@pytest.mark.parametrize("De", [16, 24, 4])
+def test_dual_gather_gradients_with_small_and_huge_ids(op, div2, De):
+    """mi_dual_gather_fwd / _bwd against torch indexing / index_add on integer-valued data (exact), with ids below and far
+    beyond 2^32 (div2 = 2^33) and row widths that do and do not divide a wave."""
+    gen = torch.Generator().manual_seed(De + (div2 % 1000))
+    n1, n2, n = 5, 9, 3000
+    i2 = torch.randint(0, n2, (n,), generator=gen)
+    idx = i2 * div2 + torch.randint(0, min(div2, 1000), (n,), generator=gen)      # anywhere inside bucket i2
+    i1 = idx % n1
+    mk = lambda *s: torch.randint(-3, 4, s, generator=gen).float()          # noqa: E731
+    T1, T2, G = mk(n1, De), mk(n2, De), mk(n, De)
+    a, b = T1.to(DEV).requires_grad_(True), T2.to(DEV).requires_grad_(True)
+    out = _kernels.dual_gather(idx.to(DEV), a, b, n1, div2, op)
+    ref = T1[i1] * T2[i2] if op == "mult" else T1[i1] + T2[i2]
+    assert torch.equal(out.cpu(), ref)
+    (out * G.to(DEV)).sum().backward()
+    g1 = torch.zeros(n1, De).index_add_(0, i1, G * (T2[i2] if op == "mult" else 1.0))
+    g2 = torch.zeros(n2, De).index_add_(0, i2, G * (T1[i1] if op == "mult" else 1.0))
+    assert torch.equal(a.grad.cpu(), g1) and torch.equal(b.grad.cpu(), g2)
