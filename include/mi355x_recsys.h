@@ -606,6 +606,8 @@ MI_API int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_
  *
  * mi_tail_fwd_gemm:  Z[M,N] = a(X)[M,K] . W[N,K]^T (no bias: it cancels in a training-mode BatchNorm; see mean_offset);
  *   part (nullable, mi_tail_part_elems(M, N) floats): (mean, M2) of every 64-row tile of Z, per column.
+ *   a_out (nullable, [M,K] with X's pitch; needs x_mu): the activation a(X) as the operand load computed it — kept for the
+ *   weight-gradient product when that runs on mi_gemm_f32_multi.
  * mi_tail_bn_finalize_fwd: joins `part` (Chan's formula, tile order) into mu = batch mean, sc = gamma * rstd, be = beta,
  *   rstd; running_mean / running_var updated as F.batch_norm(training=True) does (unbiased variance; mean_offset =
  *   the Linear's bias, added to the mean only there); *num_batches_tracked += 1; *seed_bump += 1 (nullable each).
@@ -615,14 +617,15 @@ MI_API int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_
  * mi_tail_bn_finalize_bwd: joins part[nblk, N, 2] -> dgamma, dbeta (nullable) and al, bz, de; wpart (nullable) -> dw[N], db[1].
  * mi_tail_dgrad_gemm: da[M,K] = dz[M,N] . W[N,K]; with the layer below given (p_mu != NULL):
  *   OUT = da * keep_prev/(1-p) * [pre_prev > 0] (= DY of that layer), part[MT, K, 2] (nullable) its column sums;
- *   otherwise OUT = da (the gradient of the tail's input).
+ *   otherwise OUT = da (the gradient of the tail's input).  dz_out (nullable, [M,N] with DY's pitch; needs al): dz as the
+ *   operand load computed it, for the same purpose.
  * mi_tail_wgrad_gemm: dW[N,K] = dz[M,N]^T . a_prev[M,K]; the batch is cut into mi_tail_wgrad_splits(M, N, K) slices,
  *   slab (splits * N * K floats) holds their partial products, added in slice order into dW.                      */
 MI_API int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
                                  const int32_t *lds, uint8_t *const *bits, int32_t M, void *stream);
 MI_API int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
                             float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
-                            float *part, int32_t M, int32_t N, int32_t K, void *stream);
+                            float *part, float *a_out, int32_t M, int32_t N, int32_t K, void *stream);
 MI_API int64_t mi_tail_part_elems(int32_t M, int32_t N);
 MI_API int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, const float *gamma, const float *beta,
                                    const float *mean_offset, float *running_mean, float *running_var, float momentum,
@@ -641,8 +644,8 @@ MI_API int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, i
 MI_API int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
                               const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
                               int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,
-                              const uint8_t *p_keep, float *OUT, int32_t ldo, float *part, int32_t M, int32_t N,
-                              int32_t K, void *stream);
+                              const uint8_t *p_keep, float *OUT, int32_t ldo, float *part, float *dz_out, int32_t M,
+                              int32_t N, int32_t K, void *stream);
 MI_API int32_t mi_tail_wgrad_splits(int32_t M, int32_t N, int32_t K);
 MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
                               const float *bz, const float *de, const float *pZ, int32_t pld, const float *p_mu,

@@ -709,9 +709,13 @@ def gemm_multi(problems, transA=False, transB=False):
     for i in range(0, len(problems), MAX_GEMM_PROBLEMS):
         chunk = problems[i:i + MAX_GEMM_PROBLEMS]
         arr = (_GemmProblem * len(chunk))()
+        # K-slices for the LAUNCH, not per problem: together the problems should come to ~2.5 workgroups per CU — each
+        # slice is a workgroup that adds a whole 64x64 tile with float atomics, so more slices than that only buy atomics
+        tiles = sum(-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in chunk)
+        share = 1 if DETERMINISTIC else max(1, round(640 / max(tiles, 1)))
         for d, q in zip(arr, chunk):
             batch = q.get("batch", 1)
-            sk = q.get("splitk", 0) or auto_splitk(q["M"], q["N"], q["K"], batch)
+            sk = q.get("splitk", 0) or max(1, min(share, -(-q["K"] // 32) // 4, 65535 // max(batch, 1)))
             d.A, d.B, d.C = q["A"].data_ptr(), q["B"].data_ptr(), q["C"].data_ptr()
             d.M, d.N, d.K = q["M"], q["N"], q["K"]
             d.lda, d.ldb, d.ldc, d.batch = q["lda"], q["ldb"], q["ldc"], batch

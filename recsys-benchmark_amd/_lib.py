@@ -94,7 +94,7 @@ SIGNATURES = {
     "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
     "mi_prof_enable": [_i32],
     "mi_tail_dropout_masks": [_p, _i32, _p, _p, _p, _p, _i32, _p],
-    "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _i32, _i32, _i32, _p],
+    "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_part_elems": [_i32, _i32],
     "mi_tail_bn_finalize_fwd": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
                                 _p, _p],
@@ -103,7 +103,7 @@ SIGNATURES = {
     "mi_tail_head_bwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_tail_bn_finalize_bwd": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "mi_tail_dgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
-                           _i32, _p, _i32, _i32, _i32, _p],
+                           _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_wgrad_splits": [_i32, _i32, _i32],
     "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
                            _i32, _i32, _p],

@@ -107,6 +107,7 @@ struct FwdArgs {
   float *Z;           // [M, N] out
   int ldz;
   float *part;        // [MT, N, 2] (mean, M2) of every 64-row tile, nullable
+  float *a_out;       // [M, K] (pitch x.ld), nullable: the activation a(X) as the operand load computed it
   int M, N, K;
   int ncols;          // columns per workgroup (multiple of 4, <= 112)
   int ntn;            // column tiles
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   const LoadPlain xp{a.x.Z, a.x.ld};
   const LoadPlain wp{a.W, a.ldw};
   const KcOperand<BNT, LoadPlain> opC{wp, n0, cols_valid, a.K};
-  if constexpr (ACT) main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadAct>{act, m0, rows_valid, a.K}, opC);
+  if constexpr (ACT)
+    main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
   else main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
   // ---- epilogue.  A lane holds z[m0 + 16 wave + r][n0 + 16 s + 4 g + v] (waves 0-3); the tile goes through LDS once so
@@ -412,6 +414,7 @@ struct DgradArgs {
   float *OUT;         // [M, K] dy_prev or da_prev
   int ldo;
   float *part;        // [MT, K, 2] (sum dy, sum dy (z - mu)), nullable
+  float *dz_out;      // [M, N] (pitch dz.ld), nullable: dz as the operand load computed it
   int M, N, K;
   int ncols, ntn;     // column tiles over K
 };
@@ -434,7 +437,8 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadPlain wp{a.W, a.ldw};     // [red = n][out = k]
   const OtOperand<BNT, LoadPlain> opC{wp, k0, cols_valid, a.N};     // transposed into a KC tile on the way in
-  if constexpr (DZ) main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadDz>{dzl, m0, rows_valid, a.N}, opC);
+  if constexpr (DZ)
+    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDz>>{Tee<LoadDz>{dzl, nt == 0 ? a.dz_out : nullptr, a.dz.ld}, m0, rows_valid, a.N}, opC);
   else main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
 
   // ---- epilogue through LDS (see k_tail_fwd): all 8 waves, whole row segments
@@ -580,8 +584,8 @@ bool vec_ok(const void *p, int ld) { return aligned16(p) && ld % 4 == 0; }
 extern "C" {
 
 int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
-                     const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, int32_t M,
-                     int32_t N, int32_t K, void *stream) {
+                     const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                     int32_t M, int32_t N, int32_t K, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !W || !Z) return MI_ERR_INVALID_ARG;
@@ -591,6 +595,8 @@ int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float
   if (x_mu && x_p > 0.f && (!x_keep || ldx % 8)) return MI_ERR_INVALID_ARG;
   a.x = ActDesc{X, ldx, x_mu, x_sc, x_be, x_p, x_keep};
   a.W = W; a.ldw = ldw; a.Z = Z; a.ldz = ldz; a.part = part;
+  if (a_out && (!x_mu || !aligned16(a_out))) return MI_ERR_INVALID_ARG;      // only a transformed operand has anything to keep
+  a.a_out = a_out;
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(N, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
@@ -676,7 +682,7 @@ int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t 
 int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
                        const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
                        const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
-                       float *part, int32_t M, int32_t N, int32_t K, void *stream) {
+                       float *part, float *dz_out, int32_t M, int32_t N, int32_t K, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!DY || !W || !OUT) return MI_ERR_INVALID_ARG;
@@ -690,6 +696,8 @@ int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float
   if (p_mu && p_p > 0.f && (!p_keep || pld % 8)) return MI_ERR_INVALID_ARG;
   a.prev = ActDesc{pZ, pld, p_mu, p_sc, p_be, p_p, p_keep};
   a.OUT = OUT; a.ldo = ldo; a.part = part;
+  if (dz_out && (!al || !aligned16(dz_out))) return MI_ERR_INVALID_ARG;
+  a.dz_out = dz_out;
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(K, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;

@@ -134,6 +134,26 @@ struct LoadDz {
   }
 };
 
+// Tee: the operand value also goes to memory as it passes (out[m][c], row pitch the loader's own), so that a LATER product
+// on other kernels can read the transformed matrix (the tail's weight gradients take a(z) and dz from here).  One column
+// tile of the grid is given a non-null `out`; rows / reduction indices that were clamped store a duplicate of the same
+// value at its own (valid) address.
+template <class L>
+struct Tee {
+  L in;
+  float *out;
+  int ld;
+  typedef typename L::Raw Raw;
+  typedef typename L::Consts Consts;
+  __device__ __forceinline__ Raw fetch(int m, int c) const { return in.fetch(m, c); }
+  __device__ __forceinline__ Consts consts(int c) const { return in.consts(c); }
+  __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int m, int c) const {
+    const float4 v = in.finish(r, k, m, c);
+    if (out) vst4(out + (int64_t)m * ld + c, v);
+    return v;
+  }
+};
+
 __device__ __forceinline__ int ptid() { return (int)threadIdx.x - (kThreads - kProd); }
 
 // ---- LDS tiles -------------------------------------------------------------------------------------------------------

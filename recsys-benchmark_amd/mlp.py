@@ -37,11 +37,12 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
 TUNE_BACKWARD_GEMMS = False
 
 # FUSED_TAIL = True runs the training-mode (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail as ONE autograd
-# node over the fused MFMA kernels of csrc/tail.hip (tail.py): no atomics (bit-reproducible steps), no stored activations
-# or masks.  It is opt-in: measured on MI355X at the headline shape it is SLOWER than the general path below (0.329 vs
-# 0.290 ms per step) — at M = 4096, N,K ~ 400 every product is ~10 us of MFMA work behind ~6 us of launch + prologue +
-# epilogue, the f32 MFMA shares the vector issue with the operand transforms, and the library's kernels sit at the same
-# floor without them ("fused tail").
+# node over the fused MFMA kernels of csrc/tail.hip (tail.py): BatchNorm / ReLU / Dropout inside the operand loads and
+# epilogues of the products, the weight gradients as one multi-problem launch; with use_deterministic_algorithms(True) no
+# atomics at all (bit-reproducible steps).  It is opt-in: measured on MI355X at the headline shape it is level with the
+# general path below but not ahead (0.290 vs 0.286-0.288 ms per step) — at M = 4096, N,K ~ 400 every product is ~10 us of
+# MFMA work behind ~6 us of launch + prologue + epilogue, the f32 MFMA shares the vector issue with the operand
+# transforms, and the library's kernels sit at the same floor without them ("fused tail").
 FUSED_TAIL = False
 
 

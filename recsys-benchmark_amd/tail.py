@@ -5,8 +5,10 @@ as ONE autograd node over the kernels of csrc/tail.hip:
     forward   masks (one launch, only with dropout) ; per layer: MFMA product with the previous layer's
               BatchNorm+ReLU+Dropout applied in its operand load and the BatchNorm statistics in its epilogue, then a
               one-block finalize ; head (row dot + bias + y_fm)                                   -> 2k + 2 launches
-    backward  head backward ; per layer: finalize, weight-gradient product (+ slab sum), input-gradient product whose
-              epilogue already is the next layer's dy and its dgamma / dbeta pieces                -> 4k + 1 launches
+    backward  head backward ; per layer: finalize, input-gradient product whose epilogue already is the next layer's dy
+              and its dgamma / dbeta pieces ; the k weight-gradient products together in ONE multi-problem launch at the
+              end (mi_gemm_f32_multi) on a(z) and dz as the forward / input-gradient operand loads stored them
+              (deterministic mode: one slab-summed product per layer instead, no atomics)        -> 2k + 3 launches
 
 against 3 library GEMMs + 4 BatchNorm-family passes per layer each way before.  No activation is written or read a
 second time, the dropout decisions are one bit per element, and every reduction is joined in a fixed order: two runs
@@ -93,18 +95,23 @@ class FusedTailFn(torch.autograd.Function):
         w_head = _kernels._f32c(params[4 * k]).view(-1)
         b_head = params[4 * k + 1]
         bits = _masks(seed, plan, M, dev)
-        Zs, consts = [], []
+        keep_inputs = not _kernels.DETERMINISTIC
+        Zs, consts, acts = [], [], []
         prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
         for i, L in enumerate(plan):
             N, K = L.lin.out_features, L.lin.in_features
             Z = torch.empty((M, N), dtype=torch.float32, device=dev)
             part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
             c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
+            # the layer's input activation as its operand load computes it, kept for the weight gradient (not in
+            # deterministic mode, whose weight-gradient kernel recomputes it)
+            a_in = torch.empty((M, K), dtype=torch.float32, device=dev) if (keep_inputs and prev_c is not None) else None
             _lib.check(lib.mi_tail_fwd_gemm(
                 prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
                 _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
-                float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), M, N, K, s),
-                "mi_tail_fwd_gemm")
+                float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), _lib.ptr(a_in),
+                M, N, K, s), "mi_tail_fwd_gemm")
+            acts.append(a_in if a_in is not None else x.new_empty(0))
             bn = L.bn
             _lib.check(lib.mi_tail_bn_finalize_fwd(
                 part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
@@ -125,7 +132,7 @@ class FusedTailFn(torch.autograd.Function):
         ctx.has_head_bias = b_head is not None
         ctx.add_shape = None if last_add is None else tuple(last_add.shape)
         ctx.save_for_backward(x, w_head, *Ws, *Zs, *consts, *[b if b is not None else x.new_empty(0) for b in bits],
-                              *[L.bn.weight for L in plan])
+                              *[L.bn.weight for L in plan], *acts)
         return out
 
     @staticmethod
@@ -137,10 +144,19 @@ class FusedTailFn(torch.autograd.Function):
         Ws, Zs, consts = saved[2:2 + k], saved[2 + k:2 + 2 * k], saved[2 + 2 * k:2 + 3 * k]
         bits = [b if b.numel() else None for b in saved[2 + 3 * k:2 + 4 * k]]
         gammas = saved[2 + 4 * k:2 + 5 * k]
+        acts = [a if a.numel() else None for a in saved[2 + 5 * k:2 + 6 * k]]
         dev = x.device
         s = _lib.stream_ptr(dev)
         M = x.shape[0]
         gvec = _kernels._f32c(g).view(M)
+        later = []           # weight-gradient products for ONE launch at the end
+        # one zero-filled buffer for everything that must start at zero: the split-K weight gradients and the (exactly zero)
+        # gradients of the hidden Linear biases — one fill launch instead of 2k
+        sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
+        zeros = torch.zeros((sum(a + b for a, b in sizes),), dtype=torch.float32, device=dev)
+        zoff = [0]
+        for a, b in sizes:
+            zoff.append(zoff[-1] + a + b)
         need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, *params)
         grads: List[Optional[torch.Tensor]] = [None] * (4 * k + 2)
 
@@ -170,12 +186,20 @@ class FusedTailFn(torch.autograd.Function):
             wp = None
             grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
             if need[5 + 4 * i + 1] and plan[i].lin.bias is not None:
-                grads[4 * i + 1] = torch.zeros((N,), dtype=torch.float32, device=dev)   # exact: the batch mean is removed
+                grads[4 * i + 1] = zeros[zoff[i] + N * K: zoff[i + 1]]     # exact: the batch mean is removed
             below = Zs[i - 1] if i > 0 else x
             bc = consts[i - 1] if i > 0 else None
             bp = ctx.ps[i - 1] if i > 0 else 0.0
             bb = bits[i - 1] if i > 0 else None
-            if need[5 + 4 * i]:
+            runs_dgrad = i > 0 or need[3]
+            a_in = x if i == 0 else acts[i]
+            defer = need[5 + 4 * i] and runs_dgrad and a_in is not None and not _kernels.DETERMINISTIC
+            dz_keep = torch.empty((M, N), dtype=torch.float32, device=dev) if defer else None
+            if defer:
+                dW = zeros[zoff[i]: zoff[i] + N * K].view(N, K)               # split-K slices meet in atomics
+                later.append(dict(A=dz_keep, B=a_in, C=dW, M=N, N=K, K=M, lda=N, ldb=K, ldc=K))   # dW = dz^T a_in
+                grads[4 * i] = dW
+            elif need[5 + 4 * i]:
                 splits = int(lib.mi_tail_wgrad_splits(M, N, K))
                 slab = torch.empty((splits, N, K), dtype=torch.float32, device=dev)
                 dW = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -185,18 +209,19 @@ class FusedTailFn(torch.autograd.Function):
                     _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb), slab.data_ptr(), dW.data_ptr(), M, N, K, s),
                     "mi_tail_wgrad_gemm")
                 grads[4 * i] = dW
-            if i > 0 or need[3]:
+            if runs_dgrad:
                 OUT = torch.empty((M, K), dtype=torch.float32, device=dev)
                 npart = torch.empty(int(lib.mi_tail_part_elems(M, K)), dtype=torch.float32, device=dev) if i > 0 else None
                 _lib.check(lib.mi_tail_dgrad_gemm(
                     DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
                     Ws[i].data_ptr(), K, below.data_ptr() if i > 0 else None, K, _lib.ptr(bc[0]) if bc is not None else None,
                     _lib.ptr(bc[1]) if bc is not None else None, _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb),
-                    OUT.data_ptr(), K, _lib.ptr(npart), M, N, K, s), "mi_tail_dgrad_gemm")
+                    OUT.data_ptr(), K, _lib.ptr(npart), _lib.ptr(dz_keep), M, N, K, s), "mi_tail_dgrad_gemm")
                 if i > 0:
                     DY, part, part_rows = OUT, npart, (M + 63) // 64
                 else:
                     dx = OUT
+        _kernels.gemm_multi(later, transA=True)
         grads[4 * k] = dw_head
         grads[4 * k + 1] = db_head if ctx.has_head_bias else None
         dadd = gvec.view(ctx.add_shape) if (ctx.add_shape is not None and need[4]) else None

@@ -132,7 +132,12 @@ def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p):
     assert int(_mlp._seed_word(torch.device(DEV, 0))) == seed_value + (1 if p > 0 else 0)
 
 
-def test_fused_tail_is_bit_reproducible_and_graph_capturable():
+def test_fused_tail_is_bit_reproducible_and_graph_capturable(monkeypatch):
+    """Deterministic mode: every reduction of the fused tail is joined in a fixed order (its own slab-summed weight-gradient
+    kernel instead of the split-K multi-problem launch), so two runs of a step agree bit for bit."""
+    from recsys_benchmark_amd import _kernels
+
+    monkeypatch.setattr(_kernels, "DETERMINISTIC", True)
     torch.manual_seed(3)
     M, K, hidden, p = 4096, 416, [400, 400, 400], 0.5
     seq = _seq(K, hidden, p).train().to(DEV)
@@ -177,6 +182,41 @@ def test_fused_tail_is_bit_reproducible_and_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, a[0]) and torch.equal(xs.grad, a[1])
+
+
+def test_fused_tail_default_and_deterministic_weight_gradients_agree():
+    """Default mode keeps a(z) and dz as the operand loads computed them and runs the three weight gradients as ONE
+    multi-problem launch (split-K atomics); deterministic mode recomputes them inside its own kernel.  Same numbers up to
+    summation order; everything that does not pass through the split (outputs, input gradient, BatchNorm gradients) is
+    bit-identical."""
+    from recsys_benchmark_amd import _kernels
+
+    torch.manual_seed(5)
+    M, K, hidden, p = 4096, 416, [400, 400, 400], 0.5
+    seq0 = _seq(K, hidden, p).train().to(DEV)
+    x = torch.randn(M, K, device=DEV)
+    add = torch.randn(M, device=DEV)
+    res = {}
+    for det in (False, True):
+        _kernels.DETERMINISTIC = det
+        try:
+            seq = copy.deepcopy(seq0)
+            _mlp._seed_word(torch.device(DEV, 0)).fill_(77)
+            xd = x.clone().requires_grad_(True)
+            out = run_tail(seq, xd, last_add=add)
+            out.square().mean().backward()
+            res[det] = (out.detach(), xd.grad, {n: q.grad for n, q in seq.named_parameters()})
+        finally:
+            _kernels.DETERMINISTIC = False
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for name in a[2]:
+        ga, gb = a[2][name], b[2][name]
+        if name.endswith("weight") and ga.dim() == 2 and ga.shape[0] > 1:          # a hidden Linear's weight: through the split
+            scale = float(gb.abs().max())
+            assert float((ga - gb).abs().max()) <= 2e-5 * scale, name
+        else:
+            assert torch.equal(ga, gb), name
 
 
 def test_patterns_outside_the_fused_node_keep_the_general_path():

@@ -63,7 +63,7 @@ def main():
 
     def own_dgrad():
         _lib.check(lib.mi_tail_dgrad_gemm(P(DZ), P(Zl), N, P(c[0]), P(c[1]), P(c[2]), P(c[3]), P(W), K, None, 0, None, None, None,
-                                          0.0, None, P(DA), K, None, M, N, K, _lib.stream_ptr(dev)), "dgrad")
+                                          0.0, None, P(DA), K, None, None, M, N, K, _lib.stream_ptr(dev)), "dgrad")
 
     def own_wgrad():
         _lib.check(lib.mi_tail_wgrad_gemm(P(DZ), P(Zl), N, P(c[0]), P(c[1]), P(c[2]), P(c[3]), P(A), K, None, None, None, 0.0, None,

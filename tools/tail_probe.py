@@ -49,9 +49,9 @@ def run(M, N, K, p, check=True):
     part = torch.empty(int(lib.mi_tail_part_elems(M, N)), device=dev)
     # ---- forward, plain input
     def fwd_plain():
-        _lib.check(lib.mi_tail_fwd_gemm(P(X), K, None, None, None, 0.0, None, P(W), K, P(Z), N, P(part), M, N, K, S()), "fwd")
+        _lib.check(lib.mi_tail_fwd_gemm(P(X), K, None, None, None, 0.0, None, P(W), K, P(Z), N, P(part), None, M, N, K, S()), "fwd")
     def fwd_act():
-        _lib.check(lib.mi_tail_fwd_gemm(P(X), K, P(mu), P(sc), P(be), p, P(bitsK), P(W), K, P(Z), N, P(part), M, N, K, S()), "fwd")
+        _lib.check(lib.mi_tail_fwd_gemm(P(X), K, P(mu), P(sc), P(be), p, P(bitsK), P(W), K, P(Z), N, P(part), None, M, N, K, S()), "fwd")
     out = {}
     if check:
         fwd_plain(); ref = X.double() @ W.double().t()
@@ -81,10 +81,10 @@ def run(M, N, K, p, check=True):
     OUT = torch.empty(M, K, device=dev); dpart = torch.empty(int(lib.mi_tail_part_elems(M, K)), device=dev)
     def dgrad_mid():
         _lib.check(lib.mi_tail_dgrad_gemm(P(DY), P(Zl), N, P(mu_l), P(al), P(bz), P(de), P(W), K, P(X), K, P(mu), P(sc), P(be), p, P(bitsK),
-                                          P(OUT), K, P(dpart), M, N, K, S()), "dgrad")
+                                          P(OUT), K, P(dpart), None, M, N, K, S()), "dgrad")
     def dgrad_plain():
         _lib.check(lib.mi_tail_dgrad_gemm(P(DY), P(Zl), N, P(mu_l), P(al), P(bz), P(de), P(W), K, None, 0, None, None, None, 0.0, None,
-                                          P(OUT), K, None, M, N, K, S()), "dgrad")
+                                          P(OUT), K, None, None, M, N, K, S()), "dgrad")
     if check:
         dz = al.double() * DY.double() + bz.double() * (Zl.double() - mu_l.double()) + de.double()
         da = dz @ W.double()
