@@ -317,7 +317,7 @@ def bench_c3(args, real_stdout):
     from recsys_benchmark_amd.profiling import KernelTimer
 
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
-    _mlp.FUSED_TAIL = bool(args.fused_tail)
+    _mlp.FUSED_TAIL = bool(args.fused_tail) or _mlp.FUSED_TAIL          # (or MI_FUSED_TAIL=1)
     dims, D, hidden, B, E, r, nl = list(AVAZU_22), 16, [400, 400, 400], args.batch, 4, 64, 3
     F, d = len(dims), len(dims) * D
     torch.manual_seed(2023)
@@ -612,7 +612,7 @@ def main():
     # the MLP's two backward GEMMs per layer: let PyTorch pick the fastest rocBLAS/hipBLASLt solution per shape
     # (searched once, during the warm-up steps)
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
-    _mlp.FUSED_TAIL = bool(args.fused_tail)
+    _mlp.FUSED_TAIL = bool(args.fused_tail) or _mlp.FUSED_TAIL          # (or MI_FUSED_TAIL=1)
 
     dims, D, hidden, p_drop = list(CRITEO_KAGGLE_26), 16, [400, 400, 400], 0.5
     if args.c4:

@@ -11,6 +11,7 @@ inside the library's kernels, and the bias gradient of a Linear that feeds a tra
 BatchNorm is returned as the exact zero it is (sum_m dz = 0 when the batch mean is removed)
 instead of being reduced.  Anything that does not match the pattern runs as the plain module.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -43,7 +44,8 @@ TUNE_BACKWARD_GEMMS = False
 # general path below but not ahead (0.290 vs 0.286-0.288 ms per step) — at M = 4096, N,K ~ 400 every product is ~10 us of
 # MFMA work behind ~6 us of launch + prologue + epilogue, the f32 MFMA shares the vector issue with the operand
 # transforms, and the library's kernels sit at the same floor without them ("fused tail").
-FUSED_TAIL = False
+# (environment MI_FUSED_TAIL=1 turns it on for a whole process.)
+FUSED_TAIL = os.environ.get("MI_FUSED_TAIL", "0") == "1"
 
 
 class _tuned_gemms:
