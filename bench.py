@@ -317,7 +317,7 @@ def bench_c3(args, real_stdout):
     from recsys_benchmark_amd.profiling import KernelTimer
 
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
-    _mlp.FUSED_TAIL = bool(args.fused_tail) or _mlp.FUSED_TAIL          # (or MI_FUSED_TAIL=1)
+    _mlp.FUSED_TAIL = (bool(args.fused_tail) or _mlp.FUSED_TAIL) and not args.library_tail     # (default on; MI_FUSED_TAIL=0)
     dims, D, hidden, B, E, r, nl = list(AVAZU_22), 16, [400, 400, 400], args.batch, 4, 64, 3
     F, d = len(dims), len(dims) * D
     torch.manual_seed(2023)
@@ -542,8 +542,10 @@ def main():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the MLP's backward GEMMs on PyTorch's default hipBLASLt heuristic")
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2", help="c2 (default): the headline DeepFM workload; c3: DCN-Mix "
                     "Avazu-shaped with the QR embedding; c5: LightGCN Yelp2018-shaped (SURVEY.md §8d); --c4 is c2's 1e9-row variant")
-    ap.add_argument("--fused-tail", action="store_true", help="run the MLP tail on the fused MFMA kernels of csrc/tail.hip "
-                    "(deterministic; slower than the library GEMMs at this shape, see DESIGN.md)")
+    ap.add_argument("--fused-tail", action="store_true", help="(the default now) the MLP tail on the own fused MFMA kernels of "
+                    "csrc/tail.hip")
+    ap.add_argument("--library-tail", action="store_true", help="the MLP tail's contractions on hipBLASLt / rocBLAS through PyTorch "
+                    "(+ the fused BatchNorm passes of csrc/mlp.hip) instead of the own fused kernels; same speed (DESIGN.md §5b)")
     ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
                     "all-reduce and rank 0 prints a JSON line with no measurement in it (tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -612,7 +614,7 @@ def main():
     # the MLP's two backward GEMMs per layer: let PyTorch pick the fastest rocBLAS/hipBLASLt solution per shape
     # (searched once, during the warm-up steps)
     _mlp.TUNE_BACKWARD_GEMMS = not args.no_gemm_tuning
-    _mlp.FUSED_TAIL = bool(args.fused_tail) or _mlp.FUSED_TAIL          # (or MI_FUSED_TAIL=1)
+    _mlp.FUSED_TAIL = (bool(args.fused_tail) or _mlp.FUSED_TAIL) and not args.library_tail     # (default on; MI_FUSED_TAIL=0)
 
     dims, D, hidden, p_drop = list(CRITEO_KAGGLE_26), 16, [400, 400, 400], 0.5
     if args.c4:

@@ -37,15 +37,15 @@ def _seed_word(dev: torch.device) -> torch.Tensor:
 # backward products only, and only when a training loop opts in (it makes the first step of every new shape slow).
 TUNE_BACKWARD_GEMMS = False
 
-# FUSED_TAIL = True runs the training-mode (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail as ONE autograd
-# node over the fused MFMA kernels of csrc/tail.hip (tail.py): BatchNorm / ReLU / Dropout inside the operand loads and
-# epilogues of the products, the weight gradients as one multi-problem launch; with use_deterministic_algorithms(True) no
-# atomics at all (bit-reproducible steps).  It is opt-in: measured on MI355X at the headline shape it is level with the
-# general path below but not ahead (0.290 vs 0.286-0.288 ms per step) — at M = 4096, N,K ~ 400 every product is ~10 us of
-# MFMA work behind ~6 us of launch + prologue + epilogue, the f32 MFMA shares the vector issue with the operand
-# transforms, and the library's kernels sit at the same floor without them ("fused tail").
-# (environment MI_FUSED_TAIL=1 turns it on for a whole process.)
-FUSED_TAIL = os.environ.get("MI_FUSED_TAIL", "0") == "1"
+# FUSED_TAIL (default on; MI_FUSED_TAIL=0 or mlp.FUSED_TAIL = False turns it off): a training-mode
+# (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail runs as ONE autograd node over the fused MFMA kernels of
+# csrc/tail.hip (tail.py) — the contractions are the library's OWN kernels, BatchNorm / ReLU / Dropout sit inside their
+# operand loads and epilogues, the weight gradients are one multi-problem launch; with use_deterministic_algorithms(True)
+# there are no atomics at all (bit-reproducible steps).  Measured on MI355X, same box, A/B: DeepFM headline 0.2906 vs
+# 0.2886 ms per step for the general path below (hipBLASLt / rocBLAS products + the fused passes of csrc/mlp.hip), the
+# row-sharded step +1.2 %, DCN-Mix (C3) -1.4 % — level, without TunableOp's per-shape search at start-up.  Tails that do
+# not fit the pattern (eval mode, no BatchNorm, widths not multiples of 8, ...) take the general path by themselves.
+FUSED_TAIL = os.environ.get("MI_FUSED_TAIL", "1") != "0"
 
 
 class _tuned_gemms:

@@ -9,6 +9,15 @@ from conftest import assert_close, assert_mostly_close, assert_within_terms
 from recsys_benchmark_amd.mlp import run_tail
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=[True, False], ids=["own-tail", "library-tail"])
+def _both_tails(request, monkeypatch):
+    """Every test of this file runs with the MLP tail on the own fused kernels (the default) and on the general path
+    (library products + the fused BatchNorm passes), so both stay covered whatever the default is."""
+    from recsys_benchmark_amd import mlp as _mlp_mod
+
+    monkeypatch.setattr(_mlp_mod, "FUSED_TAIL", request.param)
 DEV = "cuda"
 
 

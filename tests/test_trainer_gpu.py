@@ -13,6 +13,15 @@ from recsys_benchmark_amd import trainer
 from recsys_benchmark_amd.optim import get_optimizers
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=[True, False], ids=["own-tail", "library-tail"])
+def _both_tails(request, monkeypatch):
+    """Every test of this file runs with the MLP tail on the own fused kernels (the default) and on the general path
+    (library products + the fused BatchNorm passes), so both stay covered whatever the default is."""
+    from recsys_benchmark_amd import mlp as _mlp_mod
+
+    monkeypatch.setattr(_mlp_mod, "FUSED_TAIL", request.param)
 DEV = torch.device("cuda", 0)
 DIMS = [50, 3, 1000, 7, 200]
 
