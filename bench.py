@@ -544,6 +544,8 @@ def main():
                     "Avazu-shaped with the QR embedding; c5: LightGCN Yelp2018-shaped (SURVEY.md §8d); --c4 is c2's 1e9-row variant")
     ap.add_argument("--fused-tail", action="store_true", help="(the default now) the MLP tail on the own fused MFMA kernels of "
                     "csrc/tail.hip")
+    ap.add_argument("--copy-batch", action="store_true", help="one graph with a static input and a device copy of the next resident "
+                    "batch into it every step (the round-1 form) instead of one graph per resident batch")
     ap.add_argument("--library-tail", action="store_true", help="the MLP tail's contractions on hipBLASLt / rocBLAS through PyTorch "
                     "(+ the fused BatchNorm passes of csrc/mlp.hip) instead of the own fused kernels; same speed (DESIGN.md §5b)")
     ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
@@ -700,18 +702,34 @@ def main():
                 eager_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
         from recsys_benchmark_amd.losses import unit_scalar
 
         one = unit_scalar(dev)      # d(loss)/d(loss) = 1 from a resident scalar: no fill per step, and the fused criterion
         #                             hands back the gradient its forward already wrote
-        with torch.cuda.graph(graph):
-            lossf(model(x), y).backward(one)
+        # One graph PER resident batch, each reading its ids and labels in place (all graphs share one memory pool: their
+        # replays never overlap): the step consumes the next resident batch without first copying it into a static input —
+        # inputs are in HBM when the timed region starts, and nothing but the step itself is timed.  (--copy-batch keeps
+        # the one-graph form with the 868 KB copy per step.)
+        graphs = []
+        slots = [cur] if args.copy_batch else ring
+        pool = None
+        for blob in slots:
+            xb, yb = blob[:nx].view(torch.int64).view(B, F), blob[nx:].view(torch.float32)
+            g = torch.cuda.CUDAGraph()
+            model.zero_grad(set_to_none=True)          # every capture builds its own gradient buffers (no accumulation)
+            with torch.cuda.graph(g, pool=pool):
+                lossf(model(xb), yb).backward(one)
+            pool = g.pool()
+            graphs.append(g)
 
         def step():
-            next_batch()
-            graph.replay()
+            if args.copy_batch:
+                next_batch()
+                graphs[0].replay()
+            else:
+                graphs[state["i"] % len(graphs)].replay()
+                state["i"] += 1
 
     for _ in range(args.warmup):
         step()
@@ -724,6 +742,9 @@ def main():
     pkg.check_index_errors()
     if sharded:
         model.check_overflow()
+    if use_graph:
+        graphs[-1].replay()         # p.grad are the buffers of the graph captured last: fill them for the check below
+        torch.cuda.synchronize()
     # the timed steps really produced gradients (a replayed graph reading a freed seed tensor would give zeros)
     # (weights only: a Linear bias in front of a training-mode BatchNorm has an exactly zero gradient)
     probe = [model._bias.grad] + [p.grad for p in model._deep_branch.parameters() if p.grad is not None and p.dim() == 2][:2]
@@ -808,7 +829,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "rccl_ranks": (collective_ranks if (sharded and not rehearse) else None),
             "collective_backend": (dist.get_backend() if sharded else None),
-            "launch": "hipGraph replay" if use_graph else ("eager RCCL collectives + one hipGraph for the local compute"
+            "launch": (("hipGraph replay, one static input refreshed by a device copy per step" if args.copy_batch else
+                        f"hipGraph replay, one graph per resident batch ({len(ring)}; ids and labels read in place)")
+                       if use_graph else "eager RCCL collectives + one hipGraph for the local compute"
                                                            if (sharded and graphed_local) else "eager"),
             "config": {"workload": f"{'C4' if args.c4 else 'C2'} DeepFM Criteo-26field full embedding: F={F}, D={D}, N={sum(dims)} rows, "
                                    f"MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(ring)} distinct uniform-id batches "
