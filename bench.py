@@ -342,6 +342,11 @@ def bench_c3(args, real_stdout):
         return
     kernels = kernel_table(kt)
     flops_step = 3.0 * nl * (E * (2 * d * r + 2 * r * r + 2 * r * d) + 2 * E * d) * B
+    tail_wgrad = 0.0
+    if _mlp.FUSED_TAIL:      # the own MLP tail runs its weight gradients as a gemm_f32_multi launch too: same kernel name, so its
+        widths = [d] + hidden      # flops join the count (its other products are tail_* kernels and stay out)
+        tail_wgrad = 2.0 * B * sum(a * b for a, b in zip(widths[:-1], widths[1:]))
+        flops_step += tail_wgrad
     # every launch that carries CrossNet products: 64x64-tile GEMMs, the head's weight gradients (one multi-problem launch
     # per backward), the layer products on 64-row panels and the per-expert kernels with the r x r product in their epilogue
     prods = [kernels[k] for k in ("gemm_f32", "gemm_f32_multi", "gemm_f32_panel", "mix_expert_fwd", "mix_expert_bwd") if k in kernels]
@@ -350,7 +355,8 @@ def bench_c3(args, real_stdout):
         launches = sum(o["launches"] for o in prods)
         per_step_us = sum(o["avg_us"] * o["launches"] for o in prods) / n_prof
         ach = flops_step / (per_step_us * 1e-6) / 1e12
-        roofline = {"bound": "mfma", "kernel": "all CrossNet products of a step (gemm_f32 / _panel / _multi, mix_expert_fwd / _bwd)",
+        roofline = {"bound": "mfma", "kernel": "all CrossNet products of a step (gemm_f32 / _panel / _multi, mix_expert_fwd / _bwd)" +
+                    (" + the MLP tail's weight gradients (the same gemm_f32_multi kernel)" if tail_wgrad else ""),
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": launches / n_prof, "us_per_step": round(per_step_us, 2),
