@@ -2,14 +2,18 @@
 Linear — reference: src/models/deepfm.py:53-66,100-102 and src/models/dcn.py:56-66.
 
 The modules stay ordinary nn.Linear / nn.BatchNorm1d / nn.ReLU / nn.Dropout inside the same
-nn.Sequential (state_dict keys unchanged); `run_tail` walks the Sequential and executes every
-(Linear, [BatchNorm1d], ReLU, [Dropout]) group as: the contraction on hipBLASLt/rocBLAS through
-PyTorch (a real GEMM), then ONE fused BN+ReLU+Dropout HIP pass each way (mi_bn_relu_dropout_*).
+nn.Sequential (state_dict keys unchanged); `run_tail` walks the Sequential.
+
+A training-mode tail with a BatchNorm after every hidden Linear and a 1-output last Linear — the
+reference's configs — runs on the library's own fused MFMA kernels (tail.py / csrc/tail.hip, see
+FUSED_TAIL below).  Every other pattern takes the GENERAL path of this file: each
+(Linear, [BatchNorm1d], ReLU, [Dropout]) group is the contraction on hipBLASLt/rocBLAS through
+PyTorch, then ONE fused BN+ReLU+Dropout HIP pass each way (mi_bn_relu_dropout_*).
 Launch count matters at B=4096 (every kernel is a few microseconds), so: all reduction targets
 of a pass live in ONE zero-filled workspace, the dropout-seed and num_batches_tracked bumps ride
 inside the library's kernels, and the bias gradient of a Linear that feeds a training-mode
 BatchNorm is returned as the exact zero it is (sum_m dz = 0 when the batch mean is removed)
-instead of being reduced.  Anything that does not match the pattern runs as the plain module.
+instead of being reduced.  Anything that does not match a group pattern runs as the plain module.
 """
 import os
 from typing import Dict, List, Optional
