@@ -1,7 +1,8 @@
 """Randomised shapes through the optimizer-side kernels against stock torch (run once in a while on a GPU box):
     python tools/fuzz.py [cases]
 field sort, sparse Adam (all widths), dense Adam (mixed sizes / unaligned views), masked InfoNCE, gather+FM with both
-gradient forms, and the fp32 MFMA GEMM at random small shapes.  Stops at the first mismatch with the seed that reproduces it."""
+gradient forms, the fp32 MFMA GEMM at random small shapes, and the round-2 CrossNet kernels (panel / multi-problem GEMMs, the
+fused backward head, the per-expert kernels).  Stops at the first mismatch with the seed that reproduces it."""
 import os
 import sys
 
@@ -152,6 +153,109 @@ def lookup_case(seed):
         raise SystemExit(f"MISMATCH route_buckets world={world} F={F} seed={seed}")
 
 
+def crossnet_case(seed):
+    """The round-2 CrossNet kernels at random shapes, integer-valued data (exact) where the arithmetic allows:
+    mi_gemm_f32_panel (layouts, groups, epilogues), mi_gemm_f32_multi, mi_cross_bwd_head, mi_rowdot_multi, and
+    mi_mix_expert_fwd/bwd against float64."""
+    from recsys_benchmark_amd import _lib
+
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    mk = lambda *sh: torch.randint(-3, 4, sh, generator=g).float()          # noqa: E731
+    d = lambda t: t.to(DEV)                                                 # noqa: E731
+    lib, st = _lib.load(), _lib.stream_ptr(DEV)
+    # ---- panel GEMM
+    M, N, K, layout = ri(1, 300), 4 * ri(1, 120), 4 * ri(1, 110), ri(0, 1)
+    A = mk(M, K)
+    side, other = (K, N) if layout == 0 else (N, K)
+    gws = [w for w in (4, 8, 16, 32, 64) if side % w == 0 and side // w >= 2]
+    if gws and ri(0, 1):
+        gw = gws[ri(0, len(gws) - 1)]
+        Bg = mk(side // gw, other, gw)
+        full = Bg.permute(1, 0, 2).reshape(other, side)
+        Bd, ldb, gs = d(Bg), gw, other * gw
+    else:
+        gw, gs = None, 0
+        full = mk(other, side)
+        Bd, ldb = d(full), side
+    prod = A @ (full.t() if layout == 0 else full)
+    C, C2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    E = ri(1, 5)
+    b, R1, R2, rs, G = mk(N), mk(M, N), mk(M, N), mk(M, E), mk(E, N)
+    epi = ("none", "cross", "add")[ri(0, 2)]
+    kw = dict(gw=gw, gstride=gs)
+    if epi == "none":
+        ok = _kernels.gemm_panel(d(A), K, Bd, ldb, layout, C, N, M, N, K, **kw)
+        want = prod
+    elif epi == "cross":
+        ok = _kernels.gemm_panel(d(A), K, Bd, ldb, layout, C, N, M, N, K, epi="cross", bias=d(b), R1=d(R1), R2=d(R2), rowscale=d(rs),
+                                 nrs=E, C2=C2, **kw)
+        lin = prod + b[None] * rs.sum(1, keepdim=True)
+        want = R1 + R2 * lin
+        if ok and not torch.equal(C2.cpu(), lin):
+            raise SystemExit(f"MISMATCH panel cross C2 seed={seed}")
+    else:
+        ok = _kernels.gemm_panel(d(A), K, Bd, ldb, layout, C, N, M, N, K, epi="add", R1=d(R1), R2=d(R2), rowscale=d(rs), nrs=E,
+                                 bias=d(G), **kw)
+        want = R1 + prod + R2 + rs @ G
+    if not ok or not torch.equal(C.cpu(), want):
+        raise SystemExit(f"MISMATCH panel M={M} N={N} K={K} layout={layout} gw={gw} epi={epi} ok={ok} seed={seed}")
+    # ---- several weight-gradient shaped problems in one launch
+    probs, refs = [], []
+    Km = ri(1, 3000)
+    for _ in range(ri(1, 6)):
+        m, n = ri(1, 200), ri(1, 200)
+        Aw, Bw = mk(Km, m), mk(Km, n)
+        Cw = torch.zeros(m, n, device=DEV)
+        probs.append(dict(A=d(Aw), B=d(Bw), C=Cw, M=m, N=n, K=Km, lda=m, ldb=n, ldc=n))
+        refs.append(Aw.t() @ Bw)
+    _kernels.gemm_multi(probs, transA=True)
+    for q, r in zip(probs, refs):
+        if not torch.equal(q["C"].cpu(), r):
+            raise SystemExit(f"MISMATCH gemm_multi seed={seed}")
+    # ---- backward head of a cross layer + the gate product
+    Mh, Nh, Eh = ri(1, 300), 4 * ri(1, 256), ri(1, 8)
+    gg, x0, lin, bb, gate, prev = mk(Mh, Nh), mk(Mh, Nh), mk(Mh, Nh), mk(Nh), mk(Mh, Eh), mk(Mh, Nh)
+    acc = ri(0, 1)
+    dlin, dx0, db, dgs = torch.empty(Mh, Nh, device=DEV), d(prev).clone(), torch.zeros(Nh, device=DEV), torch.empty(Mh, device=DEV)
+    keep = [d(t) for t in (gg, x0, lin, gate, bb)]
+    _lib.check(lib.mi_cross_bwd_head(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), Eh,
+                                     keep[4].data_ptr(), dlin.data_ptr(), dx0.data_ptr(), acc, db.data_ptr(), dgs.data_ptr(), Mh, Nh, st),
+               "mi_cross_bwd_head")
+    rdl = gg * x0
+    if not (torch.equal(dlin.cpu(), rdl) and torch.equal(dx0.cpu(), (prev if acc else 0) + gg * lin)
+            and torch.equal(db.cpu(), (rdl * gate.sum(1, keepdim=True)).sum(0)) and torch.equal(dgs.cpu(), rdl @ bb)):
+        raise SystemExit(f"MISMATCH cross_bwd_head M={Mh} N={Nh} E={Eh} seed={seed}")
+    Wg, og = mk(Eh, Nh), torch.empty(Mh, Eh, device=DEV)
+    keep2 = [d(x0), d(Wg)]
+    _lib.check(lib.mi_rowdot_multi(keep2[0].data_ptr(), Nh, keep2[1].data_ptr(), og.data_ptr(), Mh, Nh, Eh, st), "mi_rowdot_multi")
+    if not torch.equal(og.cpu(), x0 @ Wg.t()):
+        raise SystemExit(f"MISMATCH rowdot_multi seed={seed}")
+    # ---- per-expert kernels vs float64
+    Me, de, Ee, re_ = ri(1, 200), 4 * ri(1, 100), ri(1, 5), (16, 32, 64)[ri(0, 2)]
+    R = lambda *sh: torch.randn(*sh, generator=g)                           # noqa: E731
+    x, dT, gt, dgsv = R(Me, de) * 0.5, R(Me, de), R(Me, Ee), R(Me)
+    V, Cm, U = R(Ee, de, re_) / de ** 0.5, R(Ee, re_, re_) / re_ ** 0.5, R(Ee, re_, de) / re_ ** 0.5
+    t = [d(v) for v in (x, V, Cm, gt, dT, U, dgsv)]
+    H1, H2, H2g, dZ2, dZ1 = (torch.empty(Me, Ee * re_, device=DEV) for _ in range(5))
+    dgate = torch.empty(Me, Ee, device=DEV)
+    _lib.check(lib.mi_mix_expert_fwd(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), H1.data_ptr(), H2.data_ptr(),
+                                     H2g.data_ptr(), Me, de, Ee, re_, st), "fwd")
+    h1 = torch.tanh(torch.einsum("md,edr->mer", x.double(), V.double()))
+    h2 = torch.tanh(torch.einsum("mek,ekc->mec", h1, Cm.double()))
+    close(H1.view(Me, Ee, re_), h1, 2e-5, 2e-6, "expert H1", seed)
+    close(H2.view(Me, Ee, re_), h2, 2e-5, 2e-6, "expert H2", seed)
+    close(H2g.view(Me, Ee, re_), h2 * gt.double()[:, :, None], 2e-5, 2e-6, "expert H2g", seed)
+    _lib.check(lib.mi_mix_expert_bwd(t[4].data_ptr(), t[5].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), H1.data_ptr(), H2.data_ptr(),
+                                     t[6].data_ptr(), dgate.data_ptr(), dZ2.data_ptr(), dZ1.data_ptr(), Me, de, Ee, re_, st), "bwd")
+    h1f, h2f = H1.view(Me, Ee, re_).double().cpu(), H2.view(Me, Ee, re_).double().cpu()
+    dh = torch.einsum("md,erd->mer", dT.double(), U.double())
+    dz2 = dh * gt.double()[:, :, None] * (1 - h2f * h2f)
+    close(dgate, (dh * h2f).sum(2) + dgsv.double()[:, None], 1e-4, 2e-5 * de ** 0.5, "expert dgate", seed)
+    close(dZ2.view(Me, Ee, re_), dz2, 1e-4, 1e-5, "expert dZ2", seed)
+    close(dZ1.view(Me, Ee, re_), torch.einsum("mek,eck->mec", dz2, Cm.double()) * (1 - h1f * h1f), 1e-4, 1e-5, "expert dZ1", seed)
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     for s in range(cases):
@@ -159,6 +263,7 @@ if __name__ == "__main__":
         for j in range(4):
             gemm_case(100000 + 4 * s + j)
         lookup_case(500000 + s)
+        crossnet_case(700000 + s)
         if s % 25 == 24:
             print(f"{s + 1} cases ok", flush=True)
     print("FUZZ_OK")
