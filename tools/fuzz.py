@@ -86,8 +86,11 @@ def one(seed):
         emb, y = _kernels.gather_fm(x, off.view(1, -1).to(DEV), Wp, wp, None, sparse_W=sparse, sparse_w1=sparse)
         ((emb * emb).sum() * 0.5 + (y * y).sum()).backward()
         outs.append((emb, y, Wp.grad.to_dense() if sparse else Wp.grad, wp.grad.to_dense() if sparse else wp.grad))
-    close(outs[0][2], outs[1][2], 1e-4, 1e-5, "gather_fm table gradient forms", seed)
-    close(outs[0][3], outs[1][3], 1e-4, 1e-5, "gather_fm first-order gradient forms", seed)
+    # two summation orders over a row's duplicates (float atomics vs the coalesce): the difference scales with the size of
+    # the TERMS, not of a sum that may have cancelled — absolute tolerance on the matrix's own scale
+    for k, name in ((2, "table"), (3, "first-order")):
+        scale = float(outs[1][k].abs().max())
+        close(outs[0][k], outs[1][k], 1e-4, 1e-5 + 2e-6 * scale, f"gather_fm {name} gradient forms", seed)
     rw = (x.cpu() + off)
     close(outs[0][0], Wt.cpu()[rw], 0, 0, "gather_fm rows", seed)
 
@@ -256,6 +259,111 @@ def crossnet_case(seed):
     close(dZ1.view(Me, Ee, re_), torch.einsum("mek,eck->mec", dz2, Cm.double()) * (1 - h1f * h1f), 1e-4, 1e-5, "expert dZ1", seed)
 
 
+ambiguous = []     # tail cases with a pre-activation within 3e-6 of the ReLU kink whose gradients differ at the 1/M level
+
+
+def tail_case(seed):
+    """The fused MLP tail (the default path of a training step) at random widths / depths / batch sizes / dropout rates
+    against a float64 evaluation of the same modules given the very dropout mask the kernels use."""
+    import copy
+
+    from torch import nn
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from tail_helpers import tail_keep_scale
+
+    from recsys_benchmark_amd import mlp as _mlp
+    from recsys_benchmark_amd.tail import SALT, fused_tail_plan
+
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    M, K, depth = ri(2, 700), 8 * ri(1, 56), ri(1, 3)
+    hidden = [8 * ri(1, 56) for _ in range(depth)]
+    p = (0.0, 0.3, 0.5)[ri(0, 2)]
+    torch.manual_seed(seed)
+    layers, inp = [], K
+    for h in hidden:
+        layers += [nn.Linear(inp, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(p)]
+        inp = h
+    layers.append(nn.Linear(inp, 1))
+    seq = nn.Sequential(*layers).train()
+    for m in seq:
+        if isinstance(m, nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    x, add, G = torch.randn(M, K, generator=g) * 0.7 + 0.2, torch.randn(M, generator=g), torch.randn(M, 1, generator=g)
+    seed_value = 1000 + seed
+    masks = [tail_keep_scale(seed_value, SALT * (i + 1), M, h, p) for i, h in enumerate(hidden)]
+    # the reference op sequence with the explicit masks, in float64 and in stock float32 (the yardstick: a pre-activation
+    # within rounding of 0 lands on either side of the ReLU kink in ANY float32 evaluation, and at small M one flip moves a
+    # whole column's BatchNorm gradient by ~1/M)
+    def reference(dtype):
+        r = copy.deepcopy(seq).to(dtype)
+        xr, ar = x.detach().clone().to(dtype).requires_grad_(True), add.detach().clone().to(dtype).requires_grad_(True)
+        h, li, near = xr, 0, 0
+        for m in r:
+            if isinstance(m, nn.Dropout):
+                h = h * masks[li].to(dtype)
+                li += 1
+            else:
+                if isinstance(m, nn.ReLU):
+                    near += int((h.detach().abs() < 3e-6).sum())       # pre-activations a float32 evaluation may put on either side
+                h = m(h)
+        o = h + ar.view(-1, 1)
+        (o * G.to(dtype)).sum().backward()
+        return r, xr, o, near
+
+    r64, x64, out64, near_kink = reference(torch.float64)
+    r32, x32, out32, _ = reference(torch.float32)
+    # the fused node
+    was = _mlp.FUSED_TAIL
+    _mlp.FUSED_TAIL = True
+    try:
+        _mlp._seed_word(DEV).fill_(seed_value)
+        fs = copy.deepcopy(seq).to(DEV)
+        xd, ad = x.detach().to(DEV).requires_grad_(True), add.detach().to(DEV).requires_grad_(True)
+        if fused_tail_plan(fs, xd, _mlp._groups(fs)) is None:
+            raise SystemExit(f"tail_case seed={seed}: the fused node refused M={M} K={K} hidden={hidden}")
+        out = _mlp.run_tail(fs, xd, last_add=ad)
+        (out * G.to(DEV)).sum().backward()
+    finally:
+        _mlp.FUSED_TAIL = was
+    what = f"tail M={M} K={K} hidden={hidden} p={p}"
+
+    def check(got, r64_, r32_, name, k=32.0, floor=2e-6):
+        """fused error <= k x the stock float32 error, both against float64 — after setting aside what ONE or two ReLU-kink
+        flips can touch: a pre-activation within rounding of 0 falls on either side of the kink in any float32 evaluation
+        (the fused products sum in another order than torch's), and a flip of element (m, n) moves row m of every gradient
+        with respect to an activation, row n of that layer's weight gradient and, through the BatchNorm sums, column n by
+        ~1/M.  So up to three rows' and three columns' worth of elements are exempt from the tight bound and only have to
+        stay within 5 % of the tensor's scale."""
+        got, r64_, r32_ = got.detach().double().cpu(), r64_.detach().double(), r32_.detach().double()
+        scale = float(r64_.abs().max()) + 1e-30
+        e_f = ((got - r64_).abs() / scale).flatten()
+        e_s = float((r32_ - r64_).abs().max()) / scale
+        rows = got.shape[0] if got.dim() == 2 else 1
+        cols = got.shape[-1] if got.dim() >= 1 else 1
+        exempt = min(e_f.numel() - 1, 3 * (rows + cols)) if got.dim() == 2 else 3
+        srt = torch.sort(e_f, descending=True)[0]
+        tight = float(srt[exempt]) if exempt < srt.numel() else 0.0
+        if tight > max(k * e_s, floor) or float(srt[0]) > 5e-2:
+            if near_kink and float(srt[0]) <= 5e-2 and tight <= 2e-3:
+                ambiguous.append(seed)       # a kink flip in a deep layer reaches every gradient below it at the ~1/M level
+                return
+            raise SystemExit(f"MISMATCH {what} {name}: fused {float(srt[0]):.3e} (beyond the exempt rows/columns {tight:.3e}) vs stock "
+                             f"float32 {e_s:.3e}, relative to max|ref| seed={seed}")
+
+    check(out, out64, out32, "out")
+    check(xd.grad, x64.grad, x32.grad, "dx")
+    p64, p32 = dict(r64.named_parameters()), dict(r32.named_parameters())
+    for name, q in fs.named_parameters():
+        if q.grad is None or p64[name].grad is None:
+            continue
+        if name.endswith("bias") and float(q.grad.abs().max()) == 0.0:
+            continue                          # a Linear bias in front of a training BatchNorm: exactly zero
+        check(q.grad, p64[name].grad, p32[name].grad, name)
+
+
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     for s in range(cases):
@@ -264,6 +372,7 @@ if __name__ == "__main__":
             gemm_case(100000 + 4 * s + j)
         lookup_case(500000 + s)
         crossnet_case(700000 + s)
+        tail_case(900000 + s)
         if s % 25 == 24:
             print(f"{s + 1} cases ok", flush=True)
-    print("FUZZ_OK")
+    print(f"FUZZ_OK ({len(ambiguous)} tail cases with a pre-activation on the ReLU kink judged by the loose bound: seeds {ambiguous[:8]})")
