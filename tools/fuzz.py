@@ -347,11 +347,11 @@ def tail_case(seed):
         srt = torch.sort(e_f, descending=True)[0]
         tight = float(srt[exempt]) if exempt < srt.numel() else 0.0
         if tight > max(k * e_s, floor) or float(srt[0]) > 5e-2:
-            if near_kink and float(srt[0]) <= 5e-2 and tight <= 2e-3:
+            if near_kink and float(srt[0]) <= 5e-2 and tight <= max(2e-3, 2.0 / M):
                 ambiguous.append(seed)       # a kink flip in a deep layer reaches every gradient below it at the ~1/M level
                 return
             raise SystemExit(f"MISMATCH {what} {name}: fused {float(srt[0]):.3e} (beyond the exempt rows/columns {tight:.3e}) vs stock "
-                             f"float32 {e_s:.3e}, relative to max|ref| seed={seed}")
+                             f"float32 {e_s:.3e}, relative to max|ref|; pre-activations within 3e-6 of the kink: {near_kink}; seed={seed}")
 
     check(out, out64, out32, "out")
     check(xd.grad, x64.grad, x32.grad, "dx")
