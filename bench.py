@@ -248,23 +248,38 @@ def init_ranks(args, dev_index):
 
 
 def time_graphed(step, args, world, dev):
-    """Capture `step` (forward + loss + backward into static gradients) as ONE hipGraph, W warm-up replays, K timed
-    replays between fences; returns seconds (max over ranks)."""
+    """Capture `step` (forward + loss + backward into static gradients) as ONE hipGraph — or, given a LIST of steps (one per
+    resident batch, each reading its inputs in place), one graph per step sharing a memory pool, replayed in turn — W warm-up
+    replays, K timed replays between fences; returns seconds (max over ranks)."""
+    steps = list(step) if isinstance(step, (list, tuple)) else [step]
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         for _ in range(3):
-            step()
+            steps[0]()
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize()
     if args.no_graph:            # eager launches (counter collection passes)
         class _Eager:
-            replay = staticmethod(step)
-        graph = _Eager()
+            def __init__(self, fn):
+                self.replay = fn
+        graphs = [_Eager(fn) for fn in steps]
     else:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
+        graphs, pool = [], None
+        for fn in steps:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            pool = g.pool()
+            graphs.append(g)
+
+    class _Ring:
+        i = 0
+
+        def replay(self):
+            graphs[self.i % len(graphs)].replay()
+            self.i += 1
+    graph = _Ring()
 
     def fence():
         torch.cuda.synchronize()
@@ -323,14 +338,19 @@ def bench_c3(args, real_stdout):
     torch.manual_seed(2023)
     emb_cfg = {"name": "qr", "divider": 2}
     model = DCN_Mix(dims, D, hidden, num_layers=nl, num_experts=E, rank=r, embedding_config=emb_cfg, p_dropout=0.5).to(dev).train()
-    x, y = synth_batch(dims, B, 2023 + 7919 * rank, dev)
+    # resident batches with distinct ids, one hipGraph each (fresh rows every step, no input copy) — like the C2 leg
+    batches = [synth_batch(dims, B, 2023 + 7919 * rank + 104729 * i, dev) for i in range(max(1, min(args.ring, 8)))]
+    x, y = batches[0]
     lossf, one = BCEWithLogitsLoss(), unit_scalar(dev)
 
-    def step():
-        model.zero_grad(set_to_none=True)
-        lossf(model(x), y).backward(one)
+    def step_on(xb, yb):
+        def fn():
+            model.zero_grad(set_to_none=True)
+            lossf(model(xb), yb).backward(one)
+        return fn
 
-    elapsed = time_graphed(step, args, world, dev)
+    step = step_on(x, y)
+    elapsed = time_graphed([step_on(xb, yb) for xb, yb in batches], args, world, dev)
     pkg.check_index_errors()
     n_prof = min(args.steps, 50)
     with KernelTimer(capacity=96 * n_prof + 64) as kt:
@@ -366,7 +386,8 @@ def bench_c3(args, real_stdout):
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay",
            "config": {"workload": f"C3 DCN-Mix Avazu-22field: F={F}, D={D}, d={d}, N={sum(dims)} rows, QR divider 2 (mult), E={E}, "
-                                  f"rank={r}, L={nl}, MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd",
+                                  f"rank={r}, L={nl}, MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(batches)} distinct uniform-id batches rotated "
+                                  f"(one hipGraph per resident batch)",
                       "global_batch": B * world, "parallelism": "single" if world == 1 else f"{world} independent replicas"},
            "roofline": roofline, "kernels": kernels}
     if not args.no_cpu_baseline and world == 1:
