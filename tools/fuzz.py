@@ -1,5 +1,5 @@
 """Randomised shapes through the optimizer-side kernels against stock torch (run once in a while on a GPU box):
-    python tools/fuzz.py [cases]
+    python tools/fuzz.py [cases [first seed]]
 field sort, sparse Adam (all widths), dense Adam (mixed sizes / unaligned views), masked InfoNCE, gather+FM with both
 gradient forms, the fp32 MFMA GEMM at random small shapes, and the round-2 CrossNet kernels (panel / multi-problem GEMMs, the
 fused backward head, the per-expert kernels).  Stops at the first mismatch with the seed that reproduces it."""
@@ -49,7 +49,10 @@ def one(seed):
         p.grad = torch.sparse_coo_tensor(r.view(1, -1).to(DEV), v.to(DEV), (Nr, D), check_invariants=False)
         q.grad = torch.sparse_coo_tensor(r.view(1, -1), v, (Nr, D))
         o1.step(), o2.step()
-    close(p, q, 1e-4, 1e-5, f"sparse adam D={D} n={n} N={Nr}", seed)
+    # Adam divides by sqrt(v): an element whose duplicate gradients nearly cancel moves by up to a whole lr for a rounding-size
+    # change of the sum (two summation orders) — the comparison is on the scale of a step (3 % of lr); a wrong update is off by
+    # a step or more (tests/test_fullsize_properties_gpu.py brackets the same effect rigorously against float64)
+    close(p, q, 1e-4, 3e-4, f"sparse adam D={D} n={n} N={Nr}", seed)
     # ---- dense Adam over a few odd tensors
     shapes = [(ri(1, 70), ri(1, 70)) for _ in range(ri(1, 5))] + [(ri(1, 5000),)]
     ps = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
@@ -259,7 +262,7 @@ def crossnet_case(seed):
     close(dZ1.view(Me, Ee, re_), torch.einsum("mek,eck->mec", dz2, Cm.double()) * (1 - h1f * h1f), 1e-4, 1e-5, "expert dZ1", seed)
 
 
-ambiguous = []     # tail cases with a pre-activation within 3e-6 of the ReLU kink whose gradients differ at the 1/M level
+ambiguous = []     # tail cases that match float64 only with a near-kink ReLU decision taken the other way
 
 
 def tail_case(seed):
@@ -294,26 +297,40 @@ def tail_case(seed):
     x, add, G = torch.randn(M, K, generator=g) * 0.7 + 0.2, torch.randn(M, generator=g), torch.randn(M, 1, generator=g)
     seed_value = 1000 + seed
     masks = [tail_keep_scale(seed_value, SALT * (i + 1), M, h, p) for i, h in enumerate(hidden)]
-    # the reference op sequence with the explicit masks, in float64 and in stock float32 (the yardstick: a pre-activation
-    # within rounding of 0 lands on either side of the ReLU kink in ANY float32 evaluation, and at small M one flip moves a
-    # whole column's BatchNorm gradient by ~1/M)
-    def reference(dtype):
+    # The reference op sequence with the explicit masks, in float64 and in stock float32 (the yardstick).  A pre-activation
+    # within rounding of 0 lands on either side of the ReLU kink in ANY float32 evaluation (the fused products sum in another
+    # order than torch's), and one flip changes that element's whole gradient contribution: such elements are found in the
+    # float64 pass, and the fused result only has to match the float64 evaluation under ONE assignment of their ReLU decisions.
+    KINK = 3e-6
+
+    def reference(dtype, flips=None):
+        """flips: None, or a set of indices (in order of appearance) of near-kink elements whose ReLU decision is inverted"""
         r = copy.deepcopy(seq).to(dtype)
         xr, ar = x.detach().clone().to(dtype).requires_grad_(True), add.detach().clone().to(dtype).requires_grad_(True)
-        h, li, near = xr, 0, 0
+        h, li, seen = xr, 0, 0
         for m in r:
             if isinstance(m, nn.Dropout):
                 h = h * masks[li].to(dtype)
                 li += 1
+            elif isinstance(m, nn.ReLU):
+                near = (h.detach().abs() < KINK)
+                n_here = int(near.sum())
+                on = h.detach() > 0
+                if flips and n_here:
+                    pos = near.flatten().nonzero().view(-1)
+                    inv = torch.zeros(h.numel(), dtype=torch.bool)
+                    for j in range(n_here):
+                        if seen + j in flips:
+                            inv[pos[j]] = True
+                    on = on ^ inv.view_as(on)
+                seen += n_here
+                h = h * on.to(dtype)
             else:
-                if isinstance(m, nn.ReLU):
-                    near += int((h.detach().abs() < 3e-6).sum())       # pre-activations a float32 evaluation may put on either side
                 h = m(h)
         o = h + ar.view(-1, 1)
         (o * G.to(dtype)).sum().backward()
-        return r, xr, o, near
+        return r, xr, o, seen
 
-    r64, x64, out64, near_kink = reference(torch.float64)
     r32, x32, out32, _ = reference(torch.float32)
     # the fused node
     was = _mlp.FUSED_TAIL
@@ -330,43 +347,46 @@ def tail_case(seed):
         _mlp.FUSED_TAIL = was
     what = f"tail M={M} K={K} hidden={hidden} p={p}"
 
-    def check(got, r64_, r32_, name, k=32.0, floor=2e-6):
-        """fused error <= k x the stock float32 error, both against float64 — after setting aside what ONE or two ReLU-kink
-        flips can touch: a pre-activation within rounding of 0 falls on either side of the kink in any float32 evaluation
-        (the fused products sum in another order than torch's), and a flip of element (m, n) moves row m of every gradient
-        with respect to an activation, row n of that layer's weight gradient and, through the BatchNorm sums, column n by
-        ~1/M.  So up to three rows' and three columns' worth of elements are exempt from the tight bound and only have to
-        stay within 5 % of the tensor's scale."""
-        got, r64_, r32_ = got.detach().double().cpu(), r64_.detach().double(), r32_.detach().double()
-        scale = float(r64_.abs().max()) + 1e-30
-        e_f = ((got - r64_).abs() / scale).flatten()
-        e_s = float((r32_ - r64_).abs().max()) / scale
-        rows = got.shape[0] if got.dim() == 2 else 1
-        cols = got.shape[-1] if got.dim() >= 1 else 1
-        exempt = min(e_f.numel() - 1, 3 * (rows + cols)) if got.dim() == 2 else 3
-        srt = torch.sort(e_f, descending=True)[0]
-        tight = float(srt[exempt]) if exempt < srt.numel() else 0.0
-        if tight > max(k * e_s, floor) or float(srt[0]) > 5e-2:
-            if near_kink and float(srt[0]) <= 5e-2 and tight <= max(2e-3, 2.0 / M):
-                ambiguous.append(seed)       # a kink flip in a deep layer reaches every gradient below it at the ~1/M level
-                return
-            raise SystemExit(f"MISMATCH {what} {name}: fused {float(srt[0]):.3e} (beyond the exempt rows/columns {tight:.3e}) vs stock "
-                             f"float32 {e_s:.3e}, relative to max|ref|; pre-activations within 3e-6 of the kink: {near_kink}; seed={seed}")
+    def worst(ref):
+        """(name, fused error, stock error) of the tensor furthest beyond k x stock, errors relative to max|float64|"""
+        r64, x64, out64, _ = ref
+        p64, p32 = dict(r64.named_parameters()), dict(r32.named_parameters())
+        items = [("out", out, out64, out32), ("dx", xd.grad, x64.grad, x32.grad)]
+        for name, q in fs.named_parameters():
+            if q.grad is None or p64[name].grad is None:
+                continue
+            if name.endswith("bias") and float(q.grad.abs().max()) == 0.0:
+                continue                      # a Linear bias in front of a training BatchNorm: exactly zero
+            items.append((name, q.grad, p64[name].grad, p32[name].grad))
+        bad = None
+        for name, got, a64, a32 in items:
+            got, a64, a32 = got.detach().double().cpu(), a64.detach().double(), a32.detach().double()
+            scale = float(a64.abs().max()) + 1e-30
+            e_f, e_s = float((got - a64).abs().max()) / scale, float((a32 - a64).abs().max()) / scale
+            if e_f > max(32.0 * e_s, 1e-5) and (bad is None or e_f > bad[1]):
+                bad = (name, e_f, e_s)
+        return bad
 
-    check(out, out64, out32, "out")
-    check(xd.grad, x64.grad, x32.grad, "dx")
-    p64, p32 = dict(r64.named_parameters()), dict(r32.named_parameters())
-    for name, q in fs.named_parameters():
-        if q.grad is None or p64[name].grad is None:
-            continue
-        if name.endswith("bias") and float(q.grad.abs().max()) == 0.0:
-            continue                          # a Linear bias in front of a training BatchNorm: exactly zero
-        check(q.grad, p64[name].grad, p32[name].grad, name)
+    ref0 = reference(torch.float64)
+    bad = worst(ref0)
+    if bad is None:
+        return
+    near_kink = ref0[3]
+    if 0 < near_kink <= 4:
+        # (the stock float32 pass is the yardstick only; its own kink decisions are those of float32 torch)
+        for bits in range(1, 1 << near_kink):
+            alt = reference(torch.float64, {j for j in range(near_kink) if bits >> j & 1})
+            if worst(alt) is None:
+                ambiguous.append(seed)
+                return
+    raise SystemExit(f"MISMATCH {what} {bad[0]}: fused {bad[1]:.3e} vs stock float32 {bad[2]:.3e} (relative to max|ref|); "
+                     f"pre-activations within {KINK:g} of the kink: {near_kink}, no assignment of them reproduces the fused result; seed={seed}")
 
 
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-    for s in range(cases):
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # python tools/fuzz.py 500 1000: seeds 1000 .. 1499 of every family
+    for s in range(first, first + cases):
         one(1000 + s)
         for j in range(4):
             gemm_case(100000 + 4 * s + j)
@@ -375,4 +395,4 @@ if __name__ == "__main__":
         tail_case(900000 + s)
         if s % 25 == 24:
             print(f"{s + 1} cases ok", flush=True)
-    print(f"FUZZ_OK ({len(ambiguous)} tail cases with a pre-activation on the ReLU kink judged by the loose bound: seeds {ambiguous[:8]})")
+    print(f"FUZZ_OK ({len(ambiguous)} tail cases matched float64 with a ReLU decision on the kink taken the other way: seeds {ambiguous[:8]})")
