@@ -440,12 +440,17 @@ struct SlimProblem {      // what varies between the problems of one launch; the
   int splitk, epi, alignedA, alignedB, gx, gy, end, pad_;
 };
 struct MultiArgs {
-  int n;
+  int n, total;
   SlimProblem p[kMaxProblems];
 };
 template <int TA, int BT>
 __global__ __launch_bounds__(256) void k_gemm_f32_multi(MultiArgs m) {
-  const int id = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2.  Logical ids run
+  // (slice, row tile, column tile) with the column tile fastest: neighbours share the A slab of their K-slice — so every XCD
+  // gets a contiguous run of logical ids (the grid is rounded up to a multiple of 8; the padding ids leave at once).
+  const int per_xcd = (m.total + 7) >> 3;
+  const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || id >= m.total) return;
   int j = 0;
   while (j + 1 < m.n && id >= m.p[j].end) ++j;
   const SlimProblem q = m.p[j];
@@ -598,9 +603,10 @@ int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, i
   }
   if (m.n == 0) return MI_OK;
   for (int j = m.n; j < kMaxProblems; ++j) m.p[j] = m.p[m.n - 1];
+  m.total = (int)wgs;
   hipEvent_t ea, eb;
   const bool prof = mi::prof_acquire("gemm_f32_multi", &ea, &eb);
-  const dim3 grid((unsigned)wgs);
+  const dim3 grid((unsigned)((wgs + 7) / 8 * 8));
 #define GO(TA, BT)                                                                                            \
   do {                                                                                                        \
     if (prof) hipExtLaunchKernelGGL((k_gemm_f32_multi<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, m); \
