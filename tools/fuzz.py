@@ -43,16 +43,21 @@ def one(seed):
     W0 = torch.randn(Nr, D, generator=g)
     p, q = torch.nn.Parameter(W0.clone().to(DEV)), torch.nn.Parameter(W0.clone())
     o1, o2 = optim.SparseAdam([p], lr=0.01, capturable=bool(seed & 1)), torch.optim.SparseAdam([q], lr=0.01)
+    well = torch.ones(Nr, D, dtype=torch.bool)
     for _ in range(2):
         r = (Nr * torch.rand(n, generator=g).pow(ri(1, 3))).long().clamp_(max=Nr - 1)
         v = torch.randn(n, D, generator=g)
         p.grad = torch.sparse_coo_tensor(r.view(1, -1).to(DEV), v.to(DEV), (Nr, D), check_invariants=False)
         q.grad = torch.sparse_coo_tensor(r.view(1, -1), v, (Nr, D))
         o1.step(), o2.step()
-    # Adam divides by sqrt(v): an element whose duplicate gradients nearly cancel moves by up to a whole lr for a rounding-size
-    # change of the sum (two summation orders) — the comparison is on the scale of a step (3 % of lr); a wrong update is off by
-    # a step or more (tests/test_fullsize_properties_gpu.py brackets the same effect rigorously against float64)
-    close(p, q, 1e-4, 3e-4, f"sparse adam D={D} n={n} N={Nr}", seed)
+        # Adam divides by sqrt(v): where a row's duplicate gradients nearly cancel (|sum| at rounding level) the update is
+        # ill-conditioned — a rounding-size change of the sum (two summation orders) moves it by up to a whole lr.  Those
+        # elements are left out; everything else has to agree tightly.
+        g64 = torch.zeros(Nr, D, dtype=torch.float64).index_add_(0, r, v.double())
+        touched = torch.zeros(Nr, dtype=torch.bool).index_fill_(0, r, True)
+        well &= ~(touched[:, None] & (g64.abs() < 1e-4))
+    pm, qm = p.detach().cpu() * well, q.detach() * well
+    close(pm, qm, 1e-4, 1e-5, f"sparse adam D={D} n={n} N={Nr}", seed)
     # ---- dense Adam over a few odd tensors
     shapes = [(ri(1, 70), ri(1, 70)) for _ in range(ri(1, 5))] + [(ri(1, 5000),)]
     ps = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
@@ -363,7 +368,8 @@ def tail_case(seed):
             got, a64, a32 = got.detach().double().cpu(), a64.detach().double(), a32.detach().double()
             scale = float(a64.abs().max()) + 1e-30
             e_f, e_s = float((got - a64).abs().max()) / scale, float((a32 - a64).abs().max()) / scale
-            if e_f > max(32.0 * e_s, 1e-5) and (bad is None or e_f > bad[1]):
+            # (a one-element tensor — the head's bias gradient, sum_m g — is a sum that may cancel: its own magnitude is no scale)
+            if e_f > max(32.0 * e_s, 1e-5 if a64.numel() > 8 else 1e-3) and (bad is None or e_f > bad[1]):
                 bad = (name, e_f, e_s)
         return bad
 
