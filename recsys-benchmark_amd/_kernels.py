@@ -698,6 +698,16 @@ def auto_splitk(M, N, K, batch=1):
     return 1
 
 
+def multi_splits(chunk):
+    """K-slices of every problem of ONE multi-problem launch.  Chosen for the launch, not per problem: together the problems
+    should come to ~2.5 workgroups per CU (640) — each slice is a workgroup that adds a whole 64x64 tile with float atomics, so
+    more slices than that only buy atomics (C3: 4 128 -> 696 workgroups, 78 -> 66 us).  A slice keeps >= 4 k-tiles of 32;
+    deterministic mode does not split (the slices meet in atomics); an explicit q["splitk"] is kept."""
+    tiles = sum(-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in chunk)
+    share = 1 if DETERMINISTIC else max(1, round(640 / max(tiles, 1)))
+    return [q.get("splitk", 0) or max(1, min(share, -(-q["K"] // 32) // 4, 65535 // max(q.get("batch", 1), 1))) for q in chunk]
+
+
 def gemm_multi(problems, transA=False, transB=False):
     """problems: dicts with A, B, C (torch buffers / views), M, N, K, lda, ldb, ldc and optionally batch, sA, sB, sC, splitk
     (0 = automatic), accumulate — all the same operand layout, independent of each other: ONE launch per 16 problems
@@ -709,13 +719,9 @@ def gemm_multi(problems, transA=False, transB=False):
     for i in range(0, len(problems), MAX_GEMM_PROBLEMS):
         chunk = problems[i:i + MAX_GEMM_PROBLEMS]
         arr = (_GemmProblem * len(chunk))()
-        # K-slices for the LAUNCH, not per problem: together the problems should come to ~2.5 workgroups per CU — each
-        # slice is a workgroup that adds a whole 64x64 tile with float atomics, so more slices than that only buy atomics
-        tiles = sum(-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in chunk)
-        share = 1 if DETERMINISTIC else max(1, round(640 / max(tiles, 1)))
-        for d, q in zip(arr, chunk):
+        splits = multi_splits(chunk)
+        for d, q, sk in zip(arr, chunk, splits):
             batch = q.get("batch", 1)
-            sk = q.get("splitk", 0) or max(1, min(share, -(-q["K"] // 32) // 4, 65535 // max(batch, 1)))
             d.A, d.B, d.C = q["A"].data_ptr(), q["B"].data_ptr(), q["C"].data_ptr()
             d.M, d.N, d.K = q["M"], q["N"], q["K"]
             d.lda, d.ldb, d.ldc, d.batch = q["lda"], q["ldb"], q["ldc"], batch

@@ -345,3 +345,23 @@ def test_tt_approx_uniform_cores_are_the_references(name):
         assert c.dtype == torch.float32 and torch.equal(c.data, g.t(f"param/tt_cores.{i}")), f"core {i}"
     with pytest.raises(AssertionError):
         TTRecTorch(100, 8, [4], tt_p_shapes=[10, 10], tt_q_shapes=[2, 4], weight_dist="approx-uniform")
+
+
+def test_multi_problem_launch_splits_for_the_whole_launch(monkeypatch):
+    """Host logic of mi_gemm_f32_multi's K-slices (recsys-benchmark_amd/_kernels.py: multi_splits): sized for the launch, a
+    slice keeps >= 4 k-tiles, explicit values are kept, deterministic mode does not split."""
+    from recsys_benchmark_amd import _kernels
+
+    M, d, E, r = 4096, 352, 4, 64
+    layer = [dict(M=E * r, N=d, K=M), dict(M=r, N=r, K=M, batch=E), dict(M=d, N=r, K=M, batch=E), dict(M=E, N=d, K=M)]
+    c3 = layer * 3                                          # the 12 weight gradients of a DCN-Mix backward
+    sp = _kernels.multi_splits(c3)
+    tiles = [-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in c3]
+    assert len(set(sp)) == 1 and sp[0] == 4                 # 174 tiles -> round(640 / 174)
+    assert 500 <= sum(t * k for t, k in zip(tiles, sp)) <= 800
+    tail = [dict(M=400, N=416, K=M), dict(M=400, N=400, K=M), dict(M=400, N=400, K=M)]
+    assert _kernels.multi_splits(tail) == [4, 4, 4]         # 147 tiles
+    assert _kernels.multi_splits([dict(M=64, N=64, K=96)]) == [1]           # 3 k-tiles: never below 4 per slice
+    assert _kernels.multi_splits([dict(M=64, N=64, K=M, splitk=7)]) == [7]
+    monkeypatch.setattr(_kernels, "DETERMINISTIC", True)
+    assert _kernels.multi_splits(c3) == [1] * 12
