@@ -55,3 +55,31 @@ def test_product_fails_loudly_without_gpu_tensor():
     m = pkg.DeepFM([3, 4], 4, [8])
     with pytest.raises(pkg.MI355XLibraryError):
         m(torch.tensor([[0, 1]]))
+
+
+def test_header_compiles_as_plain_c_and_struct_layouts_match_the_bindings(tmp_path):
+    """include/mi355x_recsys.h is a C header (gcc -std=c99 takes it as is), and the one struct that crosses the boundary by
+    pointer — mi_gemm_problem — has the size and field offsets the ctypes mirror in _kernels.py assumes."""
+    import shutil
+    import subprocess
+
+    from recsys_benchmark_amd import _kernels
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+
+        pytest.skip("no gcc in this environment")
+    fields = [name for name, _ in _kernels._GemmProblem._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "mi355x_recsys.h")}"',
+             'int main(void) {', '  printf("%zu\\n", sizeof(mi_gemm_problem));']
+    lines += [f'  printf("%zu\\n", offsetof(mi_gemm_problem, {f}));' for f in fields]
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_kernels._GemmProblem)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_kernels._GemmProblem, f).offset == off, f
