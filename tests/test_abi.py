@@ -83,3 +83,38 @@ def test_header_compiles_as_plain_c_and_struct_layouts_match_the_bindings(tmp_pa
     assert out[0] == ctypes.sizeof(_kernels._GemmProblem)
     for f, off in zip(fields, out[1:]):
         assert getattr(_kernels._GemmProblem, f).offset == off, f
+
+
+def test_binding_argument_types_match_header():
+    """Every argument of every entry point has the ctypes kind its C declaration asks for (pointer / int32 / int64 / float /
+    double) — a drifted width would pass the arity check and corrupt the call."""
+    sizes = {"ptr": ctypes.sizeof(ctypes.c_void_p)}
+
+    def c_kind(arg: str) -> str:
+        arg = re.sub(r"/\*.*?\*/", "", arg, flags=re.S).strip()
+        if "*" in arg:
+            return "ptr"
+        for key, kind in (("int64_t", "i64"), ("int32_t", "i32"), ("double", "f64"), ("float", "f32"), ("int ", "i32")):
+            if key in arg + " ":
+                return kind
+        raise AssertionError(f"unrecognised C argument: {arg!r}")
+
+    def py_kind(t) -> str:
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) == "P":
+            return "ptr"
+        if isinstance(t, type) and issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return {ctypes.c_int32: "i32", ctypes.c_int64: "i64", ctypes.c_float: "f32", ctypes.c_double: "f64",
+                ctypes.c_int: "i32", ctypes.c_longlong: "i64"}[t]
+
+    text = ""
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text += open(h).read()
+    checked = 0
+    for name, args in DECL.findall(text):
+        args = re.sub(r"/\*.*?\*/", "", args, flags=re.S).strip()
+        want = [] if args in ("", "void") else [c_kind(a) for a in args.split(",") if a.strip()]
+        got = [py_kind(t) for t in _lib.SIGNATURES[name]]
+        assert got == want, f"{name}: bindings {got} vs header {want}"
+        checked += len(want)
+    assert checked > 500 and sizes["ptr"] == 8
