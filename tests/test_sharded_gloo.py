@@ -38,6 +38,8 @@ def _worker(rank, world, port, dims, D, hidden, B, slack, out_q):
 
         torch.manual_seed(7)
         model = ShardedDeepFM(dims, D, hidden, p_dropout=0.0, use_batchnorm=False, ops=TorchOps, bucket_slack=slack)
+        # no RCCL under gloo: the library's own communicator is not created and torch.distributed carries the collectives
+        assert model.__dict__.get("_comm") is None
         n_local = local_num_rows(N, rank, world)
         assert model.embedding_shard.shape[0] == n_local + 1          # + the sink row
         model.load_full_tables(W_full, w1_full)
