@@ -200,3 +200,27 @@ def test_panel_gemm_declines_what_it_does_not_cover():
     assert not _kernels.gemm_panel(A, 6, B, 6, 0, C, 8, 8, 8, 6)                   # K % 4
     assert not _kernels.gemm_panel(A, 6, B, 6, 0, C, 8, 8, 8, 4, epi="mul_dtanh")   # an epilogue it does not have
     assert not _kernels.gemm_panel(A[:, 1:], 6, B, 6, 0, C, 8, 8, 8, 4)             # misaligned operand
+
+
+def test_multi_problem_launch_reduction_major_form():
+    """Every problem A[k][m]^T B[k][n] with M, N multiples of 4 and aligned operands takes the kernel that keeps the tiles as
+    they lie in memory (no transposition): ragged tiles (100 x 68), a 4-row problem, K tails (45, 1000), one k-tile, batched
+    column slices, accumulate, explicit and automatic K-slices; integer-valued data: exact."""
+    gen = torch.Generator().manual_seed(77)
+    shapes = [(400, 416, 4096), (100, 68, 45), (4, 352, 4096), (64, 64, 32), (256, 352, 1000), (352, 64, 4096), (8, 4, 7)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, B = _mk((K, M), gen), _mk((K, N), gen)
+        acc = i % 3 == 2
+        C = _mk((M, N), gen).to(DEV) if acc else torch.zeros(M, N, device=DEV)
+        ref = A.t() @ B + (C.cpu() if acc else 0)
+        probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, accumulate=acc,
+                          splitk=(0, 1, 3)[i % 3]))
+        refs.append(ref)
+    A, B = _mk((512, 3 * 64), gen), _mk((512, 3 * 48), gen)
+    C = torch.zeros(3, 64, 48, device=DEV)
+    probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=64, N=48, K=512, lda=192, ldb=144, ldc=48, batch=3, sA=64, sB=48, sC=64 * 48))
+    refs.append(torch.stack([A[:, 64 * e:64 * e + 64].t() @ B[:, 48 * e:48 * e + 48] for e in range(3)]))
+    _kernels.gemm_multi(probs, transA=True)
+    for q, ref in zip(probs, refs):
+        assert torch.equal(q["C"].cpu(), ref), (q["M"], q["N"], q["K"])
