@@ -203,9 +203,9 @@ def test_panel_gemm_declines_what_it_does_not_cover():
 
 
 def test_multi_problem_launch_reduction_major_form():
-    """Every problem A[k][m]^T B[k][n] with M, N multiples of 4 and aligned operands takes the kernel that keeps the tiles as
-    they lie in memory (no transposition): ragged tiles (100 x 68), a 4-row problem, K tails (45, 1000), one k-tile, batched
-    column slices, accumulate, explicit and automatic K-slices; integer-valued data: exact."""
+    """The weight-gradient form A[k][m]^T B[k][n] (both operands reduction-major) in one multi-problem launch: ragged tiles
+    (100 x 68), a 4-row problem, K tails (45, 1000), one k-tile, batched column slices, accumulate, explicit and automatic
+    K-slices; integer-valued data: exact."""
     gen = torch.Generator().manual_seed(77)
     shapes = [(400, 416, 4096), (100, 68, 45), (4, 352, 4096), (64, 64, 32), (256, 352, 1000), (352, 64, 4096), (8, 4, 7)]
     probs, refs = [], []
