@@ -37,7 +37,9 @@ extern "C" {
 
 #define MI_API __attribute__((visibility("default")))
 
-#define MI_ABI_VERSION 1
+/* 2: round 3 — mi_sort_field_rows / mi_bpr_* / mi_rowsq_* had gained arguments under version 1 (callers built against
+ * that header must rebuild); mi_gather_fm_fwd_ld, mi_sparse_adam_sorted's row stride and the later additions are new. */
+#define MI_ABI_VERSION 2
 
 #define MI_OK 0
 #define MI_ERR_INVALID_ARG (-1)  /* null pointer, negative size, bad enum */
@@ -70,6 +72,18 @@ MI_API int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets,
                             float *emb_out, float *yfm_out, int64_t *rows_out,
                             int64_t B, int32_t F, int32_t D, int64_t N,
                             int32_t *err, void *stream);
+
+/* The same lookup over tables with a ROW STRIDE (src/models/deepfm.py:47-51 declares the two tables; this is their
+ * storage, not their arithmetic): row n of W starts at W + n*ldw floats (ldw >= D, a multiple of 4), the first-order
+ * weight of row n is w1[n*ldw1].  (ldw, ldw1) = (D, 1) is mi_gather_fm_fwd.  (32, 32) with w1 = W + 16 reads ONE packed
+ * table fp32[N,32] = {16 embedding floats, first-order weight, padding}: a lookup then touches one 128-byte line
+ * instead of two unrelated 64-byte sectors (DeepFM.pack_tables() on the Python side; both parameters become views of
+ * the packed buffer and state_dict() still emits the reference's two tensors). */
+MI_API int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets,
+                               const float *W, int64_t ldw, const float *w1, int64_t ldw1, const float *bias,
+                               float *emb_out, float *yfm_out, int64_t *rows_out,
+                               int64_t B, int32_t F, int32_t D, int64_t N,
+                               int32_t *err, void *stream);
 
 /* Backward of the above, row-sparse form (the MI355X-native default):
  *   gvals[b,f,:] = g_emb[b,f,:] + g_y[b] * (S_b - emb[b,f,:]),  S_b = sum_f emb
@@ -482,6 +496,13 @@ MI_API int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm
                                  float *exp_avg_sq, float *acc, int64_t n, int32_t D,
                                  int64_t N, float step_size, const float *step_size_dev,
                                  double beta1, double beta2, float eps, void *stream);
+/* the same step on a table with a row stride (row r of W starts at W + r*ldw floats, ldw >= D; exp_avg / exp_avg_sq stay
+ * contiguous [N,D]): the packed DeepFM tables of mi_gather_fm_fwd_ld */
+MI_API int mi_sparse_adam_sorted_ld(const int64_t *rows_sorted, const int64_t *perm,
+                                    const float *vals, float *W, int64_t ldw, float *exp_avg,
+                                    float *exp_avg_sq, float *acc, int64_t n, int32_t D,
+                                    int64_t N, float step_size, const float *step_size_dev,
+                                    double beta1, double beta2, float eps, void *stream);
 /* mi_coalesce_rows_sorted: the deterministic dense gradient of a table out of its row-form gradient (what the reference's
  *   CPU index_add accumulates in a fixed order, src/models/embeddings/base.py:74-75 through autograd): G[row,:] = sum of
  *   vals[perm[i],:] over the sorted positions with rows_sorted[i] == row, added in a fixed order (the segmented sums of

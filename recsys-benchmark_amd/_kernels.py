@@ -18,6 +18,24 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _float4_rows(D: int) -> bool:
+    """Row widths the float4 kernels take (csrc: vec_ok): D = 4 * 2^k <= 256."""
+    return D % 4 == 0 and 4 <= D <= 256 and ((D // 4) & (D // 4 - 1)) == 0
+
+
+def _row_strided(t: torch.Tensor, align: int = 4):
+    """(tensor, row stride in floats) of a 2-D fp32 table the kernels can read in place: unit stride inside a row, any
+    row stride that is a multiple of `align` floats (4 keeps float4 row accesses 16-byte aligned) — a column-slice view
+    of a packed table, DeepFM.pack_tables(); anything else is made contiguous."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if (t.dim() == 2 and t.shape[0] > 1 and (t.shape[1] == 1 or t.stride(1) == 1) and t.stride(0) >= t.shape[1]
+            and t.stride(0) % align == 0 and (t.data_ptr() % (4 * align)) == 0):
+        return t, int(t.stride(0))
+    t = t.contiguous()
+    return t, int(t.shape[1]) if t.dim() == 2 else 1
+
+
 def _i64c(t: torch.Tensor) -> torch.Tensor:
     # the reference's datasets hand over int32 or int64 ids and `x + offsets`
     # promotes to int64 (src/models/deepfm.py:88); same here.
@@ -82,7 +100,12 @@ class GatherFM(torch.autograd.Function):
         lib = _lib.load()
         idx = _i64c(idx)
         offsets = _i64c(offsets.reshape(-1))
-        Wc, w1c = _f32c(W), _f32c(w1)
+        if _float4_rows(W.shape[-1]):
+            Wc, ldw = _row_strided(W)
+            w1c, ldw1 = _row_strided(w1.reshape(w1.shape[0], -1) if w1.dim() != 2 else w1, align=1)
+        else:       # widths the float4 kernels do not cover run on the scalar kernels, which read the two plain tensors
+            Wc, w1c = _f32c(W), _f32c(w1)
+            ldw, ldw1 = int(Wc.shape[-1]), 1
         if idx.dim() != 2 or idx.shape[1] != offsets.numel():
             raise ValueError(f"idx must be [B, {offsets.numel()}], got {tuple(idx.shape)}")
         B, F = idx.shape
@@ -93,12 +116,12 @@ class GatherFM(torch.autograd.Function):
         yfm = torch.empty((B,), dtype=torch.float32, device=dev)
         rows = torch.empty((B, F), dtype=torch.int64, device=dev)
         _lib.check(
-            lib.mi_gather_fm_fwd(
-                idx.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), w1c.data_ptr(), _lib.ptr(bias),
+            lib.mi_gather_fm_fwd_ld(
+                idx.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1, _lib.ptr(bias),
                 emb.data_ptr(), yfm.data_ptr(), rows.data_ptr(), B, F, D, N,
                 _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev),
             ),
-            "mi_gather_fm_fwd",
+            "mi_gather_fm_fwd_ld",
         )
         if sparse_W or sparse_w1 or DETERMINISTIC:
             note_field_layout(rows, offsets, N)

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mi_abi_version": [],
     "mi_strerror": [ctypes.c_int],
     "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
+    "mi_gather_fm_fwd_ld": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
     "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
     "mi_gather_rows_fwd": [_p, _p, _p, _i64, _i32, _i64, _p, _p],
@@ -56,6 +57,8 @@ SIGNATURES = {
                                _p],
     "mi_sparse_adam_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
                               ctypes.c_double, ctypes.c_float, _p],
+    "mi_sparse_adam_sorted_ld": [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _i64, ctypes.c_float, _p, ctypes.c_double,
+                                 ctypes.c_double, ctypes.c_float, _p],
     "mi_coalesce_rows_sorted": [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_sort_field_rows_workspace_bytes": [_i64, _i32],
     "mi_sort_field_rows": [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p],
@@ -153,7 +156,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
-        if lib.mi_abi_version() != 1:
+        if lib.mi_abi_version() != 2:
             raise MI355XLibraryError("libmi355x_recsys.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

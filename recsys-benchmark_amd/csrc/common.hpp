@@ -60,6 +60,12 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// non-temporal 16-B store (global_store_dwordx4 ... nt): for streams nobody in the kernel reads back
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float *p, float4 v) {
+  f32x4_t x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<f32x4_t *>(p));
+}
 
 // "last workgroup sums the partials" without agent-scope fences (on gfx950 a __threadfence() is an L2 write-back +
 // invalidate per workgroup: the loss kernels took 13 us with it).  ONE lane per workgroup publishes: the partial travels

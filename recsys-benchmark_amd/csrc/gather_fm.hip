@@ -23,14 +23,22 @@ namespace {
 using namespace mi;
 
 // ---------------------------------------------------------------- forward ----
-template <int LPR, int NIT>
+// SHFL (F <= 64): the sample's F ids arrive by ONE coalesced load (lane l < F takes idx[b, l] + offsets[l]) and reach
+// the row slots by shuffles — one dependent vector-memory instruction in front of the row gathers instead of NIT id
+// loads plus NIT offset loads (measured -0.45 us of 5.8 at the headline shape, tools/probe_gather3.hip) — and
+// rows_out is one coalesced store.  emb is written with non-temporal stores: nobody in this kernel reads it back, and
+// what is not left dirty in L2 is not written back at the kernel's end (-0.4 us).
+// ldw / ldw1: floats between consecutive rows of W / w1.  (D, 1) for the reference's two tensors; (32, 32) when both
+// are views of ONE packed table fp32[N, 32] = {16 embedding floats, w1, padding} — a lookup then touches one 128-B
+// line instead of two unrelated 64-B sectors (DeepFM.pack_tables()); (D + 4, D + 4) for the packed rows a sharded
+// lookup received (route.hip).
+// (SHFL is ignored by the generic NIT = 0 form.)
+template <int LPR, int NIT, bool SHFL>
 __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
     const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
     int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err) {
-  // ldw / ldw1: floats between consecutive rows of W / w1 (D and 1 for the reference's tables;
-  // D + 4 for both when they are the packed rows a sharded lookup received, see route.hip)
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63;
@@ -39,6 +47,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const float bv = bias ? bias[0] : 0.f;
   int bad = 0;
+  int64_t myoff = 0;
+  if constexpr (SHFL) myoff = (offsets && lane < F) ? offsets[lane] : 0;
 
   for (int64_t b = wave0; b < B; b += nwaves) {
     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -49,11 +59,22 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
       bool act[NIT], ok[NIT];
       float4 v[NIT];
       float l[NIT];
+      if constexpr (SHFL) {
+        const int64_t mine = lane < F ? idx[base + lane] + myoff : 0;
+        if (rows_out && lane < F) rows_out[base + lane] = mine;
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int f = r + k * RS;
-        act[k] = f < F;
-        row[k] = act[k] ? idx[base + f] + (offsets ? offsets[f] : 0) : 0;
+        for (int k = 0; k < NIT; ++k) {
+          const int f = r + k * RS;
+          act[k] = f < F;
+          row[k] = __shfl(mine, f & 63);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int f = r + k * RS;
+          act[k] = f < F;
+          row[k] = act[k] ? idx[base + f] + (offsets ? offsets[f] : 0) : 0;
+        }
       }
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
@@ -66,8 +87,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
       for (int k = 0; k < NIT; ++k) {
         const int f = r + k * RS;
         if (act[k]) {
-          st4(emb + (base + f) * D + q * 4, v[k]);
-          if (rows_out && q == 0) rows_out[base + f] = row[k];
+          st4_nt(emb + (base + f) * D + q * 4, v[k]);
+          if (!SHFL && rows_out && q == 0) rows_out[base + f] = row[k];
         }
         S.x += v[k].x; S.y += v[k].y; S.z += v[k].z; S.w += v[k].w;
         ss += dot4(v[k], v[k]);
@@ -134,15 +155,40 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
 }
 
-// bias gradient = sum_b g_y[b] (the bias is added to every sample's y_fm): workgroup 0 of a backward kernel
-// adds it up in a fixed order (deterministic, no atomics, no zero-fill) before its own share of the rows —
-// one launch less per step than a separate reduction.
-__device__ __forceinline__ void bias_grad_block0(const float *__restrict__ g_y, int64_t B, float *__restrict__ gbias) {
-  if (!gbias || blockIdx.x != 0) return;
+// bias gradient = sum_b g_y[b] (the bias is added to every sample's y_fm): ONE EXTRA workgroup of a backward launch —
+// workgroup 0, the first one dispatched; the launcher adds it when gbias is given — adds it up in a fixed order
+// (deterministic, no atomics, no zero-fill, no separate launch) and does nothing else.  Round 2 had workgroup 0 sum it
+// with one scalar load per thread and trip IN FRONT of its share of the rows: a 3.4 us kernel then ended 1.2 us late on
+// that one workgroup (and at B = 65 536 the 256 dependent trips doubled the kernel: 55 -> 105 us,
+// tools/probe_gather3.hip).  Now: float4 loads, four independent partial sums per thread, the other workgroups' ids
+// shifted down by one.  Returns true in that workgroup; blk / nblk = this workgroup's index among, and the number of,
+// the workgroups that share the rows.
+__device__ __forceinline__ bool bias_grad_block(const float *__restrict__ g_y, int64_t B, float *__restrict__ gbias,
+                                                int &blk, int &nblk) {
+  blk = blockIdx.x;
+  nblk = gridDim.x;
+  if (!gbias) return false;
+  nblk = gridDim.x - 1;
+  blk = (int)blockIdx.x - 1;
+  if (blockIdx.x != 0) return false;
   __shared__ float part[kWavesPerBlock];
-  float s = 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += kBlock) s += g_y[b];
-  s = wave_sum(s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int64_t B4 = aligned16(g_y) ? (B & ~(int64_t)3) : 0;
+  int64_t b = (int64_t)threadIdx.x * 4;
+  for (; b + 3 * kBlock * 4 < B4; b += 4 * kBlock * 4) {         // four float4 loads in flight per thread
+    const float4 a0 = ld4(g_y + b), a1 = ld4(g_y + b + kBlock * 4), a2 = ld4(g_y + b + 2 * kBlock * 4),
+                 a3 = ld4(g_y + b + 3 * kBlock * 4);
+    s0 += (a0.x + a0.y) + (a0.z + a0.w);
+    s1 += (a1.x + a1.y) + (a1.z + a1.w);
+    s2 += (a2.x + a2.y) + (a2.z + a2.w);
+    s3 += (a3.x + a3.y) + (a3.z + a3.w);
+  }
+  for (; b < B4; b += kBlock * 4) {
+    const float4 a0 = ld4(g_y + b);
+    s0 += (a0.x + a0.y) + (a0.z + a0.w);
+  }
+  for (int64_t t = B4 + threadIdx.x; t < B; t += kBlock) s1 += g_y[t];
+  float s = wave_sum((s0 + s1) + (s2 + s3));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -150,6 +196,7 @@ __device__ __forceinline__ void bias_grad_block0(const float *__restrict__ g_y, 
     for (int j = 0; j < kWavesPerBlock; ++j) t += part[j];
     gbias[0] = t;
   }
+  return true;
 }
 
 // ----------------------------------------------------- backward, row form ----
@@ -163,11 +210,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows(
     int64_t B, int F, const int64_t *__restrict__ slot, int64_t nslot, float *__restrict__ gbias) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
-  bias_grad_block0(g_y, B, gbias);
+  int blk, nblk;
+  if (bias_grad_block(g_y, B, gbias, blk, nblk)) return;
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, r = lane / LPR;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t wave0 = (int64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)nblk * kWavesPerBlock;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int64_t b = wave0; b < B; b += nwaves) {
@@ -244,10 +292,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_rows_anyD(
     const float *__restrict__ emb, const float *__restrict__ g_y,
     const float *__restrict__ g_emb, float *__restrict__ gvals, float *__restrict__ g1vals,
     int64_t B, int F, int D, float *__restrict__ gbias) {
-  bias_grad_block0(g_y, B, gbias);
+  int blk, nblk;
+  if (bias_grad_block(g_y, B, gbias, blk, nblk)) return;
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t wave0 = (int64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)nblk * kWavesPerBlock;
   for (int64_t b = wave0; b < B; b += nwaves) {
     const int64_t base = b * F;
     const float gy = g_y[b];
@@ -278,12 +327,13 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense(
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   __shared__ float slab[kWavesPerBlock][kWave * 4];
-  bias_grad_block0(g_y, B, gbias);
+  int blk, nblk;
+  if (bias_grad_block(g_y, B, gbias, blk, nblk)) return;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int q = lane % LPR, r = lane / LPR;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wib;
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t wave0 = (int64_t)blk * kWavesPerBlock + wib;
+  const int64_t nwaves = (int64_t)nblk * kWavesPerBlock;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float *my = slab[wib];
   constexpr int NSTEP = NIT > 0 ? NIT : 1;
@@ -336,10 +386,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense_anyD(
     const int64_t *__restrict__ rows, const float *__restrict__ emb,
     const float *__restrict__ g_y, const float *__restrict__ g_emb,
     float *__restrict__ gW, float *__restrict__ gw1, int64_t B, int F, int D, int64_t N, float *__restrict__ gbias) {
-  bias_grad_block0(g_y, B, gbias);
+  int blk, nblk;
+  if (bias_grad_block(g_y, B, gbias, blk, nblk)) return;
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t wave0 = (int64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)nblk * kWavesPerBlock;
   for (int64_t b = wave0; b < B; b += nwaves) {
     const int64_t base = b * F;
     const float gy = g_y[b];
@@ -511,25 +562,40 @@ inline int nit_for(int F, int LPR) {
 
 extern "C" {
 
-int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W, const float *w1,
-                     const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
-                     int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
-  if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
+int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                        int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
+                        int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+  if (B < 0 || F < 0 || D <= 0 || N < 0 || ldw < D || ldw1 < 1) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!idx || !offsets || !W || !w1 || !emb_out || !yfm_out) return MI_ERR_INVALID_ARG;
   const int grid = grid_for_waves(B);
-  if (vec_ok(D) && aligned16(W) && aligned16(emb_out)) {
+  if (vec_ok(D) && aligned16(W) && (ldw & 3) == 0 && aligned16(emb_out)) {
     const int lpr = D / 4, nit = nit_for(F, lpr);
-#define CALL(LPR, NIT)                                                                       \
-  MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT>), grid, kBlock, stream, idx, offsets, \
-            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, (int64_t)D, (int64_t)1, err)
-    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+    if (nit > 0 && F <= kWave) {
+#define CALL(LPR, NIT)                                                                                \
+  MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT, true>), grid, kBlock, stream, idx, offsets,   \
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err)
+      MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
+    } else {
+#define CALL(LPR, NIT)                                                                               \
+  MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT, false>), grid, kBlock, stream, idx, offsets, \
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err)
+      MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+    }
   } else {
+    if (ldw != D || ldw1 != 1) return MI_ERR_UNSUPPORTED;      // the scalar fallback reads the reference's two tensors only
     MI_LAUNCH("gather_fm_fwd", k_gather_fm_fwd_anyD, grid, kBlock, stream, idx, offsets, W, w1,
               bias, emb_out, yfm_out, rows_out, B, F, D, N, err);
   }
   return launch_status();
+}
+
+int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W, const float *w1,
+                     const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
+                     int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+  return mi_gather_fm_fwd_ld(idx, offsets, W, D, w1, 1, bias, emb_out, yfm_out, rows_out, B, F, D, N, err, stream);
 }
 
 int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb, float *gvals,
@@ -537,7 +603,7 @@ int mi_gather_fm_bwd_rows(const float *emb, const float *g_y, const float *g_emb
   if (B < 0 || F < 0 || D <= 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!emb || !g_y || !gvals || !g1vals) return MI_ERR_INVALID_ARG;
-  const int grid = grid_for_waves(B);
+  const int grid = grid_for_waves(B) + (gbias ? 1 : 0);      // + the workgroup that only sums the bias gradient
   if (vec_ok(D) && aligned16(emb) && aligned16(gvals) && (!g_emb || aligned16(g_emb))) {
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                      \
@@ -558,7 +624,7 @@ int mi_gather_fm_bwd_dense(const int64_t *rows, const float *emb, const float *g
   if (B < 0 || F < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!rows || !emb || !g_y || !gW || !gw1) return MI_ERR_INVALID_ARG;
-  const int grid = grid_for_waves(B);
+  const int grid = grid_for_waves(B) + (gbias ? 1 : 0);      // + the workgroup that only sums the bias gradient
   if (vec_ok(D) && aligned16(emb) && (!g_emb || aligned16(g_emb))) {
     const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                         \
@@ -624,12 +690,21 @@ int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const f
   const int grid = grid_for_waves(B);
   const int lpr = D / 4, nit = nit_for(F, lpr);
   const int64_t ld = D + 4;
-#define CALL(LPR, NIT)                                                                        \
-  MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT>), grid, kBlock, stream, slot,           \
-            (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr, \
+  if (nit > 0 && F <= kWave) {
+#define CALL(LPR, NIT)                                                                                 \
+  MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT, true>), grid, kBlock, stream, slot,              \
+            (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr,        \
             B, F, nrows, ld, ld, err)
-  MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
+  } else {
+#define CALL(LPR, NIT)                                                                               \
+  MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT, false>), grid, kBlock, stream, slot,           \
+            (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr,      \
+            B, F, nrows, ld, ld, err)
+    MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
+  }
   return launch_status();
 }
 
@@ -645,7 +720,7 @@ int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_y, cons
     return MI_ERR_LAUNCH;
   if (B == 0) return MI_OK;
   if (!slot || !emb || !g_y) return MI_ERR_INVALID_ARG;
-  const int grid = grid_for_waves(B);
+  const int grid = grid_for_waves(B) + (gbias ? 1 : 0);      // + the workgroup that only sums the bias gradient
   const int lpr = D / 4, nit = nit_for(F, lpr);
 #define CALL(LPR, NIT)                                                                         \
   MI_LAUNCH("slot_fm_bwd", (k_gather_fm_bwd_rows<LPR, NIT, true>), grid, kBlock, stream, emb,  \

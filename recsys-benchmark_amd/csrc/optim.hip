@@ -23,6 +23,7 @@ struct AdamArgs {
   float step_size, omb1, omb2, eps;   // omb = 1 - beta, formed in double by the host (1.f - 0.999f is off by 1.3e-5)
   const float *step_size_dev;   // when given: the step size lives on the device (mi_adam_tick), hipGraph replays
   float *G;                     // when given: no update — the coalesced gradient row is STORED to G[row] (mi_coalesce_rows_sorted)
+  int64_t ldw;                  // floats between consecutive rows of W (D, or the row stride of a packed table); M, V, G: D
 };
 
 // t += 1; step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) in double, like the host computes it in the eager path
@@ -74,21 +75,21 @@ template <> struct Vec<1> {
   static __device__ __forceinline__ Vec zero() { return {0.f}; }
 };
 
-__device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, const Vec<4> &g) {
+__device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, int64_t ow, const Vec<4> &g) {
   if (a.G) { st4(a.G + o, g.v); return; }
-  float4 m = ld4(a.M + o), v = ld4(a.V + o), w = ld4(a.W + o);
+  float4 m = ld4(a.M + o), v = ld4(a.V + o), w = ld4(a.W + ow);
   w.x -= adam1(a, g.v.x, m.x, v.x);
   w.y -= adam1(a, g.v.y, m.y, v.y);
   w.z -= adam1(a, g.v.z, m.z, v.z);
   w.w -= adam1(a, g.v.w, m.w, v.w);
   st4(a.M + o, m);
   st4(a.V + o, v);
-  st4(a.W + o, w);
+  st4(a.W + ow, w);
 }
-__device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, const Vec<1> &g) {
+__device__ __forceinline__ void adam_row(const AdamArgs &a, int64_t o, int64_t ow, const Vec<1> &g) {
   if (a.G) { a.G[o] = g.v; return; }
   float m = a.M[o], v = a.V[o];
-  a.W[o] -= adam1(a, g.v, m, v);
+  a.W[ow] -= adam1(a, g.v, m, v);
   a.M[o] = m;
   a.V[o] = v;
 }
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam(AdamArgs a) {
     if (r > 0 && before) continue;                                   // not the first of its segment in this pass
     const int64_t pe = t * RS + RS;                                  // first position after the pass
     const bool after = pe < a.n && a.rows[pe] == row;
-    if (!before && !after) adam_row(a, row * D + q * VW, g);
+    if (!before && !after) adam_row(a, row * D + q * VW, row * a.ldw + q * VW, g);
     else g.store(a.acc + i * D + q * VW);
   }
 }
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam_long(AdamArgs a) {
       }
 #pragma unroll
       for (int m = LPR; m < kWave; m <<= 1) sum.add(sum.across(m));
-      if (r == 0) adam_row(a, hrow * D + q * VW, sum);
+      if (r == 0) adam_row(a, hrow * D + q * VW, hrow * a.ldw + q * VW, sum);
     }
   }
 }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_adam_anyD(AdamArgs a, int D) 
       const int64_t o = row * D + d;
       if (a.G) { a.G[o] = g; continue; }
       float m = a.M[o], v = a.V[o];
-      a.W[o] -= adam1(a, g, m, v);
+      a.W[row * a.ldw + d] -= adam1(a, g, m, v);
       a.M[o] = m;
       a.V[o] = v;
     }
@@ -294,16 +295,25 @@ extern "C" {
 static int launch_sorted_rows(AdamArgs a, int32_t D, const float *vals, const void *p0, const void *p1, const void *p2,
                               float *acc, void *stream);
 
+int mi_sparse_adam_sorted_ld(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *W, int64_t ldw,
+                             float *exp_avg, float *exp_avg_sq, float *acc, int64_t n, int32_t D, int64_t N,
+                             float step_size, const float *step_size_dev, double beta1, double beta2, float eps,
+                             void *stream) {
+  if (n < 0 || D <= 0 || N < 0 || ldw < D) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!rows_sorted || !perm || !vals || !W || !exp_avg || !exp_avg_sq || !acc) return MI_ERR_INVALID_ARG;
+  if (vec_ok(D) && (ldw & 3) != 0) return MI_ERR_UNSUPPORTED;   // float4 row accesses need 16-byte aligned rows
+  AdamArgs a{rows_sorted, perm, vals, W, exp_avg, exp_avg_sq, acc, n, N, step_size, (float)(1.0 - beta1), (float)(1.0 - beta2),
+             eps, step_size_dev, nullptr, ldw};
+  return launch_sorted_rows(a, D, vals, W, exp_avg, exp_avg_sq, acc, stream);
+}
+
 int mi_sparse_adam_sorted(const int64_t *rows_sorted, const int64_t *perm, const float *vals, float *W,
                           float *exp_avg, float *exp_avg_sq, float *acc, int64_t n, int32_t D, int64_t N,
                           float step_size, const float *step_size_dev, double beta1, double beta2, float eps,
                           void *stream) {
-  if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
-  if (n == 0) return MI_OK;
-  if (!rows_sorted || !perm || !vals || !W || !exp_avg || !exp_avg_sq || !acc) return MI_ERR_INVALID_ARG;
-  AdamArgs a{rows_sorted, perm, vals, W, exp_avg, exp_avg_sq, acc, n, N, step_size, (float)(1.0 - beta1), (float)(1.0 - beta2),
-             eps, step_size_dev, nullptr};
-  return launch_sorted_rows(a, D, vals, W, exp_avg, exp_avg_sq, acc, stream);
+  return mi_sparse_adam_sorted_ld(rows_sorted, perm, vals, W, D, exp_avg, exp_avg_sq, acc, n, D, N, step_size, step_size_dev,
+                                  beta1, beta2, eps, stream);
 }
 
 // The same segmented sums, stored instead of applied: G[row, :] = sum of vals[perm[i], :] over the sorted positions i with
@@ -314,7 +324,7 @@ int mi_coalesce_rows_sorted(const int64_t *rows_sorted, const int64_t *perm, con
   if (n < 0 || D <= 0 || N < 0) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
   if (!rows_sorted || !perm || !vals || !G || !acc) return MI_ERR_INVALID_ARG;
-  AdamArgs a{rows_sorted, perm, vals, nullptr, nullptr, nullptr, acc, n, N, 0.f, 0.f, 0.f, 0.f, nullptr, G};
+  AdamArgs a{rows_sorted, perm, vals, nullptr, nullptr, nullptr, acc, n, N, 0.f, 0.f, 0.f, 0.f, nullptr, G, D};
   return launch_sorted_rows(a, D, vals, G, G, G, acc, stream);
 }
 

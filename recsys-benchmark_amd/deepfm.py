@@ -75,6 +75,50 @@ class DeepFM(nn.Module):
         offsets = torch.cumsum(field_dims_tensor[:-1], 0).unsqueeze(0)
         self.register_buffer("offsets", offsets)
 
+    PACKED_ROW_FLOATS = 32      # one 128-byte line per row: D <= 16 embedding floats, the first-order weight, padding
+
+    def pack_tables(self) -> "DeepFM":
+        """Opt-in storage layout for the two lookup tables (an MI355X-side choice; the arithmetic and the reference's
+        tensors are unchanged): ONE buffer fp32[N, 32] whose row n holds embedding row n in floats 0..D-1 and
+        fc.weight[n] in float D, so a lookup reads one 128-byte line instead of a 64-byte embedding row plus a whole
+        64-byte sector for its 4-byte first-order weight (src/models/deepfm.py:47-51 declares them as two tensors).
+        `embedding._emb_module.weight` and `fc.weight` stay the SAME Parameter objects (optimizers, `state_dict()` keys,
+        shapes [N, D] / [N, 1] and `load_state_dict` are unaffected); their storage becomes a column-slice view of
+        the packed buffer.  Call it after the model is on its device (`.to()` copies a view out into a tensor of its
+        own).  Needs the plain full table (VanillaEmbedding, mode None) with D in {4, 8, 16}."""
+        emb = getattr(self, "embedding", None)
+        if type(emb) is not VanillaEmbedding or emb._mode is not None:
+            raise NotImplementedError("pack_tables() covers the full (vanilla) embedding table only")
+        W, w1 = emb._emb_module.weight, self.fc.weight
+        N, D = W.shape
+        LD = self.PACKED_ROW_FLOATS
+        if D not in (4, 8, 16) or w1.shape != (N, 1) or W.dtype != torch.float32 or W.device != w1.device:
+            raise NotImplementedError(f"pack_tables(): unsupported shapes {tuple(W.shape)} / {tuple(w1.shape)}")
+        if self.tables_packed:
+            return self
+        packed = torch.zeros((N, LD), dtype=torch.float32, device=W.device)
+        packed[:, :D].copy_(W.detach())
+        packed[:, D:D + 1].copy_(w1.detach())
+        W.data = packed[:, :D]
+        w1.data = packed[:, D:D + 1]
+        if not getattr(self, "_packed_hook", False):
+            # checkpoints keep the reference's format: two contiguous tensors, not two views that drag the packed buffer along
+            def _contiguous_tables(module, state_dict, prefix, local_metadata):
+                for key in (prefix + "embedding._emb_module.weight", prefix + "fc.weight"):
+                    t = state_dict.get(key)
+                    if t is not None and not t.is_contiguous():
+                        state_dict[key] = t.detach().contiguous()
+            self._register_state_dict_hook(_contiguous_tables)
+            self._packed_hook = True
+        return self
+
+    @property
+    def tables_packed(self) -> bool:
+        W, w1 = self.embedding._emb_module.weight, self.fc.weight
+        return bool(W.stride(0) == self.PACKED_ROW_FLOATS and w1.stride(0) == self.PACKED_ROW_FLOATS
+                    and w1.data_ptr() == W.data_ptr() + 4 * W.shape[1]
+                    and W.untyped_storage().data_ptr() == w1.untyped_storage().data_ptr())
+
     def _fm_and_embedding(self, x):
         emb_mod = self.embedding
         if type(emb_mod) is VanillaEmbedding and emb_mod._mode is None:      # subclasses (QAT) transform the rows

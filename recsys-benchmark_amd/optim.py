@@ -64,8 +64,9 @@ class SparseAdam(torch.optim.Optimizer):
                 state = self.state[p]
                 if not state:
                     state["step"] = torch.zeros((), dtype=torch.float32, device=dev) if capturable else 0
-                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    # contiguous [N, D] also for a parameter that is a view of a packed table (DeepFM.pack_tables())
+                    state["exp_avg"] = torch.zeros(p.shape, dtype=p.dtype, device=dev)
+                    state["exp_avg_sq"] = torch.zeros(p.shape, dtype=p.dtype, device=dev)
                 todo.append((p, dev, rows, vals, state))
             if not todo:
                 continue
@@ -95,12 +96,15 @@ class SparseAdam(torch.optim.Optimizer):
                 acc = self._workspace.get(p)           # scratch, not optimizer state
                 if acc is None or acc.numel() < vals.numel():
                     acc = self._workspace[p] = torch.empty(vals.numel(), dtype=torch.float32, device=dev)
+                ldw = D if p.is_contiguous() else _kernels._row_strided(p.view(N, D), align=4 if D >= 4 else 1)[1]
+                if not p.is_contiguous() and (p.dim() != 2 or p.stride(0) != ldw):
+                    raise RuntimeError("SparseAdam: a non-contiguous parameter must be a row-strided 2-D view (packed table)")
                 _lib.check(
-                    lib.mi_sparse_adam_sorted(rows_sorted.data_ptr(), perm.data_ptr(), vals.data_ptr(), p.data_ptr(),
-                                              state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                              acc.data_ptr(), rows.numel(), D, N, step_size, step_size_dev, beta1, beta2,
-                                              group["eps"], stream),
-                    "mi_sparse_adam_sorted",
+                    lib.mi_sparse_adam_sorted_ld(rows_sorted.data_ptr(), perm.data_ptr(), vals.data_ptr(), p.data_ptr(), ldw,
+                                                 state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                                 acc.data_ptr(), rows.numel(), D, N, step_size, step_size_dev, beta1, beta2,
+                                                 group["eps"], stream),
+                    "mi_sparse_adam_sorted_ld",
                 )
         return loss
 
@@ -123,6 +127,9 @@ class SparseSGD(torch.optim.Optimizer):
                 dev = _lib.require_gpu(p)
                 rows, vals = _coo_parts(p.grad)
                 N = p.shape[0]
+                if not p.is_contiguous():       # a view of a packed table (DeepFM.pack_tables()): torch's strided scatter-add
+                    p.index_add_(0, rows, vals.view((rows.numel(),) + tuple(p.shape[1:])), alpha=-group["lr"])
+                    continue
                 _lib.check(lib.mi_scatter_axpy_rows(rows.data_ptr(), vals.data_ptr(), -group["lr"], p.data_ptr(),
                                                     rows.numel(), p.numel() // N, N, _lib.stream_ptr(dev)),
                            "mi_scatter_axpy_rows")

@@ -43,12 +43,27 @@ def _build_from_golden(g, sparse=False, fc_sparse=False):
     return m.to(DEV)
 
 
+def _can_pack(m):
+    D = m.embedding.get_weight().shape[1]
+    return D in (4, 8, 16)
+
+
 @pytest.mark.parametrize("name", golden_names("deepfm_"))
 @pytest.mark.parametrize("grad_form", ["dense", "rows"])
-def test_deepfm_matches_reference_golden(name, grad_form):
+@pytest.mark.parametrize("layout", ["split", "packed128"])
+def test_deepfm_matches_reference_golden(name, grad_form, layout):
     g = load_golden(name)
     rows = grad_form == "rows"
     m = _build_from_golden(g, sparse=rows, fc_sparse=rows)
+    if layout == "packed128":
+        # the reference's two tensors as views of ONE [N, 32] buffer (DeepFM.pack_tables): same goldens must hold
+        if not _can_pack(m):
+            pytest.skip("pack_tables() covers D in {4, 8, 16}")
+        m.pack_tables()
+        assert m.tables_packed
+        sd = m.state_dict()      # ... and the checkpoint keeps the reference's format
+        for k in ("embedding._emb_module.weight", "fc.weight"):
+            assert sd[k].is_contiguous() and torch.equal(sd[k].cpu(), g.group("param/")[k]), k
     m.train(bool(g["training"]))
     x, y = g.t("x").to(DEV), g.t("y").to(DEV)
     logits = m(x)
@@ -106,7 +121,8 @@ CASES = [
 
 @pytest.mark.parametrize("B,dims,D", CASES)
 @pytest.mark.parametrize("zipf", [False, True])
-def test_gather_fm_kernels_vs_oracle(B, dims, D, zipf):
+@pytest.mark.parametrize("layout", ["split", "packed128", "strided"])
+def test_gather_fm_kernels_vs_oracle(B, dims, D, zipf, layout):
     p, x, g_emb, g_y = _random_case(B, dims, D, seed=B * 131 + D, zipf=zipf)
     for v in p.values():
         if v.is_floating_point():
@@ -114,8 +130,25 @@ def test_gather_fm_kernels_vs_oracle(B, dims, D, zipf):
     emb_ref, y_ref = ro.deepfm_embed_fm(x, p)
     ((emb_ref * g_emb).sum() + (y_ref.squeeze(1) * g_y).sum()).backward()
 
-    W = p["embedding._emb_module.weight"].detach().to(DEV).requires_grad_(True)
-    w1 = p["fc.weight"].detach().to(DEV).requires_grad_(True)
+    W = p["embedding._emb_module.weight"].detach().to(DEV)
+    w1 = p["fc.weight"].detach().to(DEV)
+    if layout != "split":
+        # both tables as column slices of one buffer: [N, 32] = {row, w1, pad} (pack_tables' layout), or an odd layout
+        # (row stride D + 8, w1 in a buffer of its own with stride 3) that only the stride arguments describe
+        if D % 4 or (layout == "packed128" and D > 16):
+            pytest.skip("row-strided tables need float4 rows" if D % 4 else "packed128 holds D <= 16")
+        N = W.shape[0]
+        if layout == "packed128":
+            buf = torch.zeros(N, 32, device=DEV)
+            buf[:, :D], buf[:, D:D + 1] = W, w1
+            W, w1 = buf[:, :D], buf[:, D:D + 1]
+        else:
+            bw, b1 = torch.full((N, D + 8), 7.0, device=DEV), torch.full((N, 3), 7.0, device=DEV)
+            bw[:, :D], b1[:, 1:2] = W, w1
+            W, w1 = bw[:, :D], b1[:, 1:2]
+        assert not W.is_contiguous() or N <= 1
+    W = W.detach().requires_grad_(True)
+    w1 = w1.detach().requires_grad_(True)
     bias = p["_bias"].detach().to(DEV).requires_grad_(True)
     off = p["offsets"].to(DEV)
     for sparse in (False, True):

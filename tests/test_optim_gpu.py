@@ -132,6 +132,39 @@ def test_sparse_sgd_and_factory_end_to_end():
     assert isinstance(get_optimizers(model, cfg2)[0], SparseSGD)
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_packed_tables_train_like_the_two_tensor_layout(optimizer):
+    """DeepFM.pack_tables() only changes where the two lookup tables live: five training steps with the reference's sparse
+    optimizer config leave every parameter BIT-identical to the model that keeps them as two tensors (same kernels, same
+    order of operations; the row-sparse Adam addresses the packed rows through its row stride)."""
+    dims = [20, 30, 5, 400]
+    cfg = {"sparse": True, "optimizer": optimizer, "learning_rate": 1e-2, "weight_decay": 1e-6}
+    x = torch.stack([torch.randint(0, d, (257,), generator=torch.Generator().manual_seed(3)) for d in dims], 1).to(DEV)
+    y = (torch.rand(257, generator=torch.Generator().manual_seed(4)) < 0.5).float().to(DEV)
+    finals = []
+    for packed in (False, True):
+        torch.manual_seed(0)
+        model = pkg.DeepFM(dims, 16, [32], p_dropout=0.0, use_batchnorm=True,
+                           embedding_config={"name": "vanilla", "sparse": True}, fc_sparse=True).to(DEV)
+        if packed:
+            model.pack_tables()
+        opts = get_optimizers(model, cfg)
+        for _ in range(5):
+            for o in opts:
+                o.zero_grad()
+            torch.nn.BCEWithLogitsLoss()(model(x), y).backward()
+            for o in opts:
+                o.step()
+        assert model.tables_packed == packed
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    if optimizer == "sgd":      # the strided SGD step is torch's index_add_ (atomics): equal up to the order of duplicate adds
+        for k in finals[0]:
+            assert_close(finals[1][k], finals[0][k], 1e-5, 1e-6, k)
+    else:
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 @pytest.mark.parametrize("weight_decay", [0.0, 1e-3])
 def test_dense_adam_matches_torch_adam(weight_decay):
     gen = torch.Generator().manual_seed(4)
