@@ -642,6 +642,45 @@ MI_API int mi_slot_fm_bwd(const int64_t *slot, const float *emb, const float *g_
  *   operand load computed it, for the same purpose.
  * mi_tail_wgrad_gemm: dW[N,K] = dz[M,N]^T . a_prev[M,K]; the batch is cut into mi_tail_wgrad_splits(M, N, K) slices,
  *   slab (splits * N * K floats) holds their partial products, added in slice order into dW.                      */
+/* The joins WITHOUT launches of their own (round 3): the kernel that CONSUMES an activation (or a pre-activation gradient)
+ * joins the statistics behind its constants in its prologue — every workgroup for itself, in a fixed order, into LDS;
+ * workgroup 0 writes the results where mi_tail_bn_finalize_fwd / _bwd would have (the backward pass and the optimizer
+ * read them there).  Same arithmetic for every workgroup, no atomics: deterministic.  Host structs, read at call time.
+ * mi_tail_bn_fwd: what mi_tail_bn_finalize_fwd takes — part[MT, N, 2] of the producing product, gamma / beta /
+ *   mean_offset (nullable), running statistics + counters (nullable), momentum, eps — and its outputs mu, sc, be, rstd [N].
+ * mi_tail_bn_bwd: what mi_tail_bn_finalize_bwd takes — part[nblk, N, 2], gamma (nullable), rstd, outputs dgamma / dbeta
+ *   (nullable), al, bz, de [N]; wpart[nwblk, N + 4] (nullable) -> dw[N], db[1] (joined by a second workgroup).
+ * mi_tail_fwd_gemm_m / mi_tail_head_fwd_m (x_stats / stats != NULL: the mu / sc / be arguments are ignored) and
+ * mi_tail_dgrad_gemm_m (sums != NULL: al / bz / de are ignored; mu and Zl are still read); NULL = the plain entry point.
+ * Features behind the joined constants <= 1024. */
+typedef struct mi_tail_bn_fwd {
+  const float *part;
+  const float *gamma, *beta, *mean_offset;
+  float *running_mean, *running_var;
+  int64_t *num_batches_tracked, *seed_bump;
+  float *mu, *sc, *be, *rstd;
+  float momentum, eps;
+} mi_tail_bn_fwd;
+typedef struct mi_tail_bn_bwd {
+  const float *part;
+  const float *gamma, *rstd;
+  float *dgamma, *dbeta, *al, *bz, *de;
+  const float *wpart;
+  float *dw, *db;
+  int32_t nblk, nwblk;
+} mi_tail_bn_bwd;
+MI_API int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
+                              float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
+                              float *part, float *a_out, int32_t M, int32_t N, int32_t K,
+                              const mi_tail_bn_fwd *x_stats, void *stream);
+MI_API int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                              const uint8_t *keep, const float *w, const float *b, const float *add, float *out,
+                              int32_t M, int32_t N, const mi_tail_bn_fwd *stats, void *stream);
+MI_API int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
+                                const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
+                                int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,
+                                const uint8_t *p_keep, float *OUT, int32_t ldo, float *part, float *dz_out, int32_t M,
+                                int32_t N, int32_t K, const mi_tail_bn_bwd *sums, void *stream);
 MI_API int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
                                  const int32_t *lds, uint8_t *const *bits, int32_t M, void *stream);
 MI_API int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,

@@ -14,6 +14,8 @@
 //                      in slice order (no atomics anywhere: the step is bit-reproducible).
 // The dropout decisions are ONE BIT per element, written once per step (k_tail_dropmask) and read by every kernel that
 // needs them (a byte per float4 of features).
+#include <type_traits>
+
 #include "common.hpp"
 #include "tail_gemm.hpp"
 
@@ -99,6 +101,157 @@ __device__ __forceinline__ LoadDz make_dz(const DzDesc &d) {
   return l;
 }
 
+
+// ============================================================================ BatchNorm joins in the CONSUMER's prologue ====
+// Round 2 joined the per-tile statistics of a product in a launch of their own (k_bn_finalize_fwd / _bwd: six near-empty
+// kernels per step, ~5.5 us each, almost all of it the kernel boundary).  Here every workgroup of the NEXT kernel joins
+// them itself, in a fixed order, into LDS while its first operand loads are in flight: all workgroups compute the same
+// bits (same order, same arithmetic), workgroup 0 alone writes the constants the backward pass reads later, the running
+// statistics and the counters.  No atomics, no tickets, deterministic.  Constants live in LDS as [row][kCstPitch].
+constexpr int kCstPitch = 1024;                 // features <= 1024 (tail.py's plan and the entry points check it)
+constexpr int kCstFloats = 4 * kCstPitch;
+
+struct BnFwd {           // device view of mi_tail_bn_fwd
+  const float *part, *gamma, *beta, *mean_offset;
+  float *running_mean, *running_var;
+  int64_t *nbt, *seed_bump;
+  float *mu, *sc, *be, *rstd;
+  float momentum, eps;
+};
+// (mean, M2) of the 64-row tiles -> batch mean and variance in ONE pass with every load of a chunk in flight (a thread
+// that walks 64 tiles 8 at a time pays 8 dependent L2 round trips: measured +10 us per kernel).  The tile means are
+// shifted by tile 0's mean c before they are summed and squared (tile means differ from the grand mean by ~sigma / 8,
+// so the subtraction at the end cancels nothing that matters):
+//   d_t = mean_t - c;  mean = c + sum n_t d_t / M;  M2 = sum M2_t + sum n_t d_t^2 - (sum n_t d_t)^2 / M
+// A thread joins TWO adjacent columns (one float4 = (mean, M2) x 2 per tile), kMergeChunk tiles per round trip.
+// `tid` / NT: this thread's index among, and the number of, the threads that take part.  cst rows: 0 mu, 1 sc, 2 be.
+constexpr int kMergeChunk = 32;
+template <int NT>
+__device__ __forceinline__ void bn_merge_fwd(const BnFwd &b, int M, int N, float *cst, bool writer, int tid) {
+  const int MT = (M + BM - 1) / BM;
+  const float inv_m = 1.f / (float)M;
+  for (int n = tid * 2; n < N; n += NT * 2) {
+    const float *p = b.part + (int64_t)n * 2;
+    // per-column inputs of the last step: issued with the first chunk, not after it
+    const float2 gm2 = b.gamma ? *reinterpret_cast<const float2 *>(b.gamma + n) : make_float2(1.f, 1.f);
+    const float2 bt2 = b.beta ? *reinterpret_cast<const float2 *>(b.beta + n) : make_float2(0.f, 0.f);
+    float2 mo2 = make_float2(0.f, 0.f), rm2 = mo2, rv2 = mo2;
+    if (writer && b.running_mean) {
+      rm2 = *reinterpret_cast<const float2 *>(b.running_mean + n);
+      rv2 = *reinterpret_cast<const float2 *>(b.running_var + n);
+      if (b.mean_offset) mo2 = *reinterpret_cast<const float2 *>(b.mean_offset + n);
+    }
+    float c0 = 0.f, c1 = 0.f, sn0 = 0.f, sn1 = 0.f, sq0 = 0.f, sq1 = 0.f, sm0 = 0.f, sm1 = 0.f;
+    for (int base = 0; base < MT; base += kMergeChunk) {
+      float4 v[kMergeChunk];
+#pragma unroll
+      for (int u = 0; u < kMergeChunk; ++u) v[u] = ld4(p + (int64_t)min(base + u, MT - 1) * N * 2);
+      if (base == 0) { c0 = v[0].x; c1 = v[0].z; }
+#pragma unroll
+      for (int u = 0; u < kMergeChunk; ++u) {
+        const int t = base + u;
+        if (t < MT) {
+          const float nb = (float)min(BM, M - t * BM);
+          const float d0 = v[u].x - c0, d1 = v[u].z - c1;
+          sn0 = fmaf(nb, d0, sn0); sq0 = fmaf(nb * d0, d0, sq0); sm0 += v[u].y;
+          sn1 = fmaf(nb, d1, sn1); sq1 = fmaf(nb * d1, d1, sq1); sm1 += v[u].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n + j;
+      const float c = j ? c1 : c0, sn = j ? sn1 : sn0, sq = j ? sq1 : sq0, sm = j ? sm1 : sm0;
+      const float mean = c + sn * inv_m;
+      const float m2 = fmaxf(sm + (sq - sn * sn * inv_m), 0.f);
+      const float var = m2 * inv_m;
+      const float rstd = rsqrtf(var + b.eps);
+      const float gm = j ? gm2.y : gm2.x, bt = j ? bt2.y : bt2.x;
+      cst[col] = mean;
+      cst[kCstPitch + col] = gm * rstd;
+      cst[2 * kCstPitch + col] = bt;
+      if (writer) {
+        b.mu[col] = mean;
+        b.sc[col] = gm * rstd;
+        b.be[col] = bt;
+        b.rstd[col] = rstd;
+        if (b.running_mean) {
+          b.running_mean[col] = (1.f - b.momentum) * (j ? rm2.y : rm2.x) + b.momentum * (mean + (j ? mo2.y : mo2.x));
+          const float unb = M > 1 ? m2 / (float)(M - 1) : var;
+          b.running_var[col] = (1.f - b.momentum) * (j ? rv2.y : rv2.x) + b.momentum * unb;
+        }
+      }
+    }
+  }
+  if (writer && tid == 0) {
+    if (b.nbt) b.nbt[0] += 1;
+    if (b.seed_bump) b.seed_bump[0] += 1;
+  }
+}
+
+struct BnBwd {           // device view of mi_tail_bn_bwd
+  const float *part;     // [nblk, N, 2] (sum dy, sum dy (z - mu))
+  int nblk;
+  const float *gamma, *rstd, *mu;
+  float *dgamma, *dbeta, *al, *bz, *de;
+  const float *wpart;    // [nwblk, N + 4] head pieces, nullable
+  int nwblk;
+  float *dw, *db;
+};
+// cst rows: 0 mu, 1 al, 2 bz, 3 de (the constants of LoadDz).  Two adjacent columns per thread, kMergeChunk partial rows in
+// flight.  The head's dw / db pieces are joined by ANOTHER workgroup (wwriter) so that no workgroup carries both joins.
+template <int NT>
+__device__ __forceinline__ void bn_merge_bwd(const BnBwd &b, int M, int N, float *cst, bool writer, bool wwriter, int tid) {
+  const float inv_m = 1.f / (float)M;
+  for (int n = tid * 2; n < N; n += NT * 2) {
+    const float *p = b.part + (int64_t)n * 2;
+    const float2 r2 = *reinterpret_cast<const float2 *>(b.rstd + n), mu2 = *reinterpret_cast<const float2 *>(b.mu + n);
+    const float2 gm2 = b.gamma ? *reinterpret_cast<const float2 *>(b.gamma + n) : make_float2(1.f, 1.f);
+    float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
+    for (int base = 0; base < b.nblk; base += kMergeChunk) {
+      float4 v[kMergeChunk];
+#pragma unroll
+      for (int u = 0; u < kMergeChunk; ++u) v[u] = ld4(p + (int64_t)min(base + u, b.nblk - 1) * N * 2);
+#pragma unroll
+      for (int u = 0; u < kMergeChunk; ++u)
+        if (base + u < b.nblk) { s10 += v[u].x; s20 += v[u].y; s11 += v[u].z; s21 += v[u].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n + j;
+      const float s1 = j ? s11 : s10, s2 = j ? s21 : s20;
+      const float r = j ? r2.y : r2.x, gm = j ? gm2.y : gm2.x;
+      const float dg = s2 * r;
+      const float al = gm * r, bz = -gm * r * r * dg * inv_m, de = -gm * r * s1 * inv_m;
+      cst[col] = j ? mu2.y : mu2.x;
+      cst[kCstPitch + col] = al;
+      cst[2 * kCstPitch + col] = bz;
+      cst[3 * kCstPitch + col] = de;
+      if (writer) {
+        if (b.dgamma) b.dgamma[col] = dg;
+        if (b.dbeta) b.dbeta[col] = s1;
+        b.al[col] = al; b.bz[col] = bz; b.de[col] = de;
+      }
+    }
+  }
+  if (wwriter && b.wpart) {
+    for (int n = tid; n <= N; n += NT) {
+      float sw = 0.f;
+      for (int base = 0; base < b.nwblk; base += kMergeChunk) {
+        float v[kMergeChunk];
+#pragma unroll
+        for (int u = 0; u < kMergeChunk; ++u) v[u] = b.wpart[(int64_t)min(base + u, b.nwblk - 1) * (N + 4) + n];
+#pragma unroll
+        for (int u = 0; u < kMergeChunk; ++u)
+          if (base + u < b.nwblk) sw += v[u];
+      }
+      if (n < N) b.dw[n] = sw; else if (b.db) b.db[0] = sw;
+    }
+  }
+}
+// generic -> LDS address space (p must point into a __shared__ array)
+__device__ __forceinline__ lds_cfp as_lds(const float *p) { return (lds_cfp)p; }
+
 // ============================================================================================== forward GEMM ====
 struct FwdArgs {
   ActDesc x;          // R operand [M, K]
@@ -111,14 +264,16 @@ struct FwdArgs {
   int M, N, K;
   int ncols;          // columns per workgroup (multiple of 4, <= 112)
   int ntn;            // column tiles
+  BnFwd bn;           // MERGE: the statistics behind x's constants, joined here (x.mu / sc / be are then not read)
 };
 
-template <bool ACT>
+template <bool ACT, bool MERGE>
 __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + (MERGE ? kCstFloats : 0)];
   const int mt_total = (a.M + BM - 1) / BM;
   const int tile = xcd_logical(blockIdx.x, mt_total * a.ntn);
   if (tile < 0) return;
+
   const int mt = tile / a.ntn, nt = tile % a.ntn;
   const int m0 = mt * BM, n0 = nt * a.ncols;
   const int rows_valid = min(BM, a.M - m0), cols_valid = min(a.ncols, a.N - n0);
@@ -131,7 +286,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   const LoadPlain xp{a.x.Z, a.x.ld};
   const LoadPlain wp{a.W, a.ldw};
   const KcOperand<BNT, LoadPlain> opC{wp, n0, cols_valid, a.K};
-  if constexpr (ACT)
+  if constexpr (MERGE) {
+    const lds_cfp c = as_lds(lds + kLdsFloats);
+    const LoadActL actl{a.x.Z, a.x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop};
+    float *cst = lds + kLdsFloats;
+    const bool writer = tile == 0;
+    main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadActL>>{Tee<LoadActL>{actl, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC,
+                          make_pre([&]() { bn_merge_fwd<kThreads - kProd>(a.bn, a.M, a.K, cst, writer, (int)threadIdx.x); }));
+  } else if constexpr (ACT)
     main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
   else main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
@@ -192,6 +354,7 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
 // like F.batch_norm(training=True) does (momentum; UNBIASED variance), count the batch, bump the dropout seed once per
 // step.  mean_offset: the Linear's bias, which the contraction left out because it cancels in the normalisation — it
 // only shifts the running mean.
+constexpr int kFinCols = 16, kFinGroups = kBlock / kFinCols;      // a workgroup: 16 columns x 16 tile groups
 __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restrict__ part, int M, int N,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ mean_offset, float *running_mean,
@@ -199,46 +362,54 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restr
                                                             int64_t *nbt, int64_t *seed_bump, float *__restrict__ mu,
                                                             float *__restrict__ sc, float *__restrict__ be,
                                                             float *__restrict__ rstd_out) {
-  // 64 columns x 4 tile groups per workgroup: a group merges its run of 64-row tiles in tile order (8 loads in flight —
-  // a single thread walking all tiles is one exposed memory latency per tile: 19 us at 64 tiles), then the 4 groups are
-  // merged in group order through LDS.  Same tree for every launch: deterministic.
-  __shared__ float sh[4][64][3];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl;
+  // Latency is all this kernel is: 16 columns x 16 tile groups per workgroup (25 workgroups at N = 400), so that at
+  // B = 4096 (64 tiles) a thread has 4 tiles and ONE round trip of loads (round 2: 64 columns x 4 groups, 16 tiles per
+  // thread in two trips of 8).  A group joins its run of tiles in one pass around its first tile's mean (see
+  // bn_merge_fwd), the 16 groups are merged in group order (Chan) by the group-0 thread.  Same tree every launch.
+  __shared__ float sh[kFinGroups][kFinCols][3];
+  const int cl = threadIdx.x % kFinCols, grp = threadIdx.x / kFinCols;
+  const int n = blockIdx.x * kFinCols + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (nbt) nbt[0] += 1;
     if (seed_bump) seed_bump[0] += 1;
   }
   const int MT = (M + BM - 1) / BM;
-  const int per = (MT + 3) / 4, t0 = grp * per, t1 = min(MT, t0 + per);
-  float n_a = 0.f, mean_a = 0.f, m2_a = 0.f;
-  if (n < N) {
+  const int per = (MT + kFinGroups - 1) / kFinGroups, t0 = grp * per, t1 = min(MT, t0 + per);
+  // the per-column inputs of the last step travel with the first trip
+  float gm = 1.f, bt = 0.f, mo = 0.f, rm = 0.f, rv = 0.f;
+  if (grp == 0 && n < N) {
+    if (gamma) gm = gamma[n];
+    if (beta) bt = beta[n];
+    if (running_mean) { rm = running_mean[n]; rv = running_var[n]; if (mean_offset) mo = mean_offset[n]; }
+  }
+  float n_g = 0.f, c = 0.f, sn = 0.f, sq = 0.f, sm = 0.f;
+  if (n < N && t0 < t1) {
     for (int base = t0; base < t1; base += 8) {
       float2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = min(base + u, t1 - 1);
-        v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)t * N + n) * 2);
-      }
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)min(base + u, t1 - 1) * N + n) * 2);
+      if (base == t0) c = v[0].x;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int t = base + u;
         if (t < t1) {
-          const float n_b = (float)min(BM, M - t * BM);
-          const float tot = n_a + n_b, delta = v[u].x - mean_a;
-          mean_a += delta * (n_b / tot);
-          m2_a += v[u].y + delta * delta * (n_a * n_b / tot);
-          n_a = tot;
+          const float nb = (float)min(BM, M - t * BM), d = v[u].x - c;
+          n_g += nb;
+          sn = fmaf(nb, d, sn);
+          sq = fmaf(nb * d, d, sq);
+          sm += v[u].y;
         }
       }
     }
   }
-  sh[grp][cl][0] = n_a; sh[grp][cl][1] = mean_a; sh[grp][cl][2] = m2_a;
+  const float mean_g = n_g > 0.f ? c + sn / n_g : 0.f;
+  const float m2_g = n_g > 0.f ? fmaxf(sm + (sq - sn * sn / n_g), 0.f) : 0.f;
+  sh[grp][cl][0] = n_g; sh[grp][cl][1] = mean_g; sh[grp][cl][2] = m2_g;
   __syncthreads();
   if (grp != 0 || n >= N) return;
-  n_a = 0.f; mean_a = 0.f; m2_a = 0.f;
+  float n_a = 0.f, mean_a = 0.f, m2_a = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < kFinGroups; ++q) {
     const float n_b = sh[q][cl][0];
     if (n_b > 0.f) {
       const float tot = n_a + n_b, delta = sh[q][cl][1] - mean_a;
@@ -249,36 +420,71 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restr
   }
   const float var = m2_a / (float)M;
   const float rstd = rsqrtf(var + eps);
-  const float gm = gamma ? gamma[n] : 1.f;
   mu[n] = mean_a;
   sc[n] = gm * rstd;
-  be[n] = beta ? beta[n] : 0.f;
+  be[n] = bt;
   rstd_out[n] = rstd;
   if (running_mean) {
-    const float mo = mean_offset ? mean_offset[n] : 0.f;
-    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (mean_a + mo);
+    running_mean[n] = (1.f - momentum) * rm + momentum * (mean_a + mo);
     const float unb = M > 1 ? m2_a / (float)(M - 1) : var;
-    running_var[n] = (1.f - momentum) * running_var[n] + momentum * unb;
+    running_var[n] = (1.f - momentum) * rv + momentum * unb;
   }
 }
 
 // ============================================================================================== head (Linear(., 1)) ====
 // out[m] = sum_n a(m, n) w[n] + b + add[m]: a wave per row group, float4 per lane over the features.
+template <bool MERGE>
 __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float *__restrict__ w, const float *__restrict__ b,
                                                           const float *__restrict__ add, float *__restrict__ out, int M,
-                                                          int N) {
-  const LoadAct act = make_act(x);
+                                                          int N, BnFwd bn) {
+  __shared__ __attribute__((aligned(16))) float cst[MERGE ? 3 * kCstPitch : 4];
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * kWavesPerBlock;
   const float bv = b ? b[0] : 0.f;
-  for (int m = wave0; m < M; m += nw) {
-    float s = 0.f;
-    for (int c = lane * 4; c < N; c += 256) {
-      const float4 a = act.finish(act.fetch(m, c), act.consts(c), m, c), ww = ld4(w + c);
-      s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+  auto rows = [&](const auto &act) {
+    if (N <= 512) {                              // up to 4 rows of a wave in flight (a workgroup per CU walks 16 rows)
+      const int c0 = lane * 4, c1 = lane * 4 + 256;
+      const bool v0 = c0 < N, v1 = c1 < N;
+      const float4 w0 = v0 ? ld4(w + c0) : make_float4(0.f, 0.f, 0.f, 0.f), w1 = v1 ? ld4(w + c1) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m0 = wave0; m0 < M; m0 += 4 * nw) {
+        typename std::remove_reference<decltype(act)>::type::Raw r0[4], r1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = min(m0 + u * nw, M - 1);
+          if (v0) r0[u] = act.fetch(m, c0);
+          if (v1) r1[u] = act.fetch(m, c1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * nw;
+          if (m >= M) break;
+          float s = 0.f;
+          if (v0) { const float4 a = act.finish(r0[u], act.consts(c0), m, c0); s += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w; }
+          if (v1) { const float4 a = act.finish(r1[u], act.consts(c1), m, c1); s += a.x * w1.x + a.y * w1.y + a.z * w1.z + a.w * w1.w; }
+          s = wave_sum(s);
+          if (lane == 0) out[m] = s + bv + (add ? add[m] : 0.f);
+        }
+      }
+      return;
     }
-    s = wave_sum(s);
-    if (lane == 0) out[m] = s + bv + (add ? add[m] : 0.f);
+    for (int m = wave0; m < M; m += nw) {
+      float s = 0.f;
+      for (int c = lane * 4; c < N; c += 256) {
+        const float4 a = act.finish(act.fetch(m, c), act.consts(c), m, c), ww = ld4(w + c);
+        s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+      }
+      s = wave_sum(s);
+      if (lane == 0) out[m] = s + bv + (add ? add[m] : 0.f);
+    }
+  };
+  const LoadAct act = make_act(x);
+  if constexpr (MERGE) {
+    bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
+    __syncthreads();
+    const lds_cfp c = as_lds(cst);
+    rows(LoadActL{x.Z, x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop});
+  } else {
+    rows(act);
   }
 }
 
@@ -355,31 +561,34 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
                                                             float *__restrict__ al, float *__restrict__ bz,
                                                             float *__restrict__ de, const float *__restrict__ wpart,
                                                             int nwblk, float *__restrict__ dw, float *__restrict__ db) {
-  // 32 columns x 8 row groups per workgroup (see k_bn_finalize_fwd): a group adds its run of partial rows in row order
-  // with 8 loads in flight, the 8 groups are added in group order through LDS.  Column N of the head's pieces is db.
-  __shared__ float sh[8][32][3];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int n = blockIdx.x * 32 + cl;
+  // 16 columns x 16 row groups per workgroup (see k_bn_finalize_fwd): a group adds its run of partial rows in row order
+  // with up to 16 loads in flight (64 partial rows: 4 per thread, one round trip; the head's 256: 16 per thread, one
+  // trip), the 16 groups are added in group order through LDS.  Column N of the head's pieces is db.
+  __shared__ float sh[kFinGroups][kFinCols][3];
+  const int cl = threadIdx.x % kFinCols, grp = threadIdx.x / kFinCols;
+  const int n = blockIdx.x * kFinCols + cl;
+  float r = 0.f, gm = 1.f;
+  if (grp == 0 && n < N) { r = rstd[n]; if (gamma) gm = gamma[n]; }
   float s1 = 0.f, s2 = 0.f, sw = 0.f;
   if (n < N) {
-    const int per = (nblk + 7) / 8, t0 = grp * per, t1 = min(nblk, t0 + per);
-    for (int base = t0; base < t1; base += 8) {
-      float2 v[8];
+    const int per = (nblk + kFinGroups - 1) / kFinGroups, t0 = grp * per, t1 = min(nblk, t0 + per);
+    for (int base = t0; base < t1; base += 16) {
+      float2 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)min(base + u, t1 - 1) * N + n) * 2);
+      for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float2 *>(part + ((int64_t)min(base + u, t1 - 1) * N + n) * 2);
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (base + u < t1) { s1 += v[u].x; s2 += v[u].y; }
     }
   }
   if (wpart && n <= N) {
-    const int per = (nwblk + 7) / 8, t0 = grp * per, t1 = min(nwblk, t0 + per);
-    for (int base = t0; base < t1; base += 8) {
-      float v[8];
+    const int per = (nwblk + kFinGroups - 1) / kFinGroups, t0 = grp * per, t1 = min(nwblk, t0 + per);
+    for (int base = t0; base < t1; base += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = wpart[(int64_t)min(base + u, t1 - 1) * (N + 4) + n];
+      for (int u = 0; u < 16; ++u) v[u] = wpart[(int64_t)min(base + u, t1 - 1) * (N + 4) + n];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (base + u < t1) sw += v[u];
     }
   }
@@ -388,12 +597,11 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
   if (grp != 0 || n > N) return;
   s1 = 0.f; s2 = 0.f; sw = 0.f;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1 += sh[q][cl][0]; s2 += sh[q][cl][1]; sw += sh[q][cl][2]; }
+  for (int q = 0; q < kFinGroups; ++q) { s1 += sh[q][cl][0]; s2 += sh[q][cl][1]; sw += sh[q][cl][2]; }
   if (wpart) {
     if (n < N) dw[n] = sw; else if (db) db[0] = sw;
   }
   if (n >= N) return;
-  const float r = rstd[n], gm = gamma ? gamma[n] : 1.f;
   const float dg = s2 * r;
   if (dgamma) dgamma[n] = dg;
   if (dbeta) dbeta[n] = s1;
@@ -417,14 +625,16 @@ struct DgradArgs {
   float *dz_out;      // [M, N] (pitch dz.ld), nullable: dz as the operand load computed it
   int M, N, K;
   int ncols, ntn;     // column tiles over K
+  BnBwd bn;           // MERGE: the column sums behind dz's constants, joined here (dz.al / bz / de are then not read)
 };
 
-template <bool DZ, bool MID>
+template <bool DZ, bool MID, bool MERGE>
 __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + (MERGE ? kCstFloats : 0)];
   const int mt_total = (a.M + BM - 1) / BM;
   const int tile = xcd_logical(blockIdx.x, mt_total * a.ntn);
   if (tile < 0) return;
+
   const int mt = tile / a.ntn, nt = tile % a.ntn;
   const int m0 = mt * BM, k0 = nt * a.ncols;
   const int rows_valid = min(BM, a.M - m0), cols_valid = min(a.ncols, a.K - k0);
@@ -437,7 +647,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadPlain wp{a.W, a.ldw};     // [red = n][out = k]
   const OtOperand<BNT, LoadPlain> opC{wp, k0, cols_valid, a.N};     // transposed into a KC tile on the way in
-  if constexpr (DZ)
+  if constexpr (MERGE) {
+    const lds_cfp c = as_lds(lds + kLdsFloats);
+    const LoadDzL dzm{a.dz.DY, a.dz.Z, a.dz.ld, c, c + kCstPitch, c + 2 * kCstPitch, c + 3 * kCstPitch};
+    float *cst = lds + kLdsFloats;
+    const bool writer = tile == 0, wwriter = tile == min(1, mt_total * a.ntn - 1);
+    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDzL>>{Tee<LoadDzL>{dzm, nt == 0 ? a.dz_out : nullptr, a.dz.ld}, m0, rows_valid, a.N}, opC,
+                          make_pre([&]() { bn_merge_bwd<kThreads - kProd>(a.bn, a.M, a.N, cst, writer, wwriter, (int)threadIdx.x); }));
+  } else if constexpr (DZ)
     main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDz>>{Tee<LoadDz>{dzl, nt == 0 ? a.dz_out : nullptr, a.dz.ld}, m0, rows_valid, a.N}, opC);
   else main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
 
@@ -583,15 +800,29 @@ bool vec_ok(const void *p, int ld) { return aligned16(p) && ld % 4 == 0; }
 
 extern "C" {
 
-int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
-                     const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
-                     int32_t M, int32_t N, int32_t K, void *stream) {
+static bool bn_fwd_view(const mi_tail_bn_fwd *m, BnFwd *out) {
+  if (!m->part || !aligned16(m->part) || !m->mu || !m->sc || !m->be || !m->rstd) return false;
+  if ((m->running_mean == nullptr) != (m->running_var == nullptr)) return false;
+  *out = BnFwd{m->part, m->gamma, m->beta, m->mean_offset, m->running_mean, m->running_var, m->num_batches_tracked,
+               m->seed_bump, m->mu, m->sc, m->be, m->rstd, m->momentum, m->eps};
+  return true;
+}
+
+int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                       const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                       int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !W || !Z) return MI_ERR_INVALID_ARG;
   if (!vec_ok(X, ldx) || !vec_ok(W, ldw) || !vec_ok(Z, ldz) || N % 4 || K % 4) return MI_ERR_UNSUPPORTED;
-  if (x_mu && (!x_sc || !x_be || !aligned16(x_mu) || !aligned16(x_sc) || !aligned16(x_be))) return MI_ERR_INVALID_ARG;
   FwdArgs a;
+  a.bn = BnFwd{};
+  if (x_stats) {            // the constants of X are joined in the kernel's prologue and written to x_stats->mu / sc / be
+    if (K > kCstPitch) return MI_ERR_UNSUPPORTED;
+    if (!bn_fwd_view(x_stats, &a.bn)) return MI_ERR_INVALID_ARG;
+    x_mu = x_stats->mu; x_sc = x_stats->sc; x_be = x_stats->be;
+  }
+  if (x_mu && (!x_sc || !x_be || !aligned16(x_mu) || !aligned16(x_sc) || !aligned16(x_be))) return MI_ERR_INVALID_ARG;
   if (x_mu && x_p > 0.f && (!x_keep || ldx % 8)) return MI_ERR_INVALID_ARG;
   a.x = ActDesc{X, ldx, x_mu, x_sc, x_be, x_p, x_keep};
   a.W = W; a.ldw = ldw; a.Z = Z; a.ldz = ldz; a.part = part;
@@ -600,9 +831,16 @@ int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(N, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
-  if (x_mu) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true>), grid8(tiles), kThreads, stream, a);
-  else MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<false>), grid8(tiles), kThreads, stream, a);
+  if (x_stats) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, true>), grid8(tiles), kThreads, stream, a);
+  else if (x_mu) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, false>), grid8(tiles), kThreads, stream, a);
+  else MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<false, false>), grid8(tiles), kThreads, stream, a);
   return launch_status();
+}
+
+int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                     const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                     int32_t M, int32_t N, int32_t K, void *stream) {
+  return mi_tail_fwd_gemm_m(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, nullptr, stream);
 }
 
 int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
@@ -637,22 +875,40 @@ int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, const float
                             int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc, float *be, float *rstd,
                             void *stream) {
   if (M <= 0 || N <= 0 || !part || !mu || !sc || !be || !rstd) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd, (N + 63) / 64, kBlock, stream, part, M, N, gamma, beta,
+  MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd, (N + kFinCols - 1) / kFinCols, kBlock, stream, part, M, N, gamma, beta,
             mean_offset, running_mean, running_var, momentum, eps, num_batches_tracked, seed_bump, mu, sc, be, rstd);
+  return launch_status();
+}
+
+int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                       const uint8_t *keep, const float *w, const float *b, const float *add, float *out, int32_t M,
+                       int32_t N, const mi_tail_bn_fwd *stats, void *stream) {
+  if (M < 0 || N <= 0) return MI_ERR_INVALID_ARG;
+  if (M == 0) return MI_OK;
+  BnFwd bn{};
+  if (stats) {
+    if (N > kCstPitch) return MI_ERR_UNSUPPORTED;
+    if (!bn_fwd_view(stats, &bn)) return MI_ERR_INVALID_ARG;
+    mu = stats->mu; sc = stats->sc; be = stats->be;
+  }
+  if (!Z || !mu || !sc || !be || !w || !out) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(Z, ldz) || N % 4 || !aligned16(w)) return MI_ERR_UNSUPPORTED;
+  if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
+  const ActDesc x{Z, ldz, mu, sc, be, p, keep};
+  if (stats) {
+    // every workgroup joins the statistics itself: one workgroup per CU, its waves walking the rows
+    const int grid = (M + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (M + kWavesPerBlock - 1) / kWavesPerBlock : 256;
+    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<true>), grid, kBlock, stream, x, w, b, add, out, M, N, bn);
+  } else {
+    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<false>), grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N, bn);
+  }
   return launch_status();
 }
 
 int mi_tail_head_fwd(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                      const uint8_t *keep, const float *w, const float *b, const float *add, float *out, int32_t M,
                      int32_t N, void *stream) {
-  if (M < 0 || N <= 0) return MI_ERR_INVALID_ARG;
-  if (M == 0) return MI_OK;
-  if (!Z || !mu || !sc || !be || !w || !out) return MI_ERR_INVALID_ARG;
-  if (!vec_ok(Z, ldz) || N % 4 || !aligned16(w)) return MI_ERR_UNSUPPORTED;
-  if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
-  const ActDesc x{Z, ldz, mu, sc, be, p, keep};
-  MI_LAUNCH("tail_head_fwd", k_tail_head_fwd, grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N);
-  return launch_status();
+  return mi_tail_head_fwd_m(Z, ldz, mu, sc, be, p, keep, w, b, add, out, M, N, nullptr, stream);
 }
 
 int32_t mi_tail_head_blocks(int32_t M) { return M >= 64 * 256 ? 256 : (M + 15) / 16 > 0 ? (M + 15) / 16 : 1; }
@@ -674,23 +930,33 @@ int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t 
                             int32_t nwblk, float *dw, float *db, void *stream) {
   if (M <= 0 || N <= 0 || nblk <= 0 || !part || !rstd || !al || !bz || !de) return MI_ERR_INVALID_ARG;
   if (wpart && !dw) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + 31) / 32, kBlock, stream, part, nblk, M, N,
+  MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + kFinCols - 1) / kFinCols, kBlock, stream, part, nblk, M, N,
             gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db);
   return launch_status();
 }
 
-int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
-                       const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
-                       const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
-                       float *part, float *dz_out, int32_t M, int32_t N, int32_t K, void *stream) {
+int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                         const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
+                         const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
+                         float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                         void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!DY || !W || !OUT) return MI_ERR_INVALID_ARG;
+  DgradArgs a;
+  a.bn = BnBwd{};
+  if (sums) {               // al / bz / de are joined from the column sums in the kernel's prologue and written to sums->al ...
+    if (N > kCstPitch) return MI_ERR_UNSUPPORTED;
+    if (!sums->part || !aligned16(sums->part) || sums->nblk <= 0 || !sums->rstd || !sums->al || !sums->bz || !sums->de || !mu || !Zl) return MI_ERR_INVALID_ARG;
+    if (sums->wpart && (!sums->dw || sums->nwblk <= 0)) return MI_ERR_INVALID_ARG;
+    a.bn = BnBwd{sums->part, sums->nblk, sums->gamma, sums->rstd, mu, sums->dgamma, sums->dbeta, sums->al, sums->bz, sums->de,
+                 sums->wpart, sums->nwblk, sums->dw, sums->db};
+    al = sums->al; bz = sums->bz; de = sums->de;
+  }
   if (al && (!Zl || !mu || !bz || !de)) return MI_ERR_INVALID_ARG;
   if (p_mu && (!pZ || !p_sc || !p_be)) return MI_ERR_INVALID_ARG;
   if (!vec_ok(DY, ld) || !vec_ok(W, ldw) || !vec_ok(OUT, ldo) || N % 4 || K % 4 || (pZ && !vec_ok(pZ, pld)))
     return MI_ERR_UNSUPPORTED;
-  DgradArgs a;
   a.dz = DzDesc{DY, Zl, ld, mu, al, bz, de};
   a.W = W; a.ldw = ldw;
   if (p_mu && p_p > 0.f && (!p_keep || pld % 8)) return MI_ERR_INVALID_ARG;
@@ -702,11 +968,21 @@ int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float
   a.ncols = cols_per_tile(K, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
   const bool dz = al != nullptr, mid = p_mu != nullptr;
-  if (dz && mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, true>), grid8(tiles), kThreads, stream, a);
-  else if (dz) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, false>), grid8(tiles), kThreads, stream, a);
-  else if (mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<false, true>), grid8(tiles), kThreads, stream, a);
-  else MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<false, false>), grid8(tiles), kThreads, stream, a);
+  if (sums && mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, true, true>), grid8(tiles), kThreads, stream, a);
+  else if (sums) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, false, true>), grid8(tiles), kThreads, stream, a);
+  else if (dz && mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, true, false>), grid8(tiles), kThreads, stream, a);
+  else if (dz) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, false, false>), grid8(tiles), kThreads, stream, a);
+  else if (mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<false, true, false>), grid8(tiles), kThreads, stream, a);
+  else MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<false, false, false>), grid8(tiles), kThreads, stream, a);
   return launch_status();
+}
+
+int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                       const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
+                       const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
+                       float *part, float *dz_out, int32_t M, int32_t N, int32_t K, void *stream) {
+  return mi_tail_dgrad_gemm_m(DY, Zl, ld, mu, al, bz, de, W, ldw, pZ, pld, p_mu, p_sc, p_be, p_p, p_keep, OUT, ldo, part,
+                              dz_out, M, N, K, nullptr, stream);
 }
 
 // slices of the batch for the weight-gradient product: as many as keep <= 256 workgroups busy, each a multiple of 32 rows

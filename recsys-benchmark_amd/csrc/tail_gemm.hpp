@@ -38,6 +38,14 @@ constexpr int SR_OC = 68;         // LDS row pitch (floats) of an OC tile of R (
 constexpr int SC_OC = 116;        // ... of Cc (112 wide); both = 4 mod 8: lane groups 4 rows apart fall 16 banks apart
 
 __device__ __forceinline__ float4 vld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// per-column constants may live in LDS (merged there from the producing layer's tile statistics in the kernel's prologue,
+// tail.hip): an address-space-3 pointer keeps their loads ds_read_b128 — a generic pointer would make them flat loads,
+// which wait on BOTH counters and would drain the producers' global loads at every slice
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+__device__ __forceinline__ float4 vld4(lds_cfp p) {
+  const floatx4 v = *reinterpret_cast<const __attribute__((address_space(3))) floatx4 *>(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void vst4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -81,6 +89,7 @@ struct Drop {
 struct NoConsts {};
 // Plain: the matrix itself (weights, the embedding block, a finished gradient).
 struct LoadPlain {
+  static constexpr bool kLateConsts = false;
   const float *P;
   int ld;
   struct Raw { float4 a; };
@@ -91,10 +100,14 @@ struct LoadPlain {
 };
 // Act: the activation a = dropout(relu(bn(z))) recomputed from the saved pre-activation z:
 //   pre = (z - mu[c]) * sc[c] + be[c]   (sc = gamma * rstd; BatchNorm off: mu = 0, sc = 1, be = bias or 0)
-struct LoadAct {
+template <class CP> struct ConstsTrait { static constexpr bool kLate = false; };
+template <> struct ConstsTrait<lds_cfp> { static constexpr bool kLate = true; };   // LDS constants: read when the value is formed
+template <class CP>
+struct LoadActT {
+  static constexpr bool kLateConsts = ConstsTrait<CP>::kLate;
   const float *Z;
   int ld;
-  const float *mu, *sc, *be;
+  CP mu, sc, be;
   Drop drop;
   struct Raw { float4 z; uint32_t keep; };
   struct Consts { float4 u, s, b; };
@@ -110,14 +123,18 @@ struct LoadAct {
     return a;
   }
 };
+typedef LoadActT<const float *> LoadAct;
+typedef LoadActT<lds_cfp> LoadActL;
 // Dz: the gradient w.r.t. the pre-activation of a training-mode BatchNorm layer, from dy (= dL/d(bn output), already
 // masked by ReLU and dropout) and z:  dz = al[c] * dy + bz[c] * (z - mu[c]) + de[c]
 //   al = gamma*rstd, bz = -gamma*rstd^2 * dgamma/M, de = -gamma*rstd * dbeta/M   (bn_finalize_bwd writes them;
 //   eval-mode / no BatchNorm: bz = de = 0)
-struct LoadDz {
+template <class CP>
+struct LoadDzT {
+  static constexpr bool kLateConsts = ConstsTrait<CP>::kLate;
   const float *DY, *Z;
   int ld;
-  const float *mu, *al, *bz, *de;
+  CP mu, al, bz, de;
   struct Raw { float4 dy, z; };
   struct Consts { float4 u, a, b, d; };
   __device__ __forceinline__ Raw fetch(int m, int c) const {
@@ -133,6 +150,8 @@ struct LoadDz {
     return o;
   }
 };
+typedef LoadDzT<const float *> LoadDz;
+typedef LoadDzT<lds_cfp> LoadDzL;
 
 // Tee: the operand value also goes to memory as it passes (out[m][c], row pitch the loader's own), so that a LATER product
 // on other kernels can read the transformed matrix (the tail's weight gradients take a(z) and dz from here).  One column
@@ -140,6 +159,7 @@ struct LoadDz {
 // value at its own (valid) address.
 template <class L>
 struct Tee {
+  static constexpr bool kLateConsts = L::kLateConsts;
   L in;
   float *out;
   int ld;
@@ -176,7 +196,7 @@ __device__ __forceinline__ KcStage<ROWS, L> kc_fetch(const L &ld, int row0, int 
   KcStage<ROWS, L> st;
   st.red = red0 + ((ptid() & 7) << 2);
   const int redc = st.red < red_end ? st.red : red_end - 4;
-  st.k = ld.consts(redc);
+  if constexpr (!L::kLateConsts) st.k = ld.consts(redc);      // global constants travel with the slice's loads
 #pragma unroll
   for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
     int row = (ptid() >> 3) + i * (kProd / 8);
@@ -189,12 +209,14 @@ template <int ROWS, class L>
 __device__ __forceinline__ void kc_finish(float *T, const L &ld, const KcStage<ROWS, L> &st, int row0, int rows_valid, int red_end) {
   const bool live = st.red < red_end;
   const int redc = live ? st.red : red_end - 4;
+  typename L::Consts k = st.k;
+  if constexpr (L::kLateConsts) k = ld.consts(redc);           // constants in LDS (joined by this workgroup): a ds_read here
 #pragma unroll
   for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
     const int trow = (ptid() >> 3) + i * (kProd / 8);
     if (trow < ROWS) {
       const int row = trow < rows_valid ? trow : rows_valid - 1;
-      float4 v = ld.finish(st.raw[i], st.k, row0 + row, redc);
+      float4 v = ld.finish(st.raw[i], k, row0 + row, redc);
       if (!live) v = zero4();
       vst4(T + kc_off(trow, ptid() & 7), v);
     }
@@ -411,9 +433,25 @@ __device__ __forceinline__ void consumer_barrier() { __builtin_amdgcn_s_barrier(
 // The element work of the operand loads (BatchNorm / ReLU / dropout bit) runs on the producers' VALU slots beside the
 // consumers' MFMAs (not for free: the f32 MFMA shares the vector issue, so it is kept to a few instructions per float4).  fetchR/fetchC(red0) issue the loads of one slice, finishR/finishC(T, stage, red0)
 // transform and write it.  Fetches past the last slice re-read the last slice (never written).
-template <bool R_KC, bool C_KC, int NS = NSUB, class OR, class OC>
+// `pre` (optional): work the CONSUMER waves do while the producers' first loads are in flight — joining the statistics
+// behind the R operand's constants into LDS (tail.hip) — with one extra barrier between it and the producers' first
+// LDS write (which is where those constants are first read: kLateConsts loaders).
+struct NoPre {
+  static constexpr bool kActive = false;
+  __device__ __forceinline__ void operator()() const {}
+};
+template <class F>
+struct Pre {
+  static constexpr bool kActive = true;
+  F f;
+  __device__ __forceinline__ void operator()() const { f(); }
+};
+template <class F>
+__device__ __forceinline__ Pre<F> make_pre(F f) { return Pre<F>{f}; }
+
+template <bool R_KC, bool C_KC, int NS = NSUB, class OR, class OC, class PRE = NoPre>
 __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const OR &opR,
-                                          const OC &opC) {
+                                          const OC &opC, const PRE &pre = PRE{}) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int rOff = R_KC ? kROffKC : kROffOC, cOff = C_KC ? kCOffKC : kCOffOC;
   const int nst = (red_end - red_begin + BK - 1) / BK;
@@ -435,6 +473,7 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
     auto c1 = fetchC(at(1));
     auto r2 = fetchR(at(2));
     auto c2 = fetchC(at(2));
+    if constexpr (PRE::kActive) producer_barrier();      // the consumers have joined the constants
     finishR(slot(0) + rOff, r0, at(0));
     finishC(slot(0) + cOff, c0, at(0));
     r0 = fetchR(at(3));
@@ -481,6 +520,10 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
   } else {
     // ---------------------------------------------------------------------------------------------- consumers
     Frags<NS> f0, f1;
+    if constexpr (PRE::kActive) {
+      pre();
+      producer_barrier();              // (lgkmcnt(0): the constants are in LDS) pairs with the producers' extra barrier
+    }
     __builtin_amdgcn_s_setprio(3);     // the matrix pipe's wave wins the issue arbitration against the producer beside it
     consumer_barrier();
     read_frags<R_KC, C_KC, NS>(f0, slot(0) + rOff, slot(0) + cOff, wave, lane, 0);

@@ -21,9 +21,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True)
-def _fused_tail_on(monkeypatch):
-    monkeypatch.setattr(_mlp, "FUSED_TAIL", True)      # opt-in path (mlp.FUSED_TAIL documents why)
+@pytest.fixture(autouse=True, params=[True, False], ids=["joins-in-prologue", "finalize-launches"])
+def _fused_tail_on(request, monkeypatch):
+    """Every test runs with the BatchNorm joins in the consuming kernels' prologues (the default since round 3) and with
+    the finalize launches of round 2 (MI_TAIL_MERGE_JOINS=0)."""
+    from recsys_benchmark_amd import tail as _tail_mod
+
+    monkeypatch.setattr(_mlp, "FUSED_TAIL", True)
+    monkeypatch.setattr(_tail_mod, "MERGE_JOINS", request.param)
 
 
 def _seq(inp, hidden, p):
