@@ -601,13 +601,14 @@ def bench_c5(args, real_stdout):
         return
     kernels = kernel_table(kt)
     alg = 8 * nnz + 4 * (N + 1) + 8 * N * D
-    k = kernels.get("spmm_csr")
+    kname = "spmm_tiled" if "spmm_tiled" in kernels else "spmm_csr"
+    k = kernels.get(kname)
     roofline = None
     if k:
         ach = alg / (k["avg_us"] * 1e-6) / 1e9
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        traffic = json.load(open(tpath)).get("spmm_csr") if os.path.exists(tpath) else None
-        roofline = {"bound": "hbm", "kernel": "spmm_csr", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        traffic = json.load(open(tpath)).get(kname) if os.path.exists(tpath) else None
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_us": k["avg_us"], "alg_bytes": alg,
                     "launches_per_step": k["launches"] / n_prof, "nnz": nnz,
                     "gather_bytes_without_reuse": nnz * (8 + 4 * D), "G_nnz_per_s": round(nnz / (k["avg_us"] * 1e-6) / 1e9, 2),

@@ -251,6 +251,21 @@ MI_API int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val
                        const int32_t *short_rows, int32_t n_short,
                        const int32_t *long_rows, int32_t n_long, void *stream);
 
+/* The same product (and fused epilogue) in the TILED form (round 3; csrc/spmm.hip): a workgroup owns a tile of consecutive
+ * output rows whose sums live in LDS for the whole launch, the tile's edges — one per 16-lane group, gathered row of X
+ * times value added with LDS float atomics — are walked column block by column block so that the block of X being
+ * gathered from stays in the XCD's L2.  Built once per sparsity pattern by the caller (CsrPlan.tiles on the Python side):
+ *   tile_edge0, tile_row0  int32[ntiles + 1]  first edge / first output row of every tile; the tiles' row ranges cover
+ *                          [0, n_rows) exactly once, at most max_tile_rows rows each (max_tile_rows * D * 4 <= 64 KiB);
+ *   ecr   int32[nnz] = column | (row - tile_row0[tile]) << 23   (columns < 2^23), eval fp32[nnz] the values, both in
+ *                          tile order with each tile's edges grouped by column block.
+ * X / acc_in as two row segments, Y / acc_out / scale as in mi_spmm_csr.  The order of the LDS adds depends on timing:
+ * results agree with mi_spmm_csr to float rounding, not bitwise. */
+MI_API int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, int32_t ntiles, int32_t max_tile_rows,
+                         const int32_t *ecr, const float *eval, const float *Xa, const float *Xb, int32_t x_split,
+                         float *Y, const float *acc_in_a, const float *acc_in_b, int32_t acc_split, float *acc_out,
+                         float scale, int32_t D, void *stream);
+
 /* ---- a10: TT-Rec lookup (TTRecTorch semantics) --------------------------------
  * src/models/embeddings/tensortrain_embeddings.py:100-150: mixed-radix split of idx over
  * p_shapes, one slice per core (core c: fp32[1, p_c, r_c*q_c*r_{c+1}] viewed (p_c,r_c,q_c,r_{c+1})),

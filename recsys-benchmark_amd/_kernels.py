@@ -526,6 +526,73 @@ class CsrPlan:
         return self._tv
 
 
+    # ---- tiled form (mi_spmm_tiled) ----
+    TILES_PER_LAUNCH = 512          # about two workgroups per CU, each with about nnz / 512 edges
+    COL_BLOCK_BYTES = 2 << 20       # rows of X per column block: half of an XCD's 4 MiB L2
+
+    def tiles(self, D: int, transposed: bool):
+        """The tile plan of A (or A^T) for rows of D floats, built once per (pattern, D): row tiles of about equal edge
+        count and at most 64 KiB of LDS sums, every tile's edges grouped by column block.  None when the kernel cannot
+        take the matrix (columns >= 2^23, D outside the float4 kernels)."""
+        key = (int(D), bool(transposed))
+        cache = self.__dict__.setdefault("_tiles", {})
+        if key in cache:
+            return cache[key]
+        crow, col = (self.crow_t, self.col_t) if transposed else (self.crow, self.col)
+        n_rows, n_cols = (self.shape[1], self.shape[0]) if transposed else self.shape
+        plan = None
+        if _float4_rows(D) and n_cols < (1 << 23) and self.nnz > 0 and n_rows > 0:
+            dev = crow.device
+            crow64 = crow.to(torch.int64)
+            deg = crow64[1:] - crow64[:-1]
+            budget = max(1, -(-self.nnz // self.TILES_PER_LAUNCH))
+            max_rows = max(1, min(256, (64 * 1024) // (4 * D)))
+            t_e = crow64[:-1] // budget                                  # tile id by edge budget (non-decreasing)
+            rows = torch.arange(n_rows, device=dev)
+            _, inv, cnt = torch.unique_consecutive(t_e, return_inverse=True, return_counts=True)
+            grp_first = torch.cumsum(cnt, 0) - cnt                       # first row of each edge-budget group
+            sub = (rows - grp_first[inv]) // max_rows                    # ... cut further by the row cap
+            _, row_tile, tcnt = torch.unique_consecutive(inv * (n_rows // max_rows + 2) + sub, return_inverse=True,
+                                                         return_counts=True)
+            ntiles = int(tcnt.numel())
+            tile_row0 = torch.zeros(ntiles + 1, dtype=torch.int64, device=dev)
+            tile_row0[1:] = torch.cumsum(tcnt, 0)
+            erow = torch.repeat_interleave(rows, deg)
+            etile = row_tile[erow]
+            lrow = erow - tile_row0[etile]
+            cb_rows = max(1, self.COL_BLOCK_BYTES // (4 * D))
+            col64 = col.to(torch.int64)
+            nblocks = -(-n_cols // cb_rows)
+            perm = torch.argsort(etile * nblocks + col64 // cb_rows, stable=True)
+            ecr = (col64 | (lrow << 23))[perm].to(torch.int32).contiguous()
+            tile_edge0 = torch.zeros(ntiles + 1, dtype=torch.int64, device=dev)
+            tile_edge0[1:] = torch.cumsum(torch.bincount(etile, minlength=ntiles), 0)
+            plan = dict(ntiles=ntiles, max_rows=int(tcnt.max()), ecr=ecr, perm=perm,
+                        tile_edge0=tile_edge0.to(torch.int32).contiguous(), tile_row0=tile_row0.to(torch.int32).contiguous())
+        cache[key] = plan
+        return plan
+
+    def tile_values(self, val: torch.Tensor, D: int, transposed: bool) -> torch.Tensor:
+        """`val` (the values of A, or of A^T when transposed) in the tile plan's edge order; cached per values tensor
+        (they only change with a SparseDropout draw)."""
+        key = ("_tilev", int(D), bool(transposed))
+        hit = self.__dict__.get(key)
+        if hit is not None and self._same_values(hit[0], hit[1], val):
+            return hit[2]
+        out = val.index_select(0, self.tiles(D, transposed)["perm"])
+        self.__dict__[key] = (val, val._version, out)
+        return out
+
+
+# The tiled SpMM (csrc/spmm.hip, round 3: row tiles whose sums live in LDS, edges walked column block by column block,
+# one edge per 16-lane group, LDS float adds) is parity-green and OPT-IN (MI_SPMM_TILED=1): on MI355X it runs 13x SLOWER
+# than the row-per-wave kernels (1073 vs 80 us per Yelp2018-shaped layer) because ds_add_f32 executes a wave's 64 lanes
+# one after the other — 170 cycles per wave-instruction whatever the address pattern, against 5-8 for ds_add_u32 and
+# 10-15 for a plain read + add + write (tools/probe_lds_atomic.hip, profiles/r03_lds_atomic_probe.txt).
+import os as _os
+
+TILED_SPMM = _os.environ.get("MI_SPMM_TILED", "0") == "1"
+
 _plans = {}
 
 
@@ -545,6 +612,17 @@ def csr_plan(matrix: torch.Tensor) -> CsrPlan:
 
 def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D):
     lib = _lib.load()
+    tp = plan.tiles(D, transposed) if (TILED_SPMM and not DETERMINISTIC) else None
+    if tp is not None:
+        ev = plan.tile_values(val, D, transposed)
+        _lib.check(
+            lib.mi_spmm_tiled(tp["tile_edge0"].data_ptr(), tp["tile_row0"].data_ptr(), tp["ntiles"], tp["max_rows"],
+                              tp["ecr"].data_ptr(), ev.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split, _lib.ptr(Y),
+                              _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale), D,
+                              _lib.stream_ptr(val.device)),
+            "mi_spmm_tiled",
+        )
+        return
     if transposed:
         crow, col, sr, lr, n_rows = plan.crow_t, plan.col_t, plan.short_rows_t, plan.long_rows_t, plan.shape[1]
     else:

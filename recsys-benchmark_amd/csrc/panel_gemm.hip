@@ -28,6 +28,7 @@ using namespace tg;
 
 // (m, c): row and first of 4 consecutive "contiguous-side" indices; the contiguous side is cut into groups of gw.
 struct LoadGrouped {
+  static constexpr bool kLateConsts = false;
   const float *P;
   int ld, gw;
   long long gstride;

@@ -130,6 +130,80 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- tiled, edge-parallel ----
+// Round 3.  The row-per-wave kernels above keep a row's partial sum in registers, so a row's gathers form a dependent
+// chain and every XCD gathers rows of X from all over the 17.8 MB operand: L2 hit rate 0.38, 411 MB of fabric traffic
+// per launch against 54 MB compulsory (profiles/r02_spmm_counters.md).  This form:
+//   * a workgroup owns a TILE of consecutive output rows (at most kTileRows; tiles hold about the same number of edges,
+//     so a few hub rows make a small tile instead of a long tail) and keeps their sums in LDS for the whole launch;
+//   * the tile's edges were bucketed ONCE per sparsity pattern by COLUMN BLOCK (blocks of X of about 2 MiB, half an
+//     XCD's L2): every workgroup walks the column blocks in the same order, so the block being gathered from stays in
+//     each XCD's L2 while its workgroups use it (temporal locality across workgroups, no synchronisation: speed only);
+//   * one edge per LPR-lane group: a wave takes 64 packed edges with one coalesced load, hands them to its 64/LPR groups
+//     by shuffles, and every group gathers one row of X (LPR x float4) and adds val * x into the tile with ds_add_f32 —
+//     no per-row chain, nothing to combine across workgroups;
+//   * one coalesced pass writes the tile with the fused epilogue  Y = y;  acc_out = (acc_in + y) * scale.
+// The LDS adds land in an order that depends on timing, so the sums are not bit-reproducible from run to run (within
+// float rounding of each other); use_deterministic_algorithms(True) keeps the row-per-wave form.
+// Edge word: column | (row - tile's first row) << 23  (columns < 2^23, kTileRows <= 512).
+constexpr int kTileThreads = 512;
+constexpr int kTileColBits = 23;
+
+template <int LPR>
+__global__ __launch_bounds__(kTileThreads) void k_spmm_tiled(
+    const int *__restrict__ tile_edge0, const int *__restrict__ tile_row0, const int *__restrict__ ecr,
+    const float *__restrict__ eval, Seg2 X, float *__restrict__ Y, Seg2 acc_in, int has_acc_in,
+    float *__restrict__ acc_out, float scale) {
+  constexpr int D = LPR * 4;
+  constexpr int G = kWave / LPR;             // edges per wave-instruction
+  constexpr int U = 4;                       // gathers in flight per lane
+  extern __shared__ __attribute__((aligned(16))) float tile[];       // [rows][D]
+  const int t = blockIdx.x;
+  const int r0 = tile_row0[t], nr = tile_row0[t + 1] - r0;
+  const int e0 = tile_edge0[t], e1 = tile_edge0[t + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane % LPR, g = lane / LPR;
+  for (int i = threadIdx.x; i < nr * LPR; i += kTileThreads) st4(tile + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+  __syncthreads();
+  constexpr int kWaves = kTileThreads / kWave;
+  for (int base = e0 + wave * kWave; base < e1; base += kWaves * kWave) {
+    // 64 edges of this wave: one coalesced load each of the packed word and the value
+    const int me = base + lane;
+    const int cr = me < e1 ? ecr[me] : 0;
+    const float vv = me < e1 ? eval[me] : 0.f;
+    const int cnt = min(kWave, e1 - base);
+    for (int s0 = 0; s0 < cnt; s0 += G * U) {
+      int c[U];
+      float v[U];
+      float4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = s0 + u * G + g;              // < 64 always; edges past cnt carry val = 0 and column 0
+        c[u] = __shfl(cr, src & 63);
+        v[u] = __shfl(vv, src & 63);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, c[u] & ((1 << kTileColBits) - 1), D) + q * 4);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (s0 + u * G + g < cnt) {
+          float *dst = tile + ((unsigned)c[u] >> kTileColBits) * D + q * 4;
+          atomicAdd(dst + 0, v[u] * x[u].x);
+          atomicAdd(dst + 1, v[u] * x[u].y);
+          atomicAdd(dst + 2, v[u] * x[u].z);
+          atomicAdd(dst + 3, v[u] * x[u].w);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr * LPR; i += kTileThreads) {
+    const int row = r0 + i / LPR, qq = i % LPR;
+    epilogue4(ld4(tile + i * 4), row, qq, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+  }
+}
+
 // any D: one wave per row, lanes stride the columns of the dense operand
 __global__ __launch_bounds__(kBlock) void k_spmm_anyD(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
@@ -203,6 +277,50 @@ int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, const
     MI_LAUNCH("spmm_csr_rows", k_spmm_anyD, grid_for_waves(n_rows), kBlock, stream, crow, col, val, X, Y, A,
               has_acc, acc_out, scale, n_rows, D);
   }
+  return launch_status();
+}
+
+// The tiled form (k_spmm_tiled above).  tile_edge0 / tile_row0 int32[ntiles + 1]: first edge / first row of every tile
+// (rows of tile t: [tile_row0[t], tile_row0[t+1]), at most max_tile_rows); ecr int32[nnz] = column | local row << 23 and
+// eval fp32[nnz] in tile order, each tile's edges grouped by column block.  The row ranges of the tiles must cover
+// [0, n_rows) exactly once (every output row is written by its tile).
+int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, int32_t ntiles, int32_t max_tile_rows,
+                  const int32_t *ecr, const float *eval, const float *Xa, const float *Xb, int32_t x_split, float *Y,
+                  const float *acc_in_a, const float *acc_in_b, int32_t acc_split, float *acc_out, float scale,
+                  int32_t D, void *stream) {
+  if (ntiles < 0 || D <= 0 || max_tile_rows <= 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
+  if (ntiles == 0) return MI_OK;
+  if (!tile_edge0 || !tile_row0 || !ecr || !eval || !Xa || (!Y && !acc_out)) return MI_ERR_INVALID_ARG;
+  const size_t lds = (size_t)max_tile_rows * D * sizeof(float);
+  if (!vec_ok(D) || max_tile_rows > 512 || lds > 64 * 1024) return MI_ERR_UNSUPPORTED;      // 64 KiB: no opt-in needed
+  if (!aligned16(Xa) || (Xb && !aligned16(Xb)) || (Y && !aligned16(Y)) || (acc_in_a && !aligned16(acc_in_a)) ||
+      (acc_in_b && !aligned16(acc_in_b)) || (acc_out && !aligned16(acc_out)))
+    return MI_ERR_UNSUPPORTED;
+  Seg2 X{Xa, Xb ? Xb : Xa + (int64_t)x_split * D, Xb ? x_split : 0x7fffffff};
+  const int has_acc = acc_in_a != nullptr;
+  Seg2 A{acc_in_a, acc_in_b ? acc_in_b : acc_in_a, acc_in_b ? acc_split : 0x7fffffff};
+  hipEvent_t ea, eb;
+  const bool timed = mi::prof_acquire("spmm_tiled", &ea, &eb);
+#define CALL(LPR)                                                                                                       \
+  do {                                                                                                                  \
+    if (timed)                                                                                                          \
+      hipExtLaunchKernelGGL((k_spmm_tiled<LPR>), dim3(ntiles), dim3(kTileThreads), lds, (hipStream_t)stream, ea, eb, 0, \
+                            tile_edge0, tile_row0, ecr, eval, X, Y, A, has_acc, acc_out, scale);                        \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_spmm_tiled<LPR>), dim3(ntiles), dim3(kTileThreads), lds, (hipStream_t)stream, tile_edge0,  \
+                         tile_row0, ecr, eval, X, Y, A, has_acc, acc_out, scale);                                       \
+  } while (0)
+  switch (D / 4) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    case 16: CALL(16); break;
+    case 32: CALL(32); break;
+    case 64: CALL(64); break;
+    default: return MI_ERR_UNSUPPORTED;
+  }
+#undef CALL
   return launch_status();
 }
 

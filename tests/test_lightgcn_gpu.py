@@ -73,7 +73,10 @@ def _random_graph(U, I, nnz, seed, power=3.0):
     (2000, 3000, 60000, 64, 1),
     (10, 10, 0, 64, 2),           # empty graph: all rows empty
 ])
-def test_propagate_vs_oracle(U, I, nnz, D, L):
+@pytest.mark.parametrize("form", ["row-per-wave", "tiled"])
+def test_propagate_vs_oracle(U, I, nnz, D, L, form, monkeypatch):
+    # both SpMM forms: the row-per-wave kernels (default) and the tiled, LDS-accumulated form (opt-in: correct, slower)
+    monkeypatch.setattr(_kernels, "TILED_SPMM", form == "tiled")
     adj = _random_graph(U, I, nnz, seed=U + nnz)
     gen = torch.Generator().manual_seed(1)
     Eu = torch.randn(U, D, generator=gen)
