@@ -659,6 +659,7 @@ def self_launch(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")      # a failed / timed-out collective takes the rank down
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
@@ -770,7 +771,9 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import datetime
+
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
         # how many ranks the collective backend really joins: every rank adds 1 through an all-reduce
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
@@ -865,6 +868,30 @@ def main():
             def step():
                 next_batch()
                 graphed_step(x)
+
+            def timed_phases(iters=20):
+                """Per-phase device time of the sharded step (HIP events between the phases of `iters` eager-launched
+                steps; the collectives and the graph replay are the same calls the timed region makes)."""
+                names, acc = [], {}
+                for it in range(iters + 2):
+                    evs = [torch.cuda.Event(enable_timing=True)]
+                    evs[0].record()
+                    labels = []
+
+                    def mark(name):
+                        e = torch.cuda.Event(enable_timing=True)
+                        e.record()
+                        evs.append(e)
+                        labels.append(name)
+                    next_batch()
+                    graphed_step(x, mark=mark)
+                    torch.cuda.synchronize()
+                    if it < 2:
+                        continue
+                    names = labels
+                    for k, name in enumerate(labels):
+                        acc[name] = acc.get(name, 0.0) + evs[k].elapsed_time(evs[k + 1]) * 1e3
+                return [{"phase": n, "us": round(acc[n] / iters, 2)} for n in names]
         except Exception as e:  # noqa: BLE001 - keep the run alive: the eager step is always valid
             print(f"[bench] rank {rank}: capturing the local compute failed ({type(e).__name__}: {e}); eager",
                   file=sys.stderr, flush=True)
@@ -928,9 +955,11 @@ def main():
             step()
         fence()
         window_ms.append((time.perf_counter() - tw) / args.steps * 1e3)
-    pkg.check_index_errors()
     if sharded:
+        model.check_index_errors()       # collective: every rank raises together
         model.check_overflow()
+    else:
+        pkg.check_index_errors()
     if use_graph:
         graphs[-1].replay()         # p.grad are the buffers of the graph captured last: fill them for the check below
         torch.cuda.synchronize()
@@ -963,6 +992,9 @@ def main():
         ingraph = gather_in_graph_us(model, xs_ring, B, F, D, dev, copies=64)
         if not args.no_sweep and rank == 0:
             sweep = batch_sweep(model, dims, F, D, dev, args.ids)
+    sharded_phases = None
+    if sharded and graphed_local:
+        sharded_phases = timed_phases()          # every rank runs them (collectives inside); rank 0 reports its own
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1051,6 +1083,16 @@ def main():
             "roofline": roofline,
             "kernels_eager_dispatch_clock": kernels,
         }
+        if sharded:
+            rows0 = ring[0][:nx].view(torch.int64).view(B, F) + model.offsets
+            fill = torch.bincount((rows0 % world).reshape(-1), minlength=world)
+            out["sharded"] = {
+                "direct_rccl": model.__dict__.get("_comm") is not None,
+                "bucket_capacity_per_peer": int(model.capacity(B)), "observed_max_bucket_fill": int(fill.max()),
+                "bucket_slack": model.bucket_slack, "shard_rows": int(model.num_local_rows),
+                "phases_us": sharded_phases,
+                "phases_note": "device time between HIP events placed after each phase of 20 steps; at world=1 the all-to-alls "
+                               "are one-rank copies"}
         if not args.no_train_step and world == 1 and not sharded:
             out["train_step"] = train_step_lines(dims, D, hidden, p_drop, B, dev, args.ids, args.layout)
         if not args.no_cpu_baseline and world == 1:
@@ -1065,4 +1107,17 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:          # noqa: BLE001 - a rank that fails must say why and must not linger
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # peers may be blocked in a collective this rank will never join: leave at once with a failure status (the
+            # launcher then tears the other ranks down) instead of waiting in the process group's destructors
+            os._exit(1)
+        raise

@@ -736,6 +736,7 @@ MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, cons
  * recv[p*bytes .. ) <- rank p's send[me*bytes .. ) for every peer p (ncclGroupStart / Send / Recv / GroupEnd).
  * mi_comm_all_reduce_sum_f32: in place.  mi_comm_abort: for a communicator whose enqueued work does not complete
  * (ncclCommAbort: stops its kernels, frees it without waiting); mi_comm_destroy is the orderly end. */
+MI_API int mi_comm_available(void);   /* MI_OK when librccl could be loaded in this process; agree on it before mi_comm_init */
 MI_API int mi_comm_unique_id(char *id128);
 MI_API int mi_comm_init(const char *id128, int32_t world, int32_t rank, void **comm_out);
 MI_API int mi_comm_destroy(void *comm);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "mi_mix_expert_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "mi_rowdot_multi": [_p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_cross_bwd_head": [_p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p],
+    "mi_comm_available": [],
     "mi_comm_unique_id": [ctypes.c_char_p],
     "mi_comm_init": [ctypes.c_char_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "mi_comm_destroy": [_p],

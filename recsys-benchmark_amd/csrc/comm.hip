@@ -68,6 +68,10 @@ struct Comm {
 
 extern "C" {
 
+// MI_OK when a librccl could be loaded in THIS process (every rank checks for itself and the caller agrees on the answer
+// over its own process group BEFORE anyone enters mi_comm_init, which would otherwise wait forever for the rank that cannot)
+int mi_comm_available(void) { return rccl() ? MI_OK : MI_ERR_UNSUPPORTED; }
+
 // 128 bytes of rendezvous id, created on ONE rank and handed to the others by the caller (torch.distributed broadcast)
 int mi_comm_unique_id(char *id128) {
   const Rccl *r = rccl();

@@ -70,6 +70,48 @@ class DirectComm:
 
     def __init__(self, handle, world):
         self.handle, self.world = handle, world
+        self._pending = []          # (host time, event) markers behind collectives, oldest first
+        self._last_mark = 0.0
+        self._watchdog = None
+
+    # A collective of a library-owned communicator has no ProcessGroupNCCL watchdog behind it: when a peer dies (or
+    # raises and leaves), the surviving ranks would sit in the next all-to-all forever.  Every second or so a collective
+    # leaves an event behind; a daemon thread gives the oldest unfinished one MI_COMM_DEADLINE_S seconds (default 180),
+    # then aborts the communicator and EXITS the process with status 86 (never re-execs: the GPU-box rules) so that the
+    # launcher tears the job down.
+    def _mark(self, device):
+        import os
+        import threading
+        import time
+
+        now = time.monotonic()
+        if now - self._last_mark < 1.0:
+            return
+        self._last_mark = now
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._pending.append((now, ev))
+        if self._watchdog is None:
+            deadline = float(os.environ.get("MI_COMM_DEADLINE_S", "180"))
+
+            def watch():
+                import sys
+
+                from . import _lib
+                while self.handle is not None:
+                    time.sleep(1.0)
+                    while self._pending and self._pending[0][1].query():
+                        self._pending.pop(0)
+                    if self._pending and time.monotonic() - self._pending[0][0] > deadline:
+                        print(f"mi355x_recsys: a collective of the direct RCCL communicator has not finished within "
+                              f"{deadline:.0f} s (a peer is gone?); aborting the communicator and exiting", file=sys.stderr, flush=True)
+                        try:
+                            _lib.load().mi_comm_abort(self.handle)
+                        finally:
+                            os._exit(86)
+
+            self._watchdog = threading.Thread(target=watch, name="mi-comm-watchdog", daemon=True)
+            self._watchdog.start()
 
     @staticmethod
     def create(group, device):
@@ -85,6 +127,12 @@ class DirectComm:
             return None
         lib = _lib.load()
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        # every rank must be able to load RCCL itself BEFORE anyone enters mi_comm_init (which waits for all ranks)
+        can = torch.tensor([int(lib.mi_comm_available() == 0)], device=device)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN, group=group)
+        if int(can.item()) == 0:
+            warnings.warn("mi355x_recsys: RCCL cannot be loaded on every rank; using torch.distributed's collectives")
+            return None
         buf = ctypes.create_string_buffer(128)
         ok = 1
         if rank == 0:
@@ -151,6 +199,7 @@ class DirectComm:
         assert nbytes % self.world == 0
         _lib.check(_lib.load().mi_comm_all_to_all(self.handle, inp.data_ptr(), out.data_ptr(), nbytes // self.world,
                                                   _lib.stream_ptr(inp.device)), "mi_comm_all_to_all")
+        self._mark(inp.device)
 
     def all_reduce_sum(self, flat: torch.Tensor):
         from . import _lib
@@ -158,6 +207,7 @@ class DirectComm:
         assert flat.is_contiguous() and flat.dtype == torch.float32
         _lib.check(_lib.load().mi_comm_all_reduce_sum_f32(self.handle, flat.data_ptr(), flat.numel(), _lib.stream_ptr(flat.device)),
                    "mi_comm_all_reduce_sum_f32")
+        self._mark(flat.device)
 
     def close(self):
         from . import _lib
@@ -355,12 +405,38 @@ class ShardedDeepFM(nn.Module):
         """Slots per peer bucket for a batch of `batch` samples (every rank computes the same number)."""
         return field_bucket_capacity(self.field_dims, batch, self.world, self.bucket_slack)
 
+    def _collective_flags(self) -> List[int]:
+        """[bucket overflow, index-error bits] OR-ed (MAX, bit by bit) over the ranks: a rank that raised alone would leave
+        the others waiting in the next all-to-all, so every check is a collective and every rank raises together."""
+        from . import _lib
+
+        dev = self.embedding_shard.device
+        # (the error word lives with the HIP kernels; the CPU choreography tests inject torch restatements and have none)
+        err = _lib.err_word(dev).view(-1)[0] if dev.type == "cuda" else torch.zeros((), dtype=torch.int32)
+        flags = torch.stack([self.bucket_overflow.view(-1)[0].to(torch.int32), (err & 1).to(torch.int32),
+                             ((err >> 1) & 1).to(torch.int32)])
+        if self.world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        return [int(v) for v in flags.tolist()]
+
     def check_overflow(self):
-        """Synchronise; raise if any fixed-capacity bucket overflowed since the last check."""
-        if bool(self.bucket_overflow.item()):
+        """Synchronise; raise ON EVERY RANK if a fixed-capacity bucket overflowed on any rank since the last check."""
+        if self._collective_flags()[0]:
             self.bucket_overflow.zero_()
-            raise RuntimeError("sharded lookup: a peer bucket overflowed its fixed capacity (extreme id skew); "
+            raise RuntimeError("sharded lookup: a peer bucket overflowed its fixed capacity on some rank (extreme id skew); "
                                "raise bucket_slack (bucket_slack=world can never overflow)")
+
+    def check_index_errors(self):
+        """_lib.check_index_errors() for the sharded model: the ranks agree on the error bits first, then all raise."""
+        from . import _lib
+
+        _, oob, off_field = self._collective_flags()
+        if oob or off_field:
+            if self.embedding_shard.device.type == "cuda":
+                _lib.err_word(self.embedding_shard.device).zero_()
+            if oob:
+                raise IndexError("index out of range in embedding lookup on some rank (mi355x_recsys)")
+            raise IndexError("an id lies outside its own field's range on some rank (mi355x_recsys)")
 
     @torch.no_grad()
     def load_full_tables(self, embedding_weight: torch.Tensor, fc_weight: torch.Tensor):
@@ -464,7 +540,9 @@ class ShardedDeepFM(nn.Module):
         views = [v.view_as(p) for v, p in zip(flat.split(sizes), dense)]
         Wshape, w1shape = tuple(self.embedding_shard.shape), tuple(self.fc_shard.shape)
 
-        def step(x, y=None):
+        def step(x, y=None, mark=None):
+            """mark (optional callable): called with a phase name after each phase has been ENQUEUED (bench.py records a
+            timing event there; the default path calls nothing)."""
             if tuple(x.shape) != (batch_size, F):
                 raise ValueError(f"this step was captured for x of shape {(batch_size, F)}, got {tuple(x.shape)}")
             if y is not None and y.data_ptr() != ys.data_ptr():
@@ -472,13 +550,19 @@ class ShardedDeepFM(nn.Module):
             send_rows, _ = self.ops.route_buckets(x, self.offsets, world, self.num_rows, cap, self.bucket_overflow,
                                                   slot_out=slot)
             local_rows = torch.empty_like(send_rows)
+            if mark: mark("route (3 launches)")
             _all_to_all(self, local_rows, send_rows)
+            if mark: mark("all-to-all #1: row ids")
             packed = self.ops.gather_pack_rows(local_rows, self.embedding_shard, self.fc_shard)
+            if mark: mark("pack rows at the owner")
             with torch.no_grad():
                 _all_to_all(self, recv[:S], packed)
+                if mark: mark("all-to-all #2: packed rows")
                 graph.replay()
+                if mark: mark("local graph: slot gather + FM + MLP fwd, loss, whole bwd")
                 g_owner = torch.empty_like(packed)
                 _all_to_all(self, g_owner, g_recv[:S])
+                if mark: mark("all-to-all #3: gradient rows")
                 idx = local_rows.view(1, -1)
                 # the received rows are already scaled by 1/world; COO values must be contiguous (torch's sparse
                 # kernels read strided values wrongly), so the two column blocks are copied out
@@ -486,10 +570,12 @@ class ShardedDeepFM(nn.Module):
                                                                     check_invariants=False)
                 self.fc_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, D:D + 1].contiguous(), w1shape,
                                                              check_invariants=False)
+                if mark: mark("COO gradient column copies")
                 if self.__dict__.get("_comm") is not None:
                     self._comm.all_reduce_sum(flat)
                 else:
                     dist.all_reduce(flat, group=group)
+                if mark: mark("flat all-reduce of the dense gradients")
             for p, v in zip(dense, views):
                 p.grad = v
             return loss

@@ -25,6 +25,16 @@ logger = logging.getLogger("recsys_benchmark_amd.trainer")
 now = datetime.datetime.now
 
 
+def _check_errors(model) -> None:
+    """Deferred index / overflow checks at a logging step.  A row-sharded model checks COLLECTIVELY (the ranks agree on the
+    flags, then all raise together: a rank raising alone would leave its peers waiting in the next all-to-all)."""
+    if hasattr(model, "check_overflow"):
+        model.check_index_errors()
+        model.check_overflow()       # a peer bucket that overflowed dropped lookups
+    else:
+        _lib.check_index_errors()
+
+
 def _capturable(optimizers) -> bool:
     """False when an optimizer keeps its step count on the host (torch's Adam family without `capturable=True`): its
     step() refuses to run under capture, and a capture abandoned half-way is not something to recover from — so this
@@ -146,18 +156,14 @@ def train_epoch(dataloader, model, optimizers: Union[List[torch.optim.Optimizer]
         step(inputs.to(device, non_blocking=True), labels.to(device, non_blocking=True))
         if log_step and idx % log_step == 0:
             logger.info("Idx: %d - loss: %.4g", idx, (float(step.loss_sum) - first_sum) / (idx + 1))
-            _lib.check_index_errors()        # the reference's nn.Embedding raises on the offending batch; here at the next sync
-            if hasattr(model, "check_overflow"):
-                model.check_overflow()       # row-sharded model: a peer bucket that overflowed dropped lookups
+            _check_errors(model)             # the reference's nn.Embedding raises on the offending batch; here at the next sync
         if profiler:
             profiler.step()
         end_train = start = now()
         train_time += end_train - start_train
     n = step.steps - first_steps
     loss_dict = {"loss": (float(step.loss_sum) - first_sum) / n if n else 0.0}
-    _lib.check_index_errors()
-    if hasattr(model, "check_overflow"):
-        model.check_overflow()
+    _check_errors(model)
     logger.info("train_time: %s", train_time)
     logger.info("load_data_time: %s", load_data_time)
     logger.info("total_time: %s", now() - first_start)
