@@ -13,14 +13,32 @@ from .lightgcn import LightGCN, SingleLightGCN
 
 
 
+_fused_tail_before = None
+
+
 def use_deterministic_algorithms(on: bool = True) -> None:
-    """Bit-reproducible DeepFM / DCN training steps: dense table gradients by sorted, ordered accumulation instead of float
-    atomics, unsplit K in the library's GEMM, and the MLP tail on the fused kernels of csrc/tail.hip.  Slower than the
-    default; the reference's CPU path is deterministic, which is what this mode matches."""
+    """Bit-reproducible DeepFM training steps (and LightGCN propagation, whose row-per-wave SpMM has a fixed summation
+    order by construction): dense table gradients by sorted, ordered accumulation instead of float atomics, unsplit K in
+    the library's GEMM, and the MLP tail on the fused kernels of csrc/tail.hip (no atomics).  Slower than the default
+    (see DESIGN.md); the reference's CPU path is deterministic, which is what this mode matches.
+
+    Scope: the CrossNet heads of DCN_Mix / DCNv2 and the QR / CERP table backward still accumulate column sums and
+    duplicate rows with float atomics — under this mode those models raise NotImplementedError in training rather than
+    hand out gradients that only LOOK reproducible.
+
+    on=True forces the fused tail (the deterministic one) on; on=False restores whatever mlp.FUSED_TAIL was before the
+    switch (the MI_FUSED_TAIL environment setting or an explicit assignment), it does not turn the fused tail off."""
+    global _fused_tail_before
     from . import _kernels, mlp
 
+    if on:
+        if not _kernels.DETERMINISTIC:
+            _fused_tail_before = mlp.FUSED_TAIL
+        mlp.FUSED_TAIL = True
+    elif _kernels.DETERMINISTIC and _fused_tail_before is not None:
+        mlp.FUSED_TAIL = _fused_tail_before
+        _fused_tail_before = None
     _kernels.DETERMINISTIC = bool(on)
-    mlp.FUSED_TAIL = bool(on)
 
 
 __all__ = [

@@ -1,90 +1,101 @@
-"""Model factories and checkpoint helpers — reference: src/models/__init__.py:15-131.
+"""Model factories and checkpoint helpers with the reference's names and config-dict contract
+(src/models/__init__.py:15-131), written as one registry + one generic constructor.
 
-Same names, same config-dict handling ("name" popped and restored, `compile_model` popped for
-dcn_mix — there is nothing to torch.compile here: the cross network IS the hand-written kernel
-path, so the flag is accepted and ignored and state_dict keys never gain `_orig_mod.`).
+The contract that callers rely on and that is kept: the config dict is the keyword set of the model class; its "name" key
+selects the class (default "deepfm" for CTR models) and is taken out before construction — put back for graph models,
+left out for CTR models, exactly as the reference leaves the caller's dict; `compile_model` belongs to the factory, not to
+DCN_Mix (there is nothing to torch.compile here: the cross network IS the hand-written kernel path, so the flag is
+accepted, restored and ignored, and state_dict keys never gain `_orig_mod.`).
 """
+import importlib
 import os
-from typing import Dict, Type, Union
+from typing import Callable, Dict, NamedTuple, Optional, Tuple
 
 import torch
 
-from .deepfm import DeepFM
-from .lightgcn import IGraphBaseCore, LightGCN, SingleLightGCN
+
+class _Entry(NamedTuple):
+    module: str                      # module of this package that defines the class (imported on first use)
+    cls: str
+    checkpoint_field: Optional[str]  # directory name save_ctr_checkpoint uses for the embedding, None: not supported
+    factory_keys: Tuple[str, ...]    # config keys that belong to the factory: removed for the constructor, then restored
+    restore_name: bool               # whether "name" goes back into the caller's dict after construction
 
 
-def get_graph_model(num_users: int, num_items: int, model_config: Dict) -> IGraphBaseCore:
-    name = model_config.pop("name")
-    name_to_cls: Dict[str, Type[IGraphBaseCore]] = {
-        "lightgcn": LightGCN,
-        "single-lightgcn": SingleLightGCN,
-    }
-    if name == "hccf":
-        model_config["name"] = name
-        raise NotImplementedError("hccf is outside this build's scope (SURVEY.md §2.1 #14)")
-    assert name in name_to_cls
-    model = name_to_cls[name](num_users, num_items, **model_config)
-    model_config["name"] = name
-    return model
+_CTR: Dict[str, _Entry] = {
+    "deepfm": _Entry(".deepfm", "DeepFM", "deepfm", (), False),
+    "dcn_mix": _Entry(".dcn", "DCN_Mix", "dcn", ("compile_model",), False),
+    "dcn": _Entry(".dcn", "DCNv2", None, (), False),
+}
+_GRAPH: Dict[str, _Entry] = {
+    "lightgcn": _Entry(".lightgcn", "LightGCN", None, (), True),
+    "single-lightgcn": _Entry(".lightgcn", "SingleLightGCN", None, (), True),
+}
+_OUT_OF_SCOPE = {"hccf": "hccf is outside this build's scope (SURVEY.md §2.1 #14)"}
+_LOADABLE = ("deepfm", "dcn_mix")    # the model kinds load_ctr_model knows (the reference's `load` classmethods)
 
 
-def load_graph_model(checkpoint_path: str, strict=True) -> IGraphBaseCore:
+def _resolve(entry: _Entry):
+    return getattr(importlib.import_module(entry.module, __package__), entry.cls)
+
+
+def _build(registry: Dict[str, _Entry], config: dict, default: Optional[str], make: Callable):
+    """Take "name" (and the factory's own keys) out of `config`, call make(cls, config), put back what the contract says."""
+    name = config.pop("name", default)
+    try:
+        if name in _OUT_OF_SCOPE:
+            raise NotImplementedError(_OUT_OF_SCOPE[name])
+        entry = registry.get(name)
+        if entry is None:
+            raise NotImplementedError(f"unknown model name {name!r}")
+        held = {k: config.pop(k) for k in entry.factory_keys if k in config}
+        try:
+            return make(_resolve(entry), config)
+        finally:
+            config.update(held)
+    finally:
+        entry = registry.get(name)
+        if name is not None and (name in _OUT_OF_SCOPE or (entry is not None and entry.restore_name)):
+            config["name"] = name
+
+
+def get_graph_model(num_users: int, num_items: int, model_config: Dict):
+    return _build(_GRAPH, model_config, None, lambda cls, cfg: cls(num_users, num_items, **cfg))
+
+
+def get_ctr_model(field_dims, model_config: dict):
+    return _build(_CTR, model_config, "deepfm", lambda cls, cfg: cls(field_dims, **cfg))
+
+
+def load_ctr_model(model_config, checkpoint, strict=True, *, empty_embedding=False):
+    loadable = {k: _CTR[k] for k in _LOADABLE}
+    return _build(loadable, model_config, "deepfm",
+                  lambda cls, cfg: cls.load(checkpoint, strict, empty_embedding=empty_embedding))
+
+
+def load_graph_model(checkpoint_path: str, strict=True):
     checkpoint = torch.load(checkpoint_path, map_location="cpu")
     model = get_graph_model(checkpoint["num_users"], checkpoint["num_items"], checkpoint["model_config"])
     model.load_state_dict(checkpoint["state_dict"], strict=strict)
     return model
 
 
-def save_cf_emb_checkpoint(model: Union[LightGCN, SingleLightGCN], checkpoint_dir: str, name: str = "target"):
+def _save_embedding(emb, checkpoint_dir: str, field_name: str, name: str) -> None:
+    field_dir = os.path.join(checkpoint_dir, field_name)
+    os.makedirs(field_dir, exist_ok=True)
+    torch.save(emb.state_dict(), os.path.join(field_dir, f"{name}.pth"))
+
+
+def save_cf_emb_checkpoint(model, checkpoint_dir: str, name: str = "target"):
     """{checkpoint_dir}/{field_name}/{name}.pth per embedding, as the reference."""
     for field_name, emb in model.get_embs():
-        field_dir = os.path.join(checkpoint_dir, field_name)
-        os.makedirs(field_dir, exist_ok=True)
-        torch.save(emb.state_dict(), os.path.join(field_dir, f"{name}.pth"))
-
-
-def get_ctr_model(field_dims, model_config: dict):
-    name = "deepfm"
-    if "name" in model_config:
-        name = model_config.pop("name")
-    if name == "deepfm":
-        return DeepFM(field_dims, **model_config)
-    elif name == "dcn_mix":
-        from .dcn import DCN_Mix
-
-        compile_model = model_config.pop("compile_model", True)
-        model = DCN_Mix(field_dims, **model_config)
-        model_config["compile_model"] = compile_model
-        return model
-    elif name == "dcn":
-        from .dcn import DCNv2
-
-        return DCNv2(field_dims, **model_config)
-    raise NotImplementedError()
-
-
-def load_ctr_model(model_config, checkpoint, strict=True, *, empty_embedding=False):
-    name = "deepfm"
-    if "name" in model_config:
-        name = model_config.pop("name")
-    if name == "deepfm":
-        return DeepFM.load(checkpoint, strict, empty_embedding=empty_embedding)
-    elif name == "dcn_mix":
-        from .dcn import DCN_Mix
-
-        return DCN_Mix.load(checkpoint, strict, empty_embedding=empty_embedding)
-    raise NotImplementedError()
+        _save_embedding(emb, checkpoint_dir, field_name, name)
 
 
 def save_ctr_checkpoint(model, checkpoint_dir: str, name: str = "target"):
     """{checkpoint_dir}/{deepfm|dcn}/{name}.pth holding the embedding's state_dict."""
-    emb = model.embedding
-    if isinstance(model, DeepFM):
-        field_name = "deepfm"
-    elif type(model).__name__ == "DCN_Mix":
-        field_name = "dcn"
-    else:
+    fields = {e.cls: e.checkpoint_field for e in _CTR.values() if e.checkpoint_field}
+    field_name = next((f for cls in type(model).__mro__ if (f := fields.get(cls.__name__))), None)
+    if field_name is None:
         raise NotImplementedError(f"Not supported for {model.__class__=}")
-    field_dir = os.path.join(checkpoint_dir, field_name)
-    os.makedirs(field_dir, exist_ok=True)
-    torch.save(emb.state_dict(), os.path.join(field_dir, f"{name}.pth"))
+    _save_embedding(model.embedding, checkpoint_dir, field_name, name)

@@ -69,7 +69,7 @@ def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[Lis
     """groups: mlp._groups(seq).  The plan (hidden layers; the head is groups[-1]) or None when the pattern does not fit."""
     if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
         return None
-    if len(groups) < 2 or groups[-1][0] != "plain":
+    if len(groups) < 2 or groups[-1][0] != "plain" or len(groups) - 1 > 8:      # (the mask kernel takes <= 8 layers)
         return None
     head = groups[-1][1]
     if not (isinstance(head, nn.Linear) and head.out_features == 1):
@@ -83,9 +83,16 @@ def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[Lis
             return None
         if lin.in_features != width or lin.in_features % 8 or lin.out_features % 8 or lin.out_features > 1024:
             return None
+        if dp is not None and dp.training and not 0.0 <= float(dp.p) < 1.0:      # p = 1 drops everything: general path
+            return None
+        if any(t is not None and (t.dtype != torch.float32 or t.device != x.device)
+               for t in (lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+            return None
         plan.append(_Layer(lin, bn, float(dp.p) if (dp is not None and dp.training) else 0.0))
         width = lin.out_features
     if head.in_features != width or x.shape[0] < 2:
+        return None
+    if any(t is not None and (t.dtype != torch.float32 or t.device != x.device) for t in (head.weight, head.bias)):
         return None
     return plan
 

@@ -22,6 +22,42 @@ def declared():
     return out
 
 
+PROTO = re.compile(r"MI_API\s+((?:const\s+)?[\w\s\*]+?)\b(mi_\w+)\s*\(([^;]*?)\)\s*;", re.S)
+
+
+def prototypes():
+    """name -> normalised prototype text (return type + parameter TYPES, names and comments dropped)."""
+    out = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        for ret, name, args in PROTO.findall(open(h).read()):
+            args = re.sub(r"/\*.*?\*/", "", args, flags=re.S)
+            norm = []
+            for a in args.split(","):
+                a = " ".join(a.split())
+                a = re.sub(r"\b\w+$", "", a).strip() if not a.endswith("*") and a not in ("void", "") else a
+                norm.append(a.replace(" *", "*").replace("* ", "*"))
+            out[name] = " ".join(ret.split()) + "(" + ",".join(norm) + ")"
+    return out
+
+
+def test_changing_an_existing_prototype_requires_an_abi_version_bump():
+    """tests/golden/abi_prototypes.json is the prototype set of the ABI version it names.  ADDING entry points is free;
+    an existing prototype that differs from the snapshot must come with a higher MI_ABI_VERSION (and a refreshed
+    snapshot): a C or ctypes caller built against the old header would otherwise misbind its arguments silently."""
+    import json
+
+    snap = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_prototypes.json")))
+    header = open(os.path.join(ROOT, "include", "mi355x_recsys.h")).read()
+    version = int(re.search(r"#define MI_ABI_VERSION (\d+)", header).group(1))
+    now = prototypes()
+    changed = [n for n, p in snap["prototypes"].items() if n in now and now[n] != p]
+    removed = [n for n in snap["prototypes"] if n not in now]
+    if changed or removed:
+        assert version > snap["abi_version"], f"prototypes changed without a version bump: {changed + removed}"
+    else:
+        assert version == snap["abi_version"], "MI_ABI_VERSION moved: refresh tests/golden/abi_prototypes.json"
+
+
 def test_header_declares_entry_points():
     d = declared()
     assert "mi_gather_fm_fwd" in d and d["mi_gather_fm_fwd"] == 14
@@ -70,6 +106,20 @@ def test_header_compiles_as_plain_c_and_struct_layouts_match_the_bindings(tmp_pa
         import pytest
 
         pytest.skip("no gcc in this environment")
+    from recsys_benchmark_amd import tail as _tailmod
+
+    for cname, ct in (("mi_tail_bn_fwd", _tailmod._BnFwd), ("mi_tail_bn_bwd", _tailmod._BnBwd)):
+        src2 = tmp_path / f"{cname}.c"
+        lines2 = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "mi355x_recsys.h")}"',
+                  'int main(void) {', f'  printf("%zu\\n", sizeof({cname}));']
+        lines2 += [f'  printf("%zu\\n", offsetof({cname}, {f}));' for f, _ in ct._fields_]
+        lines2 += ['  return 0;', '}']
+        src2.write_text("\n".join(lines2))
+        exe2 = tmp_path / cname
+        subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", str(src2), "-o", str(exe2)])
+        got = [int(v) for v in subprocess.check_output([str(exe2)]).split()]
+        assert got[0] == ctypes.sizeof(ct), cname
+        assert got[1:] == [getattr(ct, f).offset for f, _ in ct._fields_], cname
     fields = [name for name, _ in _kernels._GemmProblem._fields_]
     src = tmp_path / "layout.c"
     lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "mi355x_recsys.h")}"',

@@ -365,3 +365,32 @@ def test_multi_problem_launch_splits_for_the_whole_launch(monkeypatch):
     assert _kernels.multi_splits([dict(M=64, N=64, K=M, splitk=7)]) == [7]
     monkeypatch.setattr(_kernels, "DETERMINISTIC", True)
     assert _kernels.multi_splits(c3) == [1] * 12
+
+
+def test_deterministic_switch_restores_the_fused_tail_setting_and_refuses_crossnet_training():
+    """use_deterministic_algorithms(False) must give back the mlp.FUSED_TAIL that was in effect before (round 2 switched
+    the default-on fused tail OFF for every later run), and DCN training under the switch must refuse: its backward
+    accumulates with float atomics, which the switch promises not to use."""
+    import pytest
+
+    from recsys_benchmark_amd import _kernels, mlp
+    from recsys_benchmark_amd.dcn import DCN_Mix
+
+    before = mlp.FUSED_TAIL
+    try:
+        for setting in (True, False):
+            mlp.FUSED_TAIL = setting
+            pkg.use_deterministic_algorithms(True)
+            assert mlp.FUSED_TAIL is True and _kernels.DETERMINISTIC
+            pkg.use_deterministic_algorithms(True)          # twice: the remembered setting must survive
+            pkg.use_deterministic_algorithms(False)
+            assert mlp.FUSED_TAIL is setting and not _kernels.DETERMINISTIC
+        pkg.use_deterministic_algorithms(False)             # off while off: nothing to restore, nothing changes
+        assert mlp.FUSED_TAIL is False
+        m = DCN_Mix([3, 4], 4, [8], num_layers=1, num_experts=2, rank=2)
+        pkg.use_deterministic_algorithms(True)
+        with pytest.raises(NotImplementedError):
+            m(torch.tensor([[0, 1]]))
+    finally:
+        pkg.use_deterministic_algorithms(False)
+        mlp.FUSED_TAIL = before
