@@ -6,6 +6,7 @@ path is held to the same multiple of the stock path's own error.  Dropout: the o
 use (tests/tail_helpers.py restates the bit generator).  Integer / bookkeeping state (num_batches_tracked, masks,
 bit-identical reruns) is exact."""
 import copy
+import os
 
 import pytest
 import torch
@@ -105,13 +106,17 @@ def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p):
     fs, fx, fa, fout = _run_fused(seq, x, add, seed_value)
     (fout * G.to(DEV)).sum().backward()
 
-    def check(name, got, r64, r32, k=32.0, floor=1e-6):
+    def check(name, got, r64, r32, k=8.0, floor=1e-6):
         """|got - r64| <= k * max(|r32 - r64|, floor-scaled noise): the fused result is as close to the float64 value as the
-        stock float32 modules are, up to the factor k (different summation order / fused multiply-adds)."""
+        stock float32 modules are, up to the factor k (different summation order / fused multiply-adds).  k = 8: over
+        every tensor of every case of this test the measured ratio is at most 4.1 (MI_TEST_REPORT=1 prints them; round 2
+        allowed 32)."""
         got, r64, r32 = got.detach().double().cpu(), r64.detach().double(), r32.detach().double()
         scale = r64.abs().max().clamp_min(1e-30)
         err_f = (got - r64).abs().max() / scale
         err_s = (r32 - r64).abs().max() / scale
+        if os.environ.get("MI_TEST_REPORT"):
+            print(f"RATIO {name} M={M} K={K} p={p}: fused {float(err_f):.3e} stock {float(err_s):.3e} ratio {float(err_f / err_s.clamp_min(1e-30)):.2f}")
         assert err_f <= max(k * err_s, floor), f"{name}: fused {err_f:.3e} vs stock {err_s:.3e} (relative to max |ref|)"
 
     check("out", fout, ref64[3], ref32[3])
