@@ -698,6 +698,11 @@ MI_API int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, co
                                 int32_t N, int32_t K, const mi_tail_bn_bwd *sums, void *stream);
 MI_API int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
                                  const int32_t *lds, uint8_t *const *bits, int32_t M, void *stream);
+/* the same launch also zero-fills zero_buf[0 .. zero_floats) (a multiple of 4 floats, 16-byte aligned): the backward pass's
+ * accumulation buffer (split-K weight gradients) without a fill launch of its own */
+MI_API int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
+                                   const int32_t *lds, uint8_t *const *bits, int32_t M, float *zero_buf,
+                                   int64_t zero_floats, void *stream);
 MI_API int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
                             float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
                             float *part, float *a_out, int32_t M, int32_t N, int32_t K, void *stream);

@@ -42,7 +42,10 @@ struct MaskJob {
   uint32_t thr[8];
   int n;
 };
-__global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64_t *seed) {
+__global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4) {
+  // rides along: the zero fill of the backward pass's accumulation buffer (split-K weight gradients), one launch less
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nzero4; i += (int64_t)gridDim.x * kBlock)
+    zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < j.n; ++l) {
     const uint64_t sd = layer_seed(seed, j.salt[l]);
     const uint32_t thr = j.thr[l];
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float
 //   wpart[blk][n] = sum_m g[m] * a(m, n),  wpart[blk][N] = sum_m g[m]    (dw / db pieces)
 // One workgroup = 16 rows x all features per trip; per-workgroup partials are joined by k_bn_finalize_bwd in block
 // order (deterministic).
+constexpr int kHeadRows = 8;
 __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float *__restrict__ g, const float *__restrict__ w,
                                                           float *__restrict__ DY, float *__restrict__ part,
                                                           float *__restrict__ wpart, int M, int N) {
@@ -507,12 +511,12 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
   if (cv) { u_ = ld4(x.mu + c); sc = ld4(x.sc + c); be = ld4(x.be + c); ww = ld4(w + c); }
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int mb = blockIdx.x * rows_per, me = min(M, mb + rows_per);
-  for (int m4 = mb; m4 < me; m4 += 4) {          // 4 rows in flight per thread
-    float4 z[4];
-    uint32_t kb[4];
-    float gv[4];
+  for (int m4 = mb; m4 < me; m4 += kHeadRows) {   // kHeadRows rows in flight per thread: 16 rows per workgroup = 2 trips
+    float4 z[kHeadRows];
+    uint32_t kb[kHeadRows];
+    float gv[kHeadRows];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kHeadRows; ++u) {
       const int m = min(m4 + u, me - 1);
       gv[u] = g[m];
       if (cv) {
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kHeadRows; ++u) {
       const int m = m4 + u;
       if (m >= me) break;
       const float gm = gv[u];
@@ -843,15 +847,16 @@ int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float
   return mi_tail_fwd_gemm_m(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, nullptr, stream);
 }
 
-int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
-                          uint8_t *const *bits, int32_t M, void *stream) {
-  if (nlayers < 0 || nlayers > 8 || M < 0) return MI_ERR_INVALID_ARG;
-  if (nlayers == 0 || M == 0) return MI_OK;
-  if (!seed || !salts || !ps || !lds || !bits) return MI_ERR_INVALID_ARG;
+int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
+                            uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, void *stream) {
+  if (nlayers < 0 || nlayers > 8 || M < 0 || zero_floats < 0 || (zero_floats & 3)) return MI_ERR_INVALID_ARG;
+  if (zero_floats && (!zero_buf || !aligned16(zero_buf))) return MI_ERR_INVALID_ARG;
+  if ((nlayers == 0 || M == 0) && zero_floats == 0) return MI_OK;
+  if (nlayers && M && (!seed || !salts || !ps || !lds || !bits)) return MI_ERR_INVALID_ARG;
   MaskJob j;
   j.n = 0;
-  int64_t most = 0;
-  for (int l = 0; l < nlayers; ++l) {
+  int64_t most = zero_floats / 4;
+  for (int l = 0; l < nlayers && M > 0; ++l) {
     if (ps[l] <= 0.f) continue;
     if (!bits[l] || lds[l] <= 0 || lds[l] % 8 || ps[l] >= 1.f) return MI_ERR_INVALID_ARG;
     j.bits[j.n] = bits[l];
@@ -861,11 +866,18 @@ int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *s
     most = j.nbytes[j.n] > most ? j.nbytes[j.n] : most;
     ++j.n;
   }
-  if (j.n == 0) return MI_OK;
+  if (j.n == 0 && zero_floats == 0) return MI_OK;
   int64_t grid = (most + kBlock - 1) / kBlock;
   if (grid > kMaxGrid) grid = kMaxGrid;
-  MI_LAUNCH("tail_dropout_masks", k_tail_dropmask, (int)grid, kBlock, stream, j, seed);
+  if (grid < 1) grid = 1;
+  MI_LAUNCH("tail_dropout_masks", k_tail_dropmask, (int)grid, kBlock, stream, j, seed, reinterpret_cast<float4 *>(zero_buf),
+            zero_floats / 4);
   return launch_status();
+}
+
+int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
+                          uint8_t *const *bits, int32_t M, void *stream) {
+  return mi_tail_dropout_masks_z(seed, nlayers, salts, ps, lds, bits, M, nullptr, 0, stream);
 }
 
 int64_t mi_tail_part_elems(int32_t M, int32_t N) { return (int64_t)((M + BM - 1) / BM) * N * 2; }

@@ -97,7 +97,9 @@ def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[Lis
     return plan
 
 
-def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev) -> List[Optional[torch.Tensor]]:
+def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+    """Keep bits of every layer with dropout, one launch; `zero_buf` (optional, fp32, a multiple of 4 elements) is
+    zero-filled by the same launch.  Without any dropout layer nothing is launched and zero_buf is NOT touched."""
     lib = _lib.load()
     n = len(plan)
     bits = [torch.empty(M * L.lin.out_features // 8, dtype=torch.uint8, device=dev) if L.p > 0 else None for L in plan]
@@ -107,8 +109,9 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev) -> List[Optional
     ps = (ctypes.c_float * n)(*[L.p for L in plan])
     lds = (ctypes.c_int32 * n)(*[L.lin.out_features for L in plan])
     ptrs = (ctypes.c_void_p * n)(*[0 if b is None else b.data_ptr() for b in bits])
-    _lib.check(lib.mi_tail_dropout_masks(seed.data_ptr(), n, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
-                                         ctypes.addressof(ptrs), M, _lib.stream_ptr(dev)), "mi_tail_dropout_masks")
+    _lib.check(lib.mi_tail_dropout_masks_z(seed.data_ptr(), n, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
+                                           ctypes.addressof(ptrs), M, _lib.ptr(zero_buf), zero_buf.numel() if zero_buf is not None else 0,
+                                           _lib.stream_ptr(dev)), "mi_tail_dropout_masks_z")
     return bits
 
 
@@ -131,7 +134,13 @@ class FusedTailFn(torch.autograd.Function):
         Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
         w_head = _kernels._f32c(params[4 * k]).view(-1)
         b_head = params[4 * k + 1]
-        bits = _masks(seed, plan, M, dev)
+        # the backward pass's accumulation buffer (split-K weight gradients + the exactly-zero Linear bias gradients) is
+        # zero-filled by the mask launch of THIS forward when there is one: no fill launch in the backward
+        zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
+        zsize = (zsize + 3) // 4 * 4
+        zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if any(L.p > 0 for L in plan) else None
+        bits = _masks(seed, plan, M, dev, zeros)
+        ctx.zeros = zeros
         keep_inputs = not _kernels.DETERMINISTIC
         Zs, consts, acts = [], [], []
         prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
@@ -203,7 +212,10 @@ class FusedTailFn(torch.autograd.Function):
         # one zero-filled buffer for everything that must start at zero: the split-K weight gradients and the (exactly zero)
         # gradients of the hidden Linear biases — one fill launch instead of 2k
         sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
-        zeros = torch.zeros((sum(a + b for a, b in sizes),), dtype=torch.float32, device=dev)
+        zeros = ctx.zeros                      # filled by the forward's mask launch; a second backward needs a fresh one
+        ctx.zeros = None
+        if zeros is None:
+            zeros = torch.zeros((sum(a + b for a, b in sizes),), dtype=torch.float32, device=dev)
         zoff = [0]
         for a, b in sizes:
             zoff.append(zoff[-1] + a + b)
