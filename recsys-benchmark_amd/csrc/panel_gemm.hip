@@ -29,6 +29,7 @@ using namespace tg;
 // (m, c): row and first of 4 consecutive "contiguous-side" indices; the contiguous side is cut into groups of gw.
 struct LoadGrouped {
   static constexpr bool kLateConsts = false;
+  static constexpr bool kLean = false;      // the group of a column changes with the slice: general addressing
   const float *P;
   int ld, gw;
   long long gstride;
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(kThreads) void k_panel_gemm(PanelArgs a) {
   for (int s = 0; s < NSUB; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   const KcOperand<64, LoadPlain> opR{LoadPlain{a.A, a.lda}, m0, rows_valid, a.K};
-  if constexpr (B_KC) main_loop<true, true, NS>(acc, lds, 0, a.K, opR, KcOperand<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
-  else main_loop<true, true, NS>(acc, lds, 0, a.K, opR, OtOperand<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
+  if constexpr (B_KC) main_loop<true, true, NS>(acc, lds, 0, a.K, opR, KcOperandG<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
+  else main_loop<true, true, NS>(acc, lds, 0, a.K, opR, OtOperandG<16 * NS, LoadGrouped>{a.B, n0, cols_valid, a.K});
 
   // ---- epilogue through an LDS tile: thread -> (row, float4 of columns); whole row segments per wave-instruction
   float *T = lds;

@@ -14,6 +14,7 @@
 //                      in slice order (no atomics anywhere: the step is bit-reproducible).
 // The dropout decisions are ONE BIT per element, written once per step (k_tail_dropmask) and read by every kernel that
 // needs them (a byte per float4 of features).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -270,9 +271,9 @@ struct FwdArgs {
   BnFwd bn;           // MERGE: the statistics behind x's constants, joined here (x.mu / sc / be are then not read)
 };
 
-template <bool ACT, bool MERGE>
+template <bool ACT, bool MERGE, bool DMA = false>
 __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + (MERGE ? kCstFloats : 0)];
+  __shared__ __attribute__((aligned(16))) float lds[DMA ? kDmaLdsFloats : kLdsFloats + (MERGE ? kCstFloats : 0)];
   const int mt_total = (a.M + BM - 1) / BM;
   const int tile = xcd_logical(blockIdx.x, mt_total * a.ntn);
   if (tile < 0) return;
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
     const bool writer = tile == 0;
     main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadActL>>{Tee<LoadActL>{actl, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC,
                           make_pre([&]() { bn_merge_fwd<kThreads - kProd>(a.bn, a.M, a.K, cst, writer, (int)threadIdx.x); }));
-  } else if constexpr (ACT)
+  } else if constexpr (DMA && ACT)      // the weights by LDS-DMA (two loader waves), the activation through two producer waves
+    main_loop_dma(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>, 128>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K},
+                  a.W, a.ldw, n0, cols_valid);
+  else if constexpr (DMA)
+    main_loop_dma(acc, lds, 0, a.K, KcOperand<64, LoadPlain, 128>{xp, m0, rows_valid, a.K}, a.W, a.ldw, n0, cols_valid);
+  else if constexpr (ACT)
     main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
   else main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
@@ -762,12 +768,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_wgrad(WgradArgs a) {
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadAct act = make_act(a.prev);
   const LoadPlain xp{a.prev.Z, a.prev.ld};
+  // (general addressing: two transformed, transposed operands with three register stages each leave no room for the
+  // lean form's per-thread offsets — it spilled; this kernel only runs in deterministic mode)
   auto run = [&](const auto &opR) {       // both operands have the batch as the slow index: transposed into KC tiles
-    if constexpr (ACT) main_loop<true, true>(acc, lds, mb, me, opR, OtOperand<BNT, LoadAct>{act, k0, cols_valid, me});
-    else main_loop<true, true>(acc, lds, mb, me, opR, OtOperand<BNT, LoadPlain>{xp, k0, cols_valid, me});
+    if constexpr (ACT) main_loop<true, true>(acc, lds, mb, me, opR, OtOperandG<BNT, LoadAct>{act, k0, cols_valid, me});
+    else main_loop<true, true>(acc, lds, mb, me, opR, OtOperandG<BNT, LoadPlain>{xp, k0, cols_valid, me});
   };
-  if constexpr (DZ) run(OtOperand<64, LoadDz>{dzl, n0, nrows_valid, me});
-  else run(OtOperand<64, LoadPlain>{dyp, n0, nrows_valid, me});
+  if constexpr (DZ) run(OtOperandG<64, LoadDz>{dzl, n0, nrows_valid, me});
+  else run(OtOperandG<64, LoadPlain>{dyp, n0, nrows_valid, me});
 
   const int r = lane & 15, g = lane >> 4;
   const int n = wave < 4 ? n0 + wave * 16 + r : a.N;      // waves 4-7 were the producers
@@ -835,8 +843,12 @@ int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const flo
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(N, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
+  static const bool dma = [] { const char *e = getenv("MI_TAIL_DMA"); return e && e[0] == '1'; }();
+
   if (x_stats) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, true>), grid8(tiles), kThreads, stream, a);
+  else if (x_mu && dma) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, false, true>), grid8(tiles), kThreads, stream, a);
   else if (x_mu) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, false>), grid8(tiles), kThreads, stream, a);
+  else if (dma) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<false, false, true>), grid8(tiles), kThreads, stream, a);
   else MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<false, false>), grid8(tiles), kThreads, stream, a);
   return launch_status();
 }

@@ -30,6 +30,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 512;     // 8 waves: 4 consumers (MFMA, one per SIMD) + 4 producers (load / transform / LDS write)
 constexpr int kProd = 256;        // producer threads; their index is threadIdx.x - 256
+constexpr int kWaveLanes = 64;
 constexpr int BM = 64;            // rows of R per workgroup (4 waves x 16)
 constexpr int BK = 32;            // reduction indices per stage
 constexpr int NSUB = 7;           // 16-column sub-tiles per wave
@@ -87,13 +88,43 @@ struct Drop {
 // finish(raw, consts, m, c) turns them into the operand value right before the LDS write, one or two MFMA phases later.
 // (m, c) = row and first of 4 consecutive features of a [M, ld] matrix.
 struct NoConsts {};
+// LEAN addressing (round 3).  The f32 MFMA runs on the vector ALU's rate and every VALU instruction of a producer wave is
+// paid by the matrix pipe of its SIMD (measured: +64 VALU per producer phase = +12 us per product; SQ_INSTS_VALU 3.06 M
+// against 0.75 M MFMAs in the fused forward product, profiles/r03_tail_sq_counters.csv).  A producer phase of round 2
+// spent ~94 vector instructions on addresses, clamps and selects per slice.  Lean form: an operand element's address is
+//   UNIFORM base (pointers shifted to the tile's first row and the slice's first reduction index: scalar registers, SALU)
+//   + a per-thread 32-bit byte offset that never changes (row inside the tile x pitch + column inside the slice),
+// so a load is `global_load_dwordx4 v, v_off, s[base]` with no vector arithmetic at all; clamps of rows beyond the tile
+// happen once, in the offsets; the zeroing of reduction indices beyond the end exists only in the LAST slice, which takes
+// the general path (uniform branch).  Each loader L provides:
+//   UBase ubase(row, col)            the uniform part for a tile whose element (0, 0) is (row, col); with dropout
+//                                    (row * ld + col) % 8 == 0 is required (callers pass col = 0 or a multiple of 32)
+//   TC    tconst(r, c)               the thread-constant part of element (r, c) relative to it
+//   Raw   fetch_u(ub, tc)            issue the loads
+//   Consts consts_u(ub, c)           per-column constants of column c relative to ub (KC operands: c = the thread's column
+//                                    inside the slice)
+//   float4 finish_u(raw, k, ub, tc)  form the operand value
+// An empty volatile asm keeps hipcc from turning the (uniform, rarely taken) partial-slice branches into selects that every
+// slice would execute: a block with a volatile asm cannot be speculated.
+#define PARTIAL_SLICE_ONLY() asm volatile("; partial slice only" ::: "memory")
+__device__ __forceinline__ float4 vld4u(const float *base, uint32_t boff) {
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + boff);
+}
 // Plain: the matrix itself (weights, the embedding block, a finished gradient).
 struct LoadPlain {
   static constexpr bool kLateConsts = false;
+  static constexpr bool kLean = true;
   const float *P;
   int ld;
   struct Raw { float4 a; };
   typedef NoConsts Consts;
+  struct UBase { const float *p; };
+  struct TC { uint32_t off; };
+  __device__ __forceinline__ UBase ubase(int row, int col) const { return UBase{P + (int64_t)row * ld + col}; }
+  __device__ __forceinline__ TC tconst(int r, int c) const { return TC{(uint32_t)(r * ld + c) * 4u}; }
+  __device__ __forceinline__ Raw fetch_u(const UBase &u, const TC &t) const { return Raw{vld4u(u.p, t.off)}; }
+  __device__ __forceinline__ Consts consts_u(const UBase &, int) const { return Consts{}; }
+  __device__ __forceinline__ float4 finish_u(const Raw &r, const Consts &, const UBase &, const TC &) const { return r.a; }
   __device__ __forceinline__ Raw fetch(int m, int c) const { return Raw{vld4(P + (int64_t)m * ld + c)}; }
   __device__ __forceinline__ Consts consts(int) const { return Consts{}; }
   __device__ __forceinline__ float4 finish(const Raw &r, const Consts &, int, int) const { return r.a; }
@@ -105,12 +136,36 @@ template <> struct ConstsTrait<lds_cfp> { static constexpr bool kLate = true; };
 template <class CP>
 struct LoadActT {
   static constexpr bool kLateConsts = ConstsTrait<CP>::kLate;
+  static constexpr bool kLean = true;
   const float *Z;
   int ld;
   CP mu, sc, be;
   Drop drop;
   struct Raw { float4 z; uint32_t keep; };
   struct Consts { float4 u, s, b; };
+  struct UBase { const float *z; const uint8_t *bits; CP mu, sc, be; };
+  struct TC { uint32_t off, koff, nib; };     // byte offset of z; byte offset and nibble shift (0 / 4) of the keep bits
+  __device__ __forceinline__ UBase ubase(int row, int col) const {
+    const int64_t e = (int64_t)row * ld + col;
+    return UBase{Z + e, drop.bits ? drop.bits + (e >> 3) : nullptr, mu + col, sc + col, be + col};
+  }
+  __device__ __forceinline__ TC tconst(int r, int c) const {
+    const uint32_t e = (uint32_t)(r * ld + c);
+    return TC{e * 4u, e >> 3, (uint32_t)(c & 4)};
+  }
+  __device__ __forceinline__ Raw fetch_u(const UBase &u, const TC &t) const {
+    return Raw{vld4u(u.z, t.off), u.bits ? (uint32_t)u.bits[t.koff] : 0xFFu};
+  }
+  __device__ __forceinline__ Consts consts_u(const UBase &u, int c) const { return Consts{vld4(u.mu + c), vld4(u.sc + c), vld4(u.be + c)}; }
+  __device__ __forceinline__ float4 finish_u(const Raw &r, const Consts &k, const UBase &, const TC &t) const {
+    const uint32_t nib = r.keep >> t.nib;
+    float4 a;
+    a.x = (nib & 1u) ? fmaxf(fmaf(r.z.x - k.u.x, k.s.x, k.b.x), 0.f) * drop.inv_keep : 0.f;
+    a.y = (nib & 2u) ? fmaxf(fmaf(r.z.y - k.u.y, k.s.y, k.b.y), 0.f) * drop.inv_keep : 0.f;
+    a.z = (nib & 4u) ? fmaxf(fmaf(r.z.z - k.u.z, k.s.z, k.b.z), 0.f) * drop.inv_keep : 0.f;
+    a.w = (nib & 8u) ? fmaxf(fmaf(r.z.w - k.u.w, k.s.w, k.b.w), 0.f) * drop.inv_keep : 0.f;
+    return a;
+  }
   __device__ __forceinline__ Raw fetch(int m, int c) const { return Raw{vld4(Z + (int64_t)m * ld + c), drop.fetch(m, c)}; }
   __device__ __forceinline__ Consts consts(int c) const { return Consts{vld4(mu + c), vld4(sc + c), vld4(be + c)}; }
   __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int m, int c) const {
@@ -132,11 +187,24 @@ typedef LoadActT<lds_cfp> LoadActL;
 template <class CP>
 struct LoadDzT {
   static constexpr bool kLateConsts = ConstsTrait<CP>::kLate;
+  static constexpr bool kLean = true;
   const float *DY, *Z;
   int ld;
   CP mu, al, bz, de;
   struct Raw { float4 dy, z; };
   struct Consts { float4 u, a, b, d; };
+  struct UBase { const float *dy, *z; CP mu, al, bz, de; };
+  struct TC { uint32_t off; };
+  __device__ __forceinline__ UBase ubase(int row, int col) const {
+    const int64_t e = (int64_t)row * ld + col;
+    return UBase{DY + e, Z + e, mu + col, al + col, bz + col, de + col};
+  }
+  __device__ __forceinline__ TC tconst(int r, int c) const { return TC{(uint32_t)(r * ld + c) * 4u}; }
+  __device__ __forceinline__ Raw fetch_u(const UBase &u, const TC &t) const { return Raw{vld4u(u.dy, t.off), vld4u(u.z, t.off)}; }
+  __device__ __forceinline__ Consts consts_u(const UBase &u, int c) const {
+    return Consts{vld4(u.mu + c), vld4(u.al + c), vld4(u.bz + c), vld4(u.de + c)};
+  }
+  __device__ __forceinline__ float4 finish_u(const Raw &r, const Consts &k, const UBase &, const TC &) const { return finish(r, k, 0, 0); }
   __device__ __forceinline__ Raw fetch(int m, int c) const {
     return Raw{vld4(DY + (int64_t)m * ld + c), vld4(Z + (int64_t)m * ld + c)};
   }
@@ -160,11 +228,25 @@ typedef LoadDzT<lds_cfp> LoadDzL;
 template <class L>
 struct Tee {
   static constexpr bool kLateConsts = L::kLateConsts;
+  static constexpr bool kLean = L::kLean;
   L in;
   float *out;
   int ld;
   typedef typename L::Raw Raw;
   typedef typename L::Consts Consts;
+  struct UBase { typename L::UBase in; float *out; };
+  struct TC { typename L::TC in; uint32_t off; };
+  __device__ __forceinline__ UBase ubase(int row, int col) const {
+    return UBase{in.ubase(row, col), out ? out + (int64_t)row * ld + col : nullptr};
+  }
+  __device__ __forceinline__ TC tconst(int r, int c) const { return TC{in.tconst(r, c), (uint32_t)(r * ld + c) * 4u}; }
+  __device__ __forceinline__ Raw fetch_u(const UBase &u, const TC &t) const { return in.fetch_u(u.in, t.in); }
+  __device__ __forceinline__ Consts consts_u(const UBase &u, int c) const { return in.consts_u(u.in, c); }
+  __device__ __forceinline__ float4 finish_u(const Raw &r, const Consts &k, const UBase &u, const TC &t) const {
+    const float4 v = in.finish_u(r, k, u.in, t.in);
+    if (u.out) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(u.out) + t.off) = v;
+    return v;
+  }
   __device__ __forceinline__ Raw fetch(int m, int c) const { return in.fetch(m, c); }
   __device__ __forceinline__ Consts consts(int c) const { return in.consts(c); }
   __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int m, int c) const {
@@ -173,6 +255,9 @@ struct Tee {
     return v;
   }
 };
+
+template <class L, bool LEAN = L::kLean> struct LeanTypes { struct TC {}; struct UBase {}; };
+template <class L> struct LeanTypes<L, true> { typedef typename L::TC TC; typedef typename L::UBase UBase; };
 
 __device__ __forceinline__ int ptid() { return (int)threadIdx.x - (kThreads - kProd); }
 
@@ -184,36 +269,36 @@ __device__ __forceinline__ int kc_off(int row, int chunk) { return row * BK + ((
 // reduction columns, so ONE set of constants serves them (the transformed matrices of a KC operand are indexed
 // [row = m][red = feature]).  Rows beyond rows_valid re-read the last valid row (finite values that only feed masked
 // outputs); reduction indices >= red_end are fetched from a clamped (valid) address and zeroed at the LDS write.
-template <int ROWS, class L>
+template <int ROWS, class L, int NP = kProd>
 struct KcStage {
-  static constexpr int NV = (ROWS * 8 + kProd - 1) / kProd;
+  static constexpr int NV = (ROWS * 8 + NP - 1) / NP;
   typename L::Raw raw[NV];
   typename L::Consts k;
   int red;       // this thread's first reduction index of the slice (unclamped)
 };
-template <int ROWS, class L>
-__device__ __forceinline__ KcStage<ROWS, L> kc_fetch(const L &ld, int row0, int rows_valid, int red0, int red_end) {
-  KcStage<ROWS, L> st;
+template <int ROWS, class L, int NP = kProd>
+__device__ __forceinline__ KcStage<ROWS, L, NP> kc_fetch(const L &ld, int row0, int rows_valid, int red0, int red_end) {
+  KcStage<ROWS, L, NP> st;
   st.red = red0 + ((ptid() & 7) << 2);
   const int redc = st.red < red_end ? st.red : red_end - 4;
   if constexpr (!L::kLateConsts) st.k = ld.consts(redc);      // global constants travel with the slice's loads
 #pragma unroll
-  for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
-    int row = (ptid() >> 3) + i * (kProd / 8);
+  for (int i = 0; i < KcStage<ROWS, L, NP>::NV; ++i) {
+    int row = (ptid() >> 3) + i * (NP / 8);
     row = row < rows_valid ? row : rows_valid - 1;
     st.raw[i] = ld.fetch(row0 + row, redc);
   }
   return st;
 }
-template <int ROWS, class L>
-__device__ __forceinline__ void kc_finish(float *T, const L &ld, const KcStage<ROWS, L> &st, int row0, int rows_valid, int red_end) {
+template <int ROWS, class L, int NP = kProd>
+__device__ __forceinline__ void kc_finish(float *T, const L &ld, const KcStage<ROWS, L, NP> &st, int row0, int rows_valid, int red_end) {
   const bool live = st.red < red_end;
   const int redc = live ? st.red : red_end - 4;
   typename L::Consts k = st.k;
   if constexpr (L::kLateConsts) k = ld.consts(redc);           // constants in LDS (joined by this workgroup): a ds_read here
 #pragma unroll
-  for (int i = 0; i < KcStage<ROWS, L>::NV; ++i) {
-    const int trow = (ptid() >> 3) + i * (kProd / 8);
+  for (int i = 0; i < KcStage<ROWS, L, NP>::NV; ++i) {
+    const int trow = (ptid() >> 3) + i * (NP / 8);
     if (trow < ROWS) {
       const int row = trow < rows_valid ? trow : rows_valid - 1;
       float4 v = ld.finish(st.raw[i], k, row0 + row, redc);
@@ -292,6 +377,7 @@ __device__ __forceinline__ void oc_finish(float *T, const L &ld, const OcStage<W
 template <int ROWS, class L>
 struct OtMap {
   typename L::Consts k;
+  typename LeanTypes<L>::TC tc[4];   // thread-constant address parts of the block's 4 reduction rows (lean loaders)
   int col;          // first output column (global), clamped
   int ob, rb;       // output block, reduction block; ob < 0: this thread has no block
 };
@@ -299,8 +385,9 @@ template <int ROWS, class L>
 struct OtStage {
   typename L::Raw raw[4];
 };
+// General addressing (loaders without the lean interface: panel_gemm.hip's grouped operand).
 template <int ROWS, class L>
-struct OtOperand {
+struct OtOperandG {
   L ld;
   int out0, out_valid, red_end;
   __device__ __forceinline__ OtMap<ROWS, L> prep() const {
@@ -343,18 +430,135 @@ struct OtOperand {
     vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
   }
 };
+// Lean addressing: ONE code path; the last slice, when it is partial (rem = red_end - red0 < BK, a uniform test), re-aims
+// the rows beyond the end at the last valid row and zeroes their values at the LDS write.
+template <int ROWS, class L>
+struct OtOperand {
+  static_assert(L::kLean, "OtOperand needs a loader with the lean interface (else OtOperandG)");
+  L ld;
+  int out0, out_valid, red_end;
+  __device__ __forceinline__ OtMap<ROWS, L> prep() const {
+    constexpr int OB = ROWS / 4;
+    OtMap<ROWS, L> m;
+    const int b = ptid();
+    const bool has = b < OB * 8;
+    const int bc = has ? b : OB * 8 - 1;
+    m.ob = has ? bc % OB : -1;
+    m.rb = bc / OB;
+    const int o = (bc % OB) << 2;
+    m.col = out0 + (o < out_valid ? o : out_valid - 4);
+    m.k = ld.consts(m.col);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m.tc[j] = ld.tconst(4 * m.rb + j, m.col);      // relative to ubase(red0, 0)
+    return m;
+  }
+  __device__ __forceinline__ OtStage<ROWS, L> fetch(const OtMap<ROWS, L> &m, int red0) const {
+    OtStage<ROWS, L> st;
+    const auto ub = ld.ubase(red0, 0);
+    const int rem = red_end - red0;
+    const typename L::TC last = ld.tconst(rem - 1, m.col);       // the last valid reduction row (selects, see KcOperand)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st.raw[j] = ld.fetch_u(ub, 4 * m.rb + j >= rem ? last : m.tc[j]);
+    return st;
+  }
+  __device__ __forceinline__ void finish(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const {
+    if (m.ob < 0) return;
+    const auto ub = ld.ubase(red0, 0);
+    const int rem = red_end - red0;
+    const typename L::TC last = ld.tconst(rem - 1, m.col);
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool dead = 4 * m.rb + j >= rem;
+      v[j] = ld.finish_u(st.raw[j], m.k, ub, dead ? last : m.tc[j]);
+      if (dead) v[j] = zero4();
+    }
+    const int row = 4 * m.ob;
+    vst4(T + kc_off(row + 0, m.rb), make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    vst4(T + kc_off(row + 1, m.rb), make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+    vst4(T + kc_off(row + 2, m.rb), make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+    vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+  }
+};
 
 // Operand adaptors for the main loop: prep() once per producer thread, fetch(prep, red0) issues the loads of a slice,
 // finish(T, stage, prep, red0) transforms and writes it.
 struct NoPrep {};
-template <int ROWS, class L>
-struct KcOperand {
+// General addressing (loaders without the lean interface).
+template <int ROWS, class L, int NP = kProd>
+struct KcOperandG {
   L ld;
   int row0, rows_valid, red_end;
   __device__ __forceinline__ NoPrep prep() const { return NoPrep{}; }
-  __device__ __forceinline__ KcStage<ROWS, L> fetch(const NoPrep &, int red0) const { return kc_fetch<ROWS>(ld, row0, rows_valid, red0, red_end); }
-  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L> &st, const NoPrep &, int) const {
-    kc_finish<ROWS>(T, ld, st, row0, rows_valid, red_end);
+  __device__ __forceinline__ KcStage<ROWS, L, NP> fetch(const NoPrep &, int red0) const { return kc_fetch<ROWS, L, NP>(ld, row0, rows_valid, red0, red_end); }
+  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L, NP> &st, const NoPrep &, int) const {
+    kc_finish<ROWS, L, NP>(T, ld, st, row0, rows_valid, red_end);
+  }
+};
+// Lean addressing (see LoadPlain): per-thread offsets and LDS positions prepared once; a slice costs the producers no
+// address arithmetic.  The last slice, when partial (rem < BK: uniform), re-aims the chunks beyond the end at the last
+// valid chunk of their row and zeroes their values at the LDS write.
+template <int ROWS, class L, int NP = kProd>
+struct KcPrep {
+  static constexpr int NV = (ROWS * 8 + NP - 1) / NP;
+  typename L::TC tc[NV];
+  int lofs[NV];                         // LDS float offset of the chunk, -1: the chunk does not exist
+  int cc;                               // first column of the thread's chunk inside a slice
+};
+template <int ROWS, class L, int NP = kProd>
+struct KcOperand {
+  static_assert(L::kLean, "KcOperand needs a loader with the lean interface (else KcOperandG)");
+  static constexpr int NV = KcPrep<ROWS, L, NP>::NV;
+  L ld;
+  int row0, rows_valid, red_end;
+  __device__ __forceinline__ int row_of(int i) const {
+    const int trow = (ptid() >> 3) + i * (NP / 8);
+    return trow < rows_valid ? trow : rows_valid - 1;
+  }
+  __device__ __forceinline__ KcPrep<ROWS, L, NP> prep() const {
+    KcPrep<ROWS, L, NP> p;
+    p.cc = (ptid() & 7) << 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int trow = (ptid() >> 3) + i * (NP / 8);
+      p.lofs[i] = trow < ROWS ? kc_off(trow, ptid() & 7) : -1;
+      p.tc[i] = ld.tconst(row_of(i), p.cc);
+    }
+    return p;
+  }
+  // The partial last slice (rem = red_end - red0 < BK) is handled by SELECTS that every slice executes (one per chunk on
+  // the offset, four on the value), not by branches: measured, a uniform branch around them made hipcc join the
+  // register stages at the branch exits with s_waitcnt vmcnt(0) — one slice in flight instead of three, slower than the
+  // selects cost.
+  __device__ __forceinline__ KcStage<ROWS, L, NP> fetch(const KcPrep<ROWS, L, NP> &p, int red0) const {
+    KcStage<ROWS, L, NP> st;
+    const auto ub = ld.ubase(row0, red0);
+    const int rem = red_end - red0;
+    const bool dead = p.cc >= rem;
+    const int cc = dead ? rem - 4 : p.cc;
+    if constexpr (!L::kLateConsts) st.k = ld.consts_u(ub, cc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const typename L::TC re = ld.tconst(row_of(i), rem - 4);
+      st.raw[i] = ld.fetch_u(ub, dead ? re : p.tc[i]);
+    }
+    return st;
+  }
+  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L, NP> &st, const KcPrep<ROWS, L, NP> &p, int red0) const {
+    const auto ub = ld.ubase(row0, red0);
+    const int rem = red_end - red0;
+    const bool dead = p.cc >= rem;
+    typename L::Consts k = st.k;
+    if constexpr (L::kLateConsts) k = ld.consts_u(ub, dead ? rem - 4 : p.cc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if ((ROWS * 8) % NP == 0 || i + 1 < NV || p.lofs[i] >= 0) {
+        const typename L::TC re = ld.tconst(row_of(i), rem - 4);
+        float4 v = ld.finish_u(st.raw[i], k, ub, dead ? re : p.tc[i]);      // (a Tee stores the re-aimed value at its own address)
+        if (dead) v = zero4();
+        vst4(T + p.lofs[i], v);
+      }
+    }
   }
 };
 template <int WIDTH, int S, class L>
@@ -541,6 +745,122 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
     }
   }
   __syncthreads();     // (full fence) every wave has passed 1 + nst ring barriers; the ring is free from here on
+}
+
+
+// ---- main loop with the UNTRANSFORMED operand on LDS-DMA ------------------------------------------------------------
+// The C operand of a forward product is the weight matrix as it lies in memory: nothing to transform, so it need not pass
+// through registers at all.  Here waves 6-7 move it global -> LDS with global_load_lds_dwordx4 (16 B per lane, 1 KiB per
+// wave-instruction, no VGPR destination, no ds_write, no VALU): the KC tile's XOR swizzle goes on the per-lane SOURCE
+// address, the LDS side is lane-linear (cdna_hip_programming.md, rule 21).  Waves 4-5 stage the transformed R operand
+// through registers as before (128 threads: 4 chunks each), waves 0-3 are the consumers.  Roles are split BY WAVE because
+// a wave that mixes LDS-DMA with ordinary loads makes hipcc drain vmcnt(0) at every use of an ordinary load's result;
+// a loader wave issues nothing but DMA and counts it by hand.
+//   R ring: 4 slots of 64 x 32 floats, written in phase i for slice i + 3 (as in main_loop).
+//   C ring: 6 slots of 112 x 32 floats; the DMA of slice s is issued in phase s - 5 and must have landed before the
+//           barrier that ends phase s - 2 (the consumers read the first half of slice i + 1 in the middle of phase i):
+//           three newer slices (21 instructions per loader wave) may still be in flight -> s_waitcnt vmcnt(21).
+// Rows of C beyond cols_valid re-read the last valid row; reduction indices >= red_end read a clamped (valid, finite)
+// address: the R operand is zero there, so their products vanish.
+constexpr int kRSlots = 4, kCSlots = 6;
+constexpr int kRSlotFloats = 64 * BK, kCSlotFloats = BNT * BK;
+constexpr int kDmaLdsFloats = kRSlots * kRSlotFloats + kCSlots * kCSlotFloats;      // 116 KB
+constexpr int kDmaPerSlice = BNT * 8 / kWaveLanes;                                   // 14 wave-instructions per C slice
+static_assert(kDmaPerSlice == 14, "two loader waves take 7 each");
+
+__device__ __forceinline__ void dma_c_slice(const float *W, int ldw, int n0, int cols_valid, int red0, int red_end, float *slot,
+                                            int lw /* 0 or 1: which loader wave */, int lane) {
+  const int cpos = lane & 7;
+#pragma unroll
+  for (int jj = 0; jj < kDmaPerSlice / 2; ++jj) {
+    const int j = 2 * jj + lw;
+    const int row = 8 * j + (lane >> 3);
+    const int chunk = cpos ^ ((row >> 1) & 7);
+    const int rc = row < cols_valid ? row : cols_valid - 1;
+    int red = red0 + 4 * chunk;
+    red = red < red_end ? red : red_end - 4;
+    const float *src = W + (int64_t)(n0 + rc) * ldw + red;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(slot + j * 256), 16, 0, 0);
+  }
+}
+
+template <int NS = NSUB, class OR>
+__device__ __forceinline__ void main_loop_dma(floatx4 (&acc)[NSUB], float *lds, int red_begin, int red_end, const OR &opR,
+                                              const float *W, int ldw, int n0, int cols_valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nst = (red_end - red_begin + BK - 1) / BK;
+  if (nst <= 0) return;
+  auto at = [&](int i) { return red_begin + (i < nst ? i : nst - 1) * BK; };
+  auto rslot = [&](int i) { return lds + (i % kRSlots) * kRSlotFloats; };
+  auto cslot = [&](int i) { return lds + kRSlots * kRSlotFloats + (i % kCSlots) * kCSlotFloats; };
+  if (wave >= 6) {
+    // ------------------------------------------------------------------------------------------ C loaders (DMA only)
+    const int lw = wave - 6;
+    for (int s = 0; s < 5; ++s)
+      if (s < nst) dma_c_slice(W, ldw, n0, cols_valid, at(s), red_end, cslot(s), lw, lane);
+    // slices 0 and 1 landed (up to three newer ones in flight); fewer slices than that: everything
+    if (nst > 4) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nst; ++i) {
+      if (i + 5 < nst) dma_c_slice(W, ldw, n0, cols_valid, at(i + 5), red_end, cslot(i + 5), lw, lane);
+      // before the barrier that ends phase i, slice i + 2 must be in LDS; issued after it: slices i+3, i+4, i+5 (those
+      // that exist)
+      const int newer = min(nst - 1, i + 5) - min(nst - 1, i + 2);
+      if (newer >= 3) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+      else if (newer == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------ R producers
+    const auto pR = opR.prep();
+    auto fetchR = [&](int red0) { return opR.fetch(pR, red0); };
+    auto finishR = [&](float *T, const auto &st, int red0) { opR.finish(T, st, pR, red0); };
+    auto r0 = fetchR(at(0));
+    auto r1 = fetchR(at(1));
+    auto r2 = fetchR(at(2));
+    finishR(rslot(0), r0, at(0));
+    r0 = fetchR(at(3));
+    if (nst > 1) finishR(rslot(1), r1, at(1));
+    r1 = fetchR(at(4));
+    if (nst > 2) finishR(rslot(2), r2, at(2));
+    r2 = fetchR(at(5));
+    producer_barrier();
+    for (int i = 0; i < nst; i += 3) {
+      if (i + 3 < nst) finishR(rslot(i + 3), r0, at(i + 3));
+      r0 = fetchR(at(i + 6));
+      producer_barrier();
+      if (i + 1 >= nst) break;
+      if (i + 4 < nst) finishR(rslot(i + 4), r1, at(i + 4));
+      r1 = fetchR(at(i + 7));
+      producer_barrier();
+      if (i + 2 >= nst) break;
+      if (i + 5 < nst) finishR(rslot(i + 5), r2, at(i + 5));
+      r2 = fetchR(at(i + 8));
+      producer_barrier();
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ consumers
+    Frags<NS> f0, f1;
+    __builtin_amdgcn_s_setprio(3);
+    consumer_barrier();
+    read_frags<true, true, NS>(f0, rslot(0), cslot(0), wave, lane, 0);
+    for (int i = 0; i < nst; ++i) {
+      read_frags<true, true, NS>(f1, rslot(i), cslot(i), wave, lane, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(acc, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < nst) read_frags<true, true, NS>(f0, rslot(i + 1), cslot(i + 1), wave, lane, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(acc, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      consumer_barrier();
+    }
+  }
+  __syncthreads();
 }
 
 // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2, so
