@@ -843,7 +843,8 @@ int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const flo
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(N, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
-  static const bool dma = [] { const char *e = getenv("MI_TAIL_DMA"); return e && e[0] == '1'; }();
+  static const bool dma_env = [] { const char *e = getenv("MI_TAIL_DMA"); return e && e[0] == '1'; }();
+  const bool dma = dma_env && K >= 2 * BK;
 
   if (x_stats) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, true>), grid8(tiles), kThreads, stream, a);
   else if (x_mu && dma) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, false, true>), grid8(tiles), kThreads, stream, a);

@@ -429,6 +429,8 @@ struct OtOperandG {
     vst4(T + kc_off(row + 2, m.rb), make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
     vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
   }
+  __device__ __forceinline__ OtStage<ROWS, L> fetch_any(const OtMap<ROWS, L> &m, int red0) const { return fetch(m, red0); }
+  __device__ __forceinline__ void finish_any(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const { finish(T, st, m, red0); }
 };
 // Lean addressing: ONE code path; the last slice, when it is partial (rem = red_end - red0 < BK, a uniform test), re-aims
 // the rows beyond the end at the last valid row and zeroes their values at the LDS write.
@@ -452,16 +454,40 @@ struct OtOperand {
     for (int j = 0; j < 4; ++j) m.tc[j] = ld.tconst(4 * m.rb + j, m.col);      // relative to ubase(red0, 0)
     return m;
   }
+  __device__ __forceinline__ void store_block(float *T, const OtMap<ROWS, L> &m, const float4 (&v)[4]) const {
+    const int row = 4 * m.ob;
+    vst4(T + kc_off(row + 0, m.rb), make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+    vst4(T + kc_off(row + 1, m.rb), make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+    vst4(T + kc_off(row + 2, m.rb), make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+    vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+  }
+  // full slices (see KcOperand)
   __device__ __forceinline__ OtStage<ROWS, L> fetch(const OtMap<ROWS, L> &m, int red0) const {
     OtStage<ROWS, L> st;
     const auto ub = ld.ubase(red0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st.raw[j] = ld.fetch_u(ub, m.tc[j]);
+    return st;
+  }
+  __device__ __forceinline__ void finish(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const {
+    if (m.ob < 0) return;
+    const auto ub = ld.ubase(red0, 0);
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ld.finish_u(st.raw[j], m.k, ub, m.tc[j]);
+    store_block(T, m, v);
+  }
+  // a slice that may be partial: rows beyond the end re-aimed at the last valid one, their values zeroed
+  __device__ __forceinline__ OtStage<ROWS, L> fetch_any(const OtMap<ROWS, L> &m, int red0) const {
+    OtStage<ROWS, L> st;
+    const auto ub = ld.ubase(red0, 0);
     const int rem = red_end - red0;
-    const typename L::TC last = ld.tconst(rem - 1, m.col);       // the last valid reduction row (selects, see KcOperand)
+    const typename L::TC last = ld.tconst(rem - 1, m.col);
 #pragma unroll
     for (int j = 0; j < 4; ++j) st.raw[j] = ld.fetch_u(ub, 4 * m.rb + j >= rem ? last : m.tc[j]);
     return st;
   }
-  __device__ __forceinline__ void finish(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const {
+  __device__ __forceinline__ void finish_any(float *T, const OtStage<ROWS, L> &st, const OtMap<ROWS, L> &m, int red0) const {
     if (m.ob < 0) return;
     const auto ub = ld.ubase(red0, 0);
     const int rem = red_end - red0;
@@ -473,11 +499,7 @@ struct OtOperand {
       v[j] = ld.finish_u(st.raw[j], m.k, ub, dead ? last : m.tc[j]);
       if (dead) v[j] = zero4();
     }
-    const int row = 4 * m.ob;
-    vst4(T + kc_off(row + 0, m.rb), make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
-    vst4(T + kc_off(row + 1, m.rb), make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
-    vst4(T + kc_off(row + 2, m.rb), make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
-    vst4(T + kc_off(row + 3, m.rb), make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+    store_block(T, m, v);
   }
 };
 
@@ -494,6 +516,8 @@ struct KcOperandG {
   __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L, NP> &st, const NoPrep &, int) const {
     kc_finish<ROWS, L, NP>(T, ld, st, row0, rows_valid, red_end);
   }
+  __device__ __forceinline__ KcStage<ROWS, L, NP> fetch_any(const NoPrep &p, int red0) const { return fetch(p, red0); }
+  __device__ __forceinline__ void finish_any(float *T, const KcStage<ROWS, L, NP> &st, const NoPrep &p, int red0) const { finish(T, st, p, red0); }
 };
 // Lean addressing (see LoadPlain): per-thread offsets and LDS positions prepared once; a slice costs the producers no
 // address arithmetic.  The last slice, when partial (rem < BK: uniform), re-aims the chunks beyond the end at the last
@@ -526,17 +550,34 @@ struct KcOperand {
     }
     return p;
   }
-  // The partial last slice (rem = red_end - red0 < BK) is handled by SELECTS that every slice executes (one per chunk on
-  // the offset, four on the value), not by branches: measured, a uniform branch around them made hipcc join the
-  // register stages at the branch exits with s_waitcnt vmcnt(0) — one slice in flight instead of three, slower than the
-  // selects cost.
+  // fetch / finish: a FULL slice (red0 + BK <= red_end) — no clamps, no selects, no address arithmetic.
+  // fetch_any / finish_any: a slice that may be the partial one (chunks beyond the end re-aimed at the row's last valid
+  // chunk, their values zeroed at the LDS write; selects).  main_loop walks the partial slice FIRST, in its prologue, so
+  // that the steady state only ever sees full slices: with the selects inside the loop the producers' vector
+  // instruction count did not drop at all (SQ_INSTS_VALU, profiles/r03_tail_sq_counters.csv), and a uniform branch
+  // around them made hipcc join the register stages with s_waitcnt vmcnt(0).
   __device__ __forceinline__ KcStage<ROWS, L, NP> fetch(const KcPrep<ROWS, L, NP> &p, int red0) const {
+    KcStage<ROWS, L, NP> st;
+    const auto ub = ld.ubase(row0, red0);
+    if constexpr (!L::kLateConsts) st.k = ld.consts_u(ub, p.cc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) st.raw[i] = ld.fetch_u(ub, p.tc[i]);
+    return st;
+  }
+  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L, NP> &st, const KcPrep<ROWS, L, NP> &p, int red0) const {
+    const auto ub = ld.ubase(row0, red0);
+    typename L::Consts k = st.k;
+    if constexpr (L::kLateConsts) k = ld.consts_u(ub, p.cc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if ((ROWS * 8) % NP == 0 || i + 1 < NV || p.lofs[i] >= 0) vst4(T + p.lofs[i], ld.finish_u(st.raw[i], k, ub, p.tc[i]));
+  }
+  __device__ __forceinline__ KcStage<ROWS, L, NP> fetch_any(const KcPrep<ROWS, L, NP> &p, int red0) const {
     KcStage<ROWS, L, NP> st;
     const auto ub = ld.ubase(row0, red0);
     const int rem = red_end - red0;
     const bool dead = p.cc >= rem;
-    const int cc = dead ? rem - 4 : p.cc;
-    if constexpr (!L::kLateConsts) st.k = ld.consts_u(ub, cc);
+    if constexpr (!L::kLateConsts) st.k = ld.consts_u(ub, dead ? rem - 4 : p.cc);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const typename L::TC re = ld.tconst(row_of(i), rem - 4);
@@ -544,7 +585,7 @@ struct KcOperand {
     }
     return st;
   }
-  __device__ __forceinline__ void finish(float *T, const KcStage<ROWS, L, NP> &st, const KcPrep<ROWS, L, NP> &p, int red0) const {
+  __device__ __forceinline__ void finish_any(float *T, const KcStage<ROWS, L, NP> &st, const KcPrep<ROWS, L, NP> &p, int red0) const {
     const auto ub = ld.ubase(row0, red0);
     const int rem = red_end - red0;
     const bool dead = p.cc >= rem;
@@ -570,6 +611,8 @@ struct OcOperand {
   __device__ __forceinline__ void finish(float *T, const OcStage<WIDTH, L> &st, const OcMap<WIDTH, L> &m, int red0) const {
     oc_finish<WIDTH>(T, ld, st, m, red0, red_end);
   }
+  __device__ __forceinline__ OcStage<WIDTH, L> fetch_any(const OcMap<WIDTH, L> &m, int red0) const { return fetch(m, red0); }
+  __device__ __forceinline__ void finish_any(float *T, const OcStage<WIDTH, L> &st, const OcMap<WIDTH, L> &m, int red0) const { finish(T, st, m, red0); }
 };
 
 // fragments of step half h (16 reduction indices): 4 values per lane = k-steps j = 0..3
@@ -660,8 +703,44 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
   constexpr int rOff = R_KC ? kROffKC : kROffOC, cOff = C_KC ? kCOffKC : kCOffOC;
   const int nst = (red_end - red_begin + BK - 1) / BK;
   if (nst <= 0) return;
-  auto at = [&](int i) { return red_begin + (i < nst ? i : nst - 1) * BK; };
+  // Slice ORDER: a sum does not care, so the partial slice (if the range is not a multiple of BK) is walked FIRST —
+  // index 0, handled by the prologue's *_any calls — and every slice the steady state touches is a full one.  Indices
+  // past the end repeat the last index (never written); with a single, partial slice that is the partial one again,
+  // which only the *_any forms may read: `lone` routes every access through them (tiny reductions only).
+  const bool partial = (red_end - red_begin) % BK != 0;
+  const bool lone = partial && nst == 1;
+  auto at = [&](int i) {
+    const int ii = i < nst ? i : nst - 1;
+    return red_begin + (partial ? (ii == 0 ? nst - 1 : ii - 1) : ii) * BK;
+  };
   auto slot = [&](int i) { return lds + (i % kRing) * kStageFloats; };
+  if (lone) {
+    // a reduction shorter than one slice: one unpipelined step through the *_any forms (the pipeline below would
+    // prefetch "the last slice" again with the full-slice loads)
+    if (wave >= 4) {
+      const auto pR = opR.prep();
+      const auto pC = opC.prep();
+      const auto r0 = opR.fetch_any(pR, red_begin);
+      const auto c0 = opC.fetch_any(pC, red_begin);
+      if constexpr (PRE::kActive) producer_barrier();
+      opR.finish_any(slot(0) + rOff, r0, pR, red_begin);
+      opC.finish_any(slot(0) + cOff, c0, pC, red_begin);
+      producer_barrier();
+    } else {
+      if constexpr (PRE::kActive) {
+        pre();
+        producer_barrier();
+      }
+      consumer_barrier();
+      Frags<NS> f0, f1;
+      read_frags<R_KC, C_KC, NS>(f0, slot(0) + rOff, slot(0) + cOff, wave, lane, 0);
+      read_frags<R_KC, C_KC, NS>(f1, slot(0) + rOff, slot(0) + cOff, wave, lane, 1);
+      mma_half(acc, f0);
+      mma_half(acc, f1);
+    }
+    __syncthreads();
+    return;
+  }
   if (wave >= 4) {
     // ---------------------------------------------------------------------------------------------- producers
     const auto pR = opR.prep();
@@ -671,15 +750,15 @@ __device__ __forceinline__ void main_loop(floatx4 (&acc)[NSUB], float *lds, int 
     auto finishR = [&](float *T, const auto &st, int red0) { opR.finish(T, st, pR, red0); };
     auto finishC = [&](float *T, const auto &st, int red0) { opC.finish(T, st, pC, red0); };
     // slices 0..2 straight into their slots, slices 3..5 left in flight in the three register stages
-    auto r0 = fetchR(at(0));
-    auto c0 = fetchC(at(0));
+    auto r0 = opR.fetch_any(pR, at(0));
+    auto c0 = opC.fetch_any(pC, at(0));
     auto r1 = fetchR(at(1));
     auto c1 = fetchC(at(1));
     auto r2 = fetchR(at(2));
     auto c2 = fetchC(at(2));
     if constexpr (PRE::kActive) producer_barrier();      // the consumers have joined the constants
-    finishR(slot(0) + rOff, r0, at(0));
-    finishC(slot(0) + cOff, c0, at(0));
+    opR.finish_any(slot(0) + rOff, r0, pR, at(0));
+    opC.finish_any(slot(0) + cOff, c0, pC, at(0));
     r0 = fetchR(at(3));
     c0 = fetchC(at(3));
     if (nst > 1) {
@@ -791,7 +870,11 @@ __device__ __forceinline__ void main_loop_dma(floatx4 (&acc)[NSUB], float *lds, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nst = (red_end - red_begin + BK - 1) / BK;
   if (nst <= 0) return;
-  auto at = [&](int i) { return red_begin + (i < nst ? i : nst - 1) * BK; };
+  const bool partial = (red_end - red_begin) % BK != 0;      // the partial slice goes first (see main_loop); callers keep
+  auto at = [&](int i) {                                      // reductions shorter than two slices off this loop
+    const int ii = i < nst ? i : nst - 1;
+    return red_begin + (partial ? (ii == 0 ? nst - 1 : ii - 1) : ii) * BK;
+  };
   auto rslot = [&](int i) { return lds + (i % kRSlots) * kRSlotFloats; };
   auto cslot = [&](int i) { return lds + kRSlots * kRSlotFloats + (i % kCSlots) * kCSlotFloats; };
   if (wave >= 6) {
@@ -819,10 +902,10 @@ __device__ __forceinline__ void main_loop_dma(floatx4 (&acc)[NSUB], float *lds, 
     const auto pR = opR.prep();
     auto fetchR = [&](int red0) { return opR.fetch(pR, red0); };
     auto finishR = [&](float *T, const auto &st, int red0) { opR.finish(T, st, pR, red0); };
-    auto r0 = fetchR(at(0));
+    auto r0 = opR.fetch_any(pR, at(0));
     auto r1 = fetchR(at(1));
     auto r2 = fetchR(at(2));
-    finishR(rslot(0), r0, at(0));
+    opR.finish_any(rslot(0), r0, pR, at(0));
     r0 = fetchR(at(3));
     if (nst > 1) finishR(rslot(1), r1, at(1));
     r1 = fetchR(at(4));
