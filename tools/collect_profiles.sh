@@ -7,13 +7,16 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 R=$GRAFT_REPO_ROOT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# kernel statistics: IN-GRAPH launches only (no eager per-kernel pass, no gather-only graphs, no extra legs), so that a
+# kernel's average is its average inside the replayed step
 for cfg in c2 c3 c5; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -- python3 $R/bench.py --config $cfg --steps 50 --warmup 5 --no-cpu-baseline > $OUT/stats_$cfg.json 2> $OUT/stats_$cfg.err || exit 1
+  extra=""; [ $cfg = c2 ] && extra="--no-eager-leg --no-gather-leg --no-train-step --no-sweep"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -- python3 $R/bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline $extra > $OUT/stats_$cfg.json 2> $OUT/stats_$cfg.err || exit 1
 done
 for cfg in c2 c3 c5; do
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
     tag=$(echo $pmc | tr ' ' '+')
-    timeout -k 10 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc_${cfg}_$tag -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $OUT/pmc_${cfg}_$tag.json 2> $OUT/pmc_${cfg}_$tag.err || echo "pmc $cfg $tag failed"
+    timeout -k 10 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc_${cfg}_$tag -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --windows 0 --no-cpu-baseline --no-graph --no-gather-leg --no-train-step --no-sweep --no-eager-leg > $OUT/pmc_${cfg}_$tag.json 2> $OUT/pmc_${cfg}_$tag.err || echo "pmc $cfg $tag failed"
   done
 done
 python3 $R/tools/summarise_profiles.py $OUT ${2:-r02} $OUT/summary
