@@ -360,8 +360,16 @@ MI_API int mi_gemm_f32(const float *A, const float *B, float *C, int32_t M, int3
 /* Several independent products of ONE operand layout in a single launch — the weight gradients of a CrossNet backward
  * (src/models/layer_dcn.py:27-115 through autograd: dU, dC, dV, dG of every layer are each a few 64x64 tiles with a
  * B-long reduction; one at a time none fills the chip).  Problem j: C_j[batch] (+)= opA(A_j) opB(B_j), batch strides
- * sA/sB/sC, `splitk` K-slices that meet in float atomics (then C_j must be zeroed by the caller, or accumulate != 0).
- * n <= 16; transA/transB as in mi_gemm_f32 and common to all problems.  `probs` is a HOST array read during the call. */
+ * sA/sB/sC, `splitk` K-slices that meet in float atomics (then C_j must be zeroed by the caller, or accumulate != 0);
+ * splitk = 0 leaves the cut to the library (C_j zeroed / accumulate as for any cut).
+ * n <= 16; transA/transB as in mi_gemm_f32 and common to all problems.  `probs` is a HOST array read during the call.
+ * The form transA = 1, transB = 0 (both operands reduction-major: dW = dz^T a, also the MLP tail's weight gradients)
+ * runs — when every problem has K % 32 == 0, M % 4 == N % 4 == 0 and 16-byte aligned operands / strides — on a kernel
+ * that moves both operands global -> LDS by DMA in their memory layout (MI_GEMM_TN_DMA=0 in the environment: the
+ * general kernel).
+ * mi_gemm_f32_multi_plan: the cut that call would make, by host arithmetic only (nothing launched, no GPU needed):
+ * *kind = 1 (the LDS-DMA kernel) or 0 (the general one), splitk[j] = K-slices of problem j (n entries; 0 for an empty
+ * problem), *workgroups = the launch's size. */
 typedef struct mi_gemm_problem {
   const float *A, *B;
   float *C;
@@ -373,6 +381,8 @@ typedef struct mi_gemm_problem {
   int32_t accumulate;
 } mi_gemm_problem;
 MI_API int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream);
+MI_API int mi_gemm_f32_multi_plan(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, int32_t *kind,
+                                  int64_t *workgroups, int32_t *splitk);
 
 /* The same contraction on a second tiling, for the large products of a DCN_MixHead layer (layer_dcn.py:90-115 and their
  * gradients): C[M,N] = epi(A[M,K] . B), A row-major.  A workgroup owns a 64-row panel of A by one of nt equal column ranges
@@ -711,6 +721,25 @@ MI_API int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, cons
                                    const float *mean_offset, float *running_mean, float *running_var, float momentum,
                                    float eps, int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc,
                                    float *be, float *rstd, void *stream);
+/* mi_tail_bn_finalize_fwd with the work of mi_tail_dropout_masks_z riding along in extra workgroups of the same launch
+ * (ride == NULL: the plain entry point).  The layer whose statistics are joined is the FIRST of the step, so every kernel
+ * that reads keep bits comes later.  seed_bump must not point at ride->seed (MI_ERR_INVALID_ARG): a launch cannot both
+ * draw from the seed and advance it; let a later finalize launch bump it.  Host struct, read at call time. */
+typedef struct mi_tail_mask_ride {
+  const int64_t *seed;          /* device */
+  int32_t nlayers;              /* <= 8 */
+  int32_t M;
+  const int64_t *salts;         /* host [nlayers] */
+  const float *ps;              /* host [nlayers] */
+  const int32_t *lds;           /* host [nlayers] */
+  uint8_t *const *bits;         /* host [nlayers] of device pointers (NULL where ps == 0) */
+  float *zero_buf;              /* device, nullable */
+  int64_t zero_floats;
+} mi_tail_mask_ride;
+MI_API int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, const float *gamma, const float *beta,
+                                     const float *mean_offset, float *running_mean, float *running_var, float momentum,
+                                     float eps, int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc,
+                                     float *be, float *rstd, const mi_tail_mask_ride *ride, void *stream);
 MI_API int mi_tail_head_fwd(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                             const uint8_t *keep, const float *w, const float *b, const float *add, float *out,
                             int32_t M, int32_t N, void *stream);

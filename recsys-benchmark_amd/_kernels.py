@@ -799,35 +799,46 @@ def auto_splitk(M, N, K, batch=1):
     return 1
 
 
-def multi_splits(chunk):
-    """K-slices of every problem of ONE multi-problem launch.  Chosen for the launch, not per problem: together the problems
-    should come to ~2.5 workgroups per CU (640) — each slice is a workgroup that adds a whole 64x64 tile with float atomics, so
-    more slices than that only buy atomics (C3: 4 128 -> 696 workgroups, 78 -> 66 us).  A slice keeps >= 4 k-tiles of 32;
-    deterministic mode does not split (the slices meet in atomics); an explicit q["splitk"] is kept."""
-    tiles = sum(-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in chunk)
-    share = 1 if DETERMINISTIC else max(1, round(640 / max(tiles, 1)))
-    return [q.get("splitk", 0) or max(1, min(share, -(-q["K"] // 32) // 4, 65535 // max(q.get("batch", 1), 1))) for q in chunk]
+def _multi_problem_array(chunk):
+    """ctypes array of mi_gemm_problem for one launch.  splitk: the caller's value, else 0 = the library cuts the launch
+    (gemm.hip auto_splitk: the slice count that loads the CUs most evenly, atomics priced in);
+    deterministic mode never splits (slices meet in float atomics)."""
+    arr = (_GemmProblem * len(chunk))()
+    for d, q in zip(arr, chunk):
+        batch = q.get("batch", 1)
+        d.A, d.B, d.C = q["A"].data_ptr(), q["B"].data_ptr(), q["C"].data_ptr()
+        d.M, d.N, d.K = q["M"], q["N"], q["K"]
+        d.lda, d.ldb, d.ldc, d.batch = q["lda"], q["ldb"], q["ldc"], batch
+        d.sA, d.sB, d.sC = q.get("sA", 0), q.get("sB", 0), q.get("sC", 0)
+        d.splitk = q.get("splitk", 0) or (1 if DETERMINISTIC else 0)
+        d.accumulate = int(bool(q.get("accumulate", False)))
+    return arr
+
+
+def gemm_multi_plan(problems, transA=False, transB=False):
+    """(kind, workgroups, splitk[n]) of the launch gemm_multi would make for <= 16 problems (mi_gemm_f32_multi_plan: host
+    arithmetic, no GPU work); kind 1 = the LDS-DMA kernel of the weight-gradient form, 0 = the general kernel."""
+    arr = _multi_problem_array(problems)
+    kind, wgs = _ctypes.c_int32(), _ctypes.c_int64()
+    splitk = (_ctypes.c_int32 * max(1, len(problems)))()
+    _lib.check(_lib.load().mi_gemm_f32_multi_plan(_ctypes.addressof(arr), len(problems), int(transA), int(transB),
+                                                  _ctypes.addressof(kind), _ctypes.addressof(wgs), _ctypes.addressof(splitk)),
+               "mi_gemm_f32_multi_plan")
+    return kind.value, wgs.value, list(splitk[:len(problems)])
 
 
 def gemm_multi(problems, transA=False, transB=False):
     """problems: dicts with A, B, C (torch buffers / views), M, N, K, lda, ldb, ldc and optionally batch, sA, sB, sC, splitk
-    (0 = automatic), accumulate — all the same operand layout, independent of each other: ONE launch per 16 problems
-    (mi_gemm_f32_multi).  C of a split problem must be zero (or accumulate): the caller allocates them zero-filled."""
+    (0 / absent = the library's cut), accumulate — all the same operand layout, independent of each other: ONE launch per 16
+    problems (mi_gemm_f32_multi).  C of a problem must be zero (or accumulate) unless splitk == 1: the caller allocates
+    them zero-filled."""
     if not problems:
         return
     dev = _lib.require_gpu(*[q[k] for q in problems for k in ("A", "B", "C")])
     lib, stream = _lib.load(), _lib.stream_ptr(dev)
     for i in range(0, len(problems), MAX_GEMM_PROBLEMS):
         chunk = problems[i:i + MAX_GEMM_PROBLEMS]
-        arr = (_GemmProblem * len(chunk))()
-        splits = multi_splits(chunk)
-        for d, q, sk in zip(arr, chunk, splits):
-            batch = q.get("batch", 1)
-            d.A, d.B, d.C = q["A"].data_ptr(), q["B"].data_ptr(), q["C"].data_ptr()
-            d.M, d.N, d.K = q["M"], q["N"], q["K"]
-            d.lda, d.ldb, d.ldc, d.batch = q["lda"], q["ldb"], q["ldc"], batch
-            d.sA, d.sB, d.sC = q.get("sA", 0), q.get("sB", 0), q.get("sC", 0)
-            d.splitk, d.accumulate = sk, int(bool(q.get("accumulate", False)))
+        arr = _multi_problem_array(chunk)
         _lib.check(lib.mi_gemm_f32_multi(_ctypes.addressof(arr), len(chunk), int(transA), int(transB), stream),
                    "mi_gemm_f32_multi")
 

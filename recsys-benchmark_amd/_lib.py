@@ -107,6 +107,8 @@ SIGNATURES = {
     "mi_tail_part_elems": [_i32, _i32],
     "mi_tail_bn_finalize_fwd": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
                                 _p, _p],
+    "mi_tail_bn_finalize_fwd_r": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
+                                  _p, _p, _p],
     "mi_tail_head_fwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_tail_head_blocks": [_i32],
     "mi_tail_head_bwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
@@ -117,6 +119,7 @@ SIGNATURES = {
     "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
                            _i32, _i32, _p],
     "mi_gemm_f32_multi": [_p, _i32, _i32, _i32, _p],
+    "mi_gemm_f32_multi_plan": [_p, _i32, _i32, _i32, _p, _p, _p],
     "mi_gemm_f32_panel": [_p, _i32, _p, _i32, _i32, _i32, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p],
     "mi_mix_expert_fwd": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "mi_mix_expert_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],

@@ -12,6 +12,8 @@
 // float4 = k-slots {8c + 4kh + j}, j=0..3, per operand and issues 4 MFMAs: the k order inside a
 // chunk is permuted identically for A and B, which a sum over k does not see.  The next tile's
 // global loads are issued before the current tile's MFMAs (register-staged double buffering).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -475,6 +477,119 @@ __global__ __launch_bounds__(256) void k_gemm_f32_multi(MultiArgs m) {
   gemm_workgroup<TA, BT, 64>(a, rem % q.gx, rem / q.gx, wz, q.gx, q.gy);
 }
 
+// ---- A^T . B with BOTH operands as they lie in memory, moved by LDS-DMA ---------------------------------------------------
+// The weight gradients (dW = dz^T . a: reduction over the batch, both operands [k][row] with the row contiguous) need no
+// transposition at all when the LDS tile keeps the memory layout: lane (i, kh) of a 32x32x2 MFMA wants A[k = kh][m = i],
+// which in a [k][64 rows] tile is 32 consecutive floats of one k-row per half-wave — a conflict-free ds_read_b32.  So the
+// tiles go global -> LDS with global_load_lds_dwordx4 (16 B per lane, 1 KiB = four k-rows per wave-instruction, lane-linear
+// on the LDS side, which IS this layout): no VGPR staging, no ds_write, no VALU in the loop except the pointer bumps.
+// (k_gemm_f32_multi<1,1> pays 16 scalar transposing ds_write_b32 + their address math per thread and k-tile.)
+// Two slots of (A tile, B tile) = 32 KB per workgroup: five workgroups fit a CU, which matters more than a deeper ring —
+// with 4 slots (two workgroups per CU) the same loop took 78 us instead of 58 for the C2 tail's gradients, with or
+// without the DMA: a lone wave per SIMD cannot keep the MFMA pipe fed.  Every wave issues its quarter of a slice (2 + 2
+// instructions) and counts its own DMA by hand (s_waitcnt vmcnt), one barrier per slice.  Waves whose 32x32 block lies
+// outside the matrix skip the MFMAs (M = 400 is 12.5 blocks: the 64-row tiles' second half is empty there).
+// Knock-outs at the C2 tail's shape (4 slices per tile, 588 workgroups): full 58 us; without the epilogue's atomics 58;
+// LDS reads replaced by registers 58; two accumulators 58; DMA + barriers + atomics without MFMAs 24; the MFMAs alone (no
+// DMA, barriers, LDS) 45 — the product is bound by how evenly the MFMA work lands on the 1024 SIMDs, which is the
+// K-slice count's business (auto_splitk below: 5 slices, 49 us).  A 16-wave workgroup on 128 x 128 tiles with one
+// workgroup per CU was built and measured too: 76-95 us (16-wave barriers and a DMA round trip per k-tile on the critical
+// path of sparse edge tiles); removed.
+// Needs: K % 32 == 0, M % 4 == 0, N % 4 == 0, 16-byte aligned operands (else the general kernel).
+constexpr int TN_S = 2, TN_TILE = BK * 64;
+
+__device__ __forceinline__ void tn_dma(const float *src, float *lds_dst) {
+  // (inline asm, not __builtin_amdgcn_global_load_lds: after the builtin hipcc treats every later LDS read as possibly
+  //  out of order with it and waits lgkmcnt(0) in front of each MFMA)
+  const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(off) : "memory");
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_multi(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) float tn_lds[TN_S * 2 * TN_TILE];
+  const int per_xcd = (m.total + 7) >> 3;
+  const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || id >= m.total) return;
+  int j = 0;
+  while (j + 1 < m.n && id >= m.p[j].end) ++j;
+  const SlimProblem &q = m.p[j];
+  const int local = id - (j ? m.p[j - 1].end : 0);
+  const int pertile = q.gx * q.gy;
+  const int wz = local / pertile, rem = local - wz * pertile;
+  const int bx = rem % q.gx, by = rem / q.gx;
+  const int z = wz / q.splitk, slice = wz % q.splitk;
+  const int ktiles = q.K / BK;
+  const int per = (ktiles + q.splitk - 1) / q.splitk;
+  const int first = slice * per;
+  const int nst = min(ktiles, first + per) - first;
+  if (nst <= 0) return;
+
+  const int m0 = by * 64, n0 = bx * BN;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // (block of wave w rotated by the workgroup's id: the empty blocks of edge tiles do not always idle the same SIMDs)
+  const int wb = (w + id) & 3;
+  const int wr = wb >> 1, wc = wb & 1, i = lane & 31, kh = lane >> 5;
+  const bool active = (m0 + wr * 32 < q.M) && (n0 + wc * 32 < q.N);
+
+  // this lane's share of a slice: k-rows 8w + (lane >> 4) and + 4 of both tiles, float4 column lane & 15 (column groups
+  // past the matrix re-read its last group: they only feed outputs that are never stored)
+  const int dr = 8 * w + (lane >> 4), dc = (lane & 15) * 4;
+  const int ca = min(m0 + dc, q.M - 4), cb = min(n0 + dc, q.N - 4);
+  const float *pa = q.A + z * q.sA + (long long)(first * BK + dr) * q.lda + ca;
+  const float *pb = q.B + z * q.sB + (long long)(first * BK + dr) * q.ldb + cb;
+  const long long a4 = 4ll * q.lda, b4 = 4ll * q.ldb, astep = (long long)BK * q.lda, bstep = (long long)BK * q.ldb;
+  auto issue = [&](int s) {
+    float *sa = tn_lds + (s % TN_S) * (2 * TN_TILE) + w * 512;
+    tn_dma(pa, sa);
+    tn_dma(pa + a4, sa + 256);
+    tn_dma(pb, sa + TN_TILE);
+    tn_dma(pb + b4, sa + TN_TILE + 256);
+    pa += astep;
+    pb += bstep;
+  };
+
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  issue(0);
+  const int fa = kh * 64 + wr * 32 + i, fb = TN_TILE + kh * 64 + wc * 32 + i;
+  for (int s = 0; s < nst; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of slice s has landed
+    __builtin_amdgcn_s_barrier();                          // everybody's has; everybody is done with the other slot
+    if (s + 1 < nst) issue(s + 1);
+    if (active) {
+      const float *t = tn_lds + (s % TN_S) * (2 * TN_TILE);
+#pragma unroll
+      for (int c = 0; c < BK / 2; ++c)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t[fa + c * 128], t[fb + c * 128], acc, 0, 0, 0);
+      // order: the fragment reads of MFMA pair p + 1 go out before the MFMAs of pair p (the scheduler's own order is
+      // read, wait, MFMA, MFMA on one register set)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int p = 0; p < BK / 4 - 2; ++p) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  }
+  if (!active) return;
+
+  // ---- epilogue: lane holds column n, rows (reg & 3) + 8 (reg >> 2) + 4 kh of its 32x32 block
+  const int n = n0 + wc * 32 + i;
+  if (n >= q.N) return;
+  float *C = q.C + z * q.sC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mm = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (mm >= q.M) continue;
+    float *c = C + (long long)mm * q.ldc + n;
+    if (q.splitk > 1) atomicAdd(c, acc[r]);
+    else if (q.epi == EPI_ACCUM) *c += acc[r];
+    else *c = acc[r];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -570,33 +685,77 @@ static void plain_args(GemmArgs &a, const float *A, const float *B, float *C, in
   a.xcd_swizzle = 0;
 }
 
-// n <= 16 independent problems C_j = opA(A_j) opB(B_j) (+ C_j when accumulate), all with the same transposes, in ONE launch.
-// split-K slices meet in float atomics: a problem with splitk > 1 needs its C zeroed by the caller (or accumulate).
-int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream) {
+static int cu_count() {
+  static const int n = []() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// K-slices the library picks for the 64 x 64-tile kernels when a problem leaves splitk = 0.  All workgroups of the launch
+// are resident together (a few per CU) and a CU is busy for (workgroups it got) x (k-tiles per slice): the cut minimises
+//   ceil(tiles * s / CUs) * ceil(ktiles / s) * (1 + 0.035 s)
+// — the last factor for the atomics every extra slice adds (a slice adds a whole 64 x 64 tile with float atomics).  A
+// slice keeps >= 4 k-tiles of 32.  Round 2 used round(640 / tiles): for the C2 tail (147 tiles, 128 k-tiles) that is 4
+// slices = 588 workgroups = 2.3 per CU, i.e. 3 on most CUs (cost 96); 5 slices put 2.9 on every CU (cost 78).
+static int auto_splitk(long long launch_tiles, int K, int batch) {
+  const int ktiles = (K + BK - 1) / BK, ncu = cu_count();
+  long long top = ktiles / 4;
+  if (top > 16) top = 16;
+  if (top > 65535 / (batch > 0 ? batch : 1)) top = 65535 / (batch > 0 ? batch : 1);
+  int best = 1;
+  double best_cost = 0;
+  for (int sk = 1; sk <= (top < 1 ? 1 : top); ++sk) {
+    const double cost = (double)((launch_tiles * sk + ncu - 1) / ncu) * ((ktiles + sk - 1) / sk) * (1.0 + 0.035 * sk);
+    if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
+  }
+  return best;
+}
+
+static bool tn_enabled() {      // MI_GEMM_TN_DMA=0: the reduction-major form stays on the general kernel
+  static const bool v = []() { const char *e = getenv("MI_GEMM_TN_DMA"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
+// Validates and cuts a launch: fills m (splitk chosen where a problem leaves it 0) and says whether the LDS-DMA kernel takes it.
+static int plan_multi(const mi_gemm_problem *probs, int n, int transA, int transB, MultiArgs &m, bool *tn) {
+  m.n = 0;
+  m.total = 0;
+  *tn = false;
   if (n < 0 || n > kMaxProblems) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
   if (!probs) return MI_ERR_INVALID_ARG;
-  MultiArgs m;
-  m.n = 0;
-  long long wgs = 0;
+  long long launch_tiles = 0;
   for (int j = 0; j < n; ++j) {
     const mi_gemm_problem &q = probs[j];
-    if (q.M < 0 || q.N < 0 || q.K < 0 || q.batch < 0 || q.splitk < 1) return MI_ERR_INVALID_ARG;
+    if (q.M < 0 || q.N < 0 || q.K < 0 || q.batch < 0 || q.splitk < 0) return MI_ERR_INVALID_ARG;
     if (q.M == 0 || q.N == 0 || q.batch == 0) continue;
     if (!q.A || !q.B || !q.C) return MI_ERR_INVALID_ARG;
+    launch_tiles += (long long)((q.N + BN - 1) / BN) * ((q.M + 63) / 64) * q.batch;
+  }
+  long long wgs = 0;
+  bool fits = tn_enabled() && transA && !transB;
+  for (int j = 0; j < n; ++j) {
+    const mi_gemm_problem &q = probs[j];
+    if (q.M == 0 || q.N == 0 || q.batch == 0) continue;
     SlimProblem &a = m.p[m.n];
     a.A = q.A; a.B = q.B; a.C = q.C;
     a.M = q.M; a.N = q.N; a.K = q.K;
     a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
     a.sA = q.sA; a.sB = q.sB; a.sC = q.sC;
-    a.splitk = q.splitk;
+    a.splitk = q.splitk > 0 ? q.splitk : auto_splitk(launch_tiles, q.K, q.batch);
+    if ((long long)q.batch * a.splitk > 65535) return MI_ERR_UNSUPPORTED;
     a.epi = q.accumulate ? EPI_ACCUM : EPI_NONE;
     a.alignedA = aligned16(q.A) && (q.lda % 4 == 0) && (q.sA % 4 == 0);
     a.alignedB = aligned16(q.B) && (q.ldb % 4 == 0) && (q.sB % 4 == 0);
     a.gx = (q.N + BN - 1) / BN;
     a.gy = (q.M + 63) / 64;
     a.pad_ = 0;
-    wgs += (long long)a.gx * a.gy * q.batch * q.splitk;
+    fits = fits && a.alignedA && a.alignedB && a.K >= BK && a.K % BK == 0 && a.M >= 4 && a.M % 4 == 0 && a.N >= 4 && a.N % 4 == 0;
+    wgs += (long long)a.gx * a.gy * q.batch * a.splitk;
     if (wgs > 0x7fffffffLL) return MI_ERR_UNSUPPORTED;
     a.end = (int)wgs;
     ++m.n;
@@ -604,9 +763,45 @@ int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, i
   if (m.n == 0) return MI_OK;
   for (int j = m.n; j < kMaxProblems; ++j) m.p[j] = m.p[m.n - 1];
   m.total = (int)wgs;
+  *tn = fits;
+  return MI_OK;
+}
+
+// How mi_gemm_f32_multi would cut this launch (host arithmetic only, nothing is launched): *kind = 1 the LDS-DMA kernel of
+// the reduction-major form, 0 the general kernel; splitk[j] = K-slices of problem j (0 for an empty one).
+int mi_gemm_f32_multi_plan(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, int32_t *kind,
+                           int64_t *workgroups, int32_t *splitk) {
+  if (!kind || !workgroups || (n > 0 && !splitk)) return MI_ERR_INVALID_ARG;
+  MultiArgs m;
+  bool tn;
+  const int rc = plan_multi(probs, n, transA, transB, m, &tn);
+  if (rc != MI_OK) return rc;
+  *kind = tn ? 1 : 0;
+  *workgroups = m.total;
+  for (int j = 0, k = 0; j < n; ++j) {
+    const bool empty = probs[j].M == 0 || probs[j].N == 0 || probs[j].batch == 0;
+    splitk[j] = empty ? 0 : m.p[k++].splitk;
+  }
+  return MI_OK;
+}
+
+// n <= 16 independent problems C_j = opA(A_j) opB(B_j) (+ C_j when accumulate), all with the same transposes, in ONE launch.
+// split-K slices meet in float atomics: a problem with splitk != 1 needs its C zeroed by the caller (or accumulate);
+// splitk = 0 leaves the cut to the library.
+int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream) {
+  MultiArgs m;
+  bool tn;
+  const int rc = plan_multi(probs, n, transA, transB, m, &tn);
+  if (rc != MI_OK || m.n == 0) return rc;
   hipEvent_t ea, eb;
+  const dim3 grid((unsigned)((m.total + 7) / 8 * 8));
+  if (tn) {      // A^T B, both operands reduction-major, every problem of the launch fits: the LDS-DMA kernel
+    const bool prof = mi::prof_acquire("gemm_tn_multi", &ea, &eb);
+    if (prof) hipExtLaunchKernelGGL(k_gemm_tn_multi, grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, m);
+    else hipLaunchKernelGGL(k_gemm_tn_multi, grid, dim3(256), 0, (hipStream_t)stream, m);
+    return launch_status();
+  }
   const bool prof = mi::prof_acquire("gemm_f32_multi", &ea, &eb);
-  const dim3 grid((unsigned)((wgs + 7) / 8 * 8));
 #define GO(TA, BT)                                                                                            \
   do {                                                                                                        \
     if (prof) hipExtLaunchKernelGGL((k_gemm_f32_multi<TA, BT>), grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, m); \

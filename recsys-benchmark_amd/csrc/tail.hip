@@ -43,14 +43,16 @@ struct MaskJob {
   uint32_t thr[8];
   int n;
 };
-__global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4) {
+// workgroup `blk` of `nblk` that share the job
+__device__ __forceinline__ void mask_blocks(const MaskJob &j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4,
+                                            int blk, int nblk) {
   // rides along: the zero fill of the backward pass's accumulation buffer (split-K weight gradients), one launch less
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nzero4; i += (int64_t)gridDim.x * kBlock)
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < nzero4; i += (int64_t)nblk * kBlock)
     zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < j.n; ++l) {
     const uint64_t sd = layer_seed(seed, j.salt[l]);
     const uint32_t thr = j.thr[l];
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < j.nbytes[l]; b += (int64_t)gridDim.x * kBlock) {
+    for (int64_t b = (int64_t)blk * kBlock + threadIdx.x; b < j.nbytes[l]; b += (int64_t)nblk * kBlock) {
       uint32_t byte = 0;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64
       j.bits[l][b] = (uint8_t)byte;
     }
   }
+}
+__global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4) {
+  mask_blocks(j, seed, zero4, nzero4, blockIdx.x, gridDim.x);
 }
 
 // The consumers' accumulators as a [64][kTilePitch] tile in LDS: lane (r, g) of wave w holds rows 16 w + r, columns
@@ -364,13 +369,32 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
 // step.  mean_offset: the Linear's bias, which the contraction left out because it cancels in the normalisation — it
 // only shifts the running mean.
 constexpr int kFinCols = 16, kFinGroups = kBlock / kFinCols;      // a workgroup: 16 columns x 16 tile groups
+// RIDE: the launch carries extra workgroups (those past the ceil(N / 16) that join statistics) which write the step's
+// dropout keep bits and zero-fill the backward pass's accumulation buffer — the work of k_tail_dropmask without a launch
+// of its own (a kernel boundary inside a step costs ~2.5 us, the mask work itself under 1 us spread over the chip; this
+// kernel is the first of the step whose successors need the bits).  The seed the bits are drawn from must not be bumped
+// by this launch (seed_bump rides with a later one).
+struct MaskRide {
+  MaskJob j;
+  const int64_t *seed;
+  float4 *zero4;
+  int64_t nzero4;
+};
+template <bool RIDE>
 __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restrict__ part, int M, int N,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ mean_offset, float *running_mean,
                                                             float *running_var, float momentum, float eps,
                                                             int64_t *nbt, int64_t *seed_bump, float *__restrict__ mu,
                                                             float *__restrict__ sc, float *__restrict__ be,
-                                                            float *__restrict__ rstd_out) {
+                                                            float *__restrict__ rstd_out, MaskRide ride) {
+  if constexpr (RIDE) {
+    const int nfin = (N + kFinCols - 1) / kFinCols;
+    if ((int)blockIdx.x >= nfin) {
+      mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, blockIdx.x - nfin, gridDim.x - nfin);
+      return;
+    }
+  }
   // Latency is all this kernel is: 16 columns x 16 tile groups per workgroup (25 workgroups at N = 400), so that at
   // B = 4096 (64 tiles) a thread has 4 tiles and ONE round trip of loads (round 2: 64 columns x 4 groups, 16 tiles per
   // thread in two trips of 8).  A group joins its run of tiles in one pass around its first tile's mean (see
@@ -860,14 +884,15 @@ int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float
   return mi_tail_fwd_gemm_m(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, nullptr, stream);
 }
 
-int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
-                            uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, void *stream) {
+// builds the device job; *grid = workgroups that suit it (0: nothing to do)
+static int mask_job(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
+                    uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, MaskJob &j, int64_t *grid_out) {
+  *grid_out = 0;
+  j.n = 0;
   if (nlayers < 0 || nlayers > 8 || M < 0 || zero_floats < 0 || (zero_floats & 3)) return MI_ERR_INVALID_ARG;
   if (zero_floats && (!zero_buf || !aligned16(zero_buf))) return MI_ERR_INVALID_ARG;
   if ((nlayers == 0 || M == 0) && zero_floats == 0) return MI_OK;
   if (nlayers && M && (!seed || !salts || !ps || !lds || !bits)) return MI_ERR_INVALID_ARG;
-  MaskJob j;
-  j.n = 0;
   int64_t most = zero_floats / 4;
   for (int l = 0; l < nlayers && M > 0; ++l) {
     if (ps[l] <= 0.f) continue;
@@ -883,6 +908,16 @@ int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t 
   int64_t grid = (most + kBlock - 1) / kBlock;
   if (grid > kMaxGrid) grid = kMaxGrid;
   if (grid < 1) grid = 1;
+  *grid_out = grid;
+  return MI_OK;
+}
+
+int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
+                            uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, void *stream) {
+  MaskJob j;
+  int64_t grid;
+  const int rc = mask_job(seed, nlayers, salts, ps, lds, bits, M, zero_buf, zero_floats, j, &grid);
+  if (rc != MI_OK || grid == 0) return rc;
   MI_LAUNCH("tail_dropout_masks", k_tail_dropmask, (int)grid, kBlock, stream, j, seed, reinterpret_cast<float4 *>(zero_buf),
             zero_floats / 4);
   return launch_status();
@@ -899,9 +934,35 @@ int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, const float
                             const float *mean_offset, float *running_mean, float *running_var, float momentum, float eps,
                             int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc, float *be, float *rstd,
                             void *stream) {
+  return mi_tail_bn_finalize_fwd_r(part, M, N, gamma, beta, mean_offset, running_mean, running_var, momentum, eps,
+                                   num_batches_tracked, seed_bump, mu, sc, be, rstd, nullptr, stream);
+}
+
+int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, const float *gamma, const float *beta,
+                              const float *mean_offset, float *running_mean, float *running_var, float momentum, float eps,
+                              int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc, float *be, float *rstd,
+                              const mi_tail_mask_ride *ride, void *stream) {
   if (M <= 0 || N <= 0 || !part || !mu || !sc || !be || !rstd) return MI_ERR_INVALID_ARG;
-  MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd, (N + kFinCols - 1) / kFinCols, kBlock, stream, part, M, N, gamma, beta,
-            mean_offset, running_mean, running_var, momentum, eps, num_batches_tracked, seed_bump, mu, sc, be, rstd);
+  const int nfin = (N + kFinCols - 1) / kFinCols;
+  MaskRide r;
+  r.j.n = 0; r.seed = nullptr; r.zero4 = nullptr; r.nzero4 = 0;
+  int64_t extra = 0;
+  if (ride) {
+    if (seed_bump && seed_bump == ride->seed) return MI_ERR_INVALID_ARG;      // the bits are drawn from it in this launch
+    const int rc = mask_job(ride->seed, ride->nlayers, ride->salts, ride->ps, ride->lds, ride->bits, ride->M, ride->zero_buf,
+                            ride->zero_floats, r.j, &extra);
+    if (rc != MI_OK) return rc;
+    r.seed = ride->seed;
+    r.zero4 = reinterpret_cast<float4 *>(ride->zero_buf);
+    r.nzero4 = ride->zero_floats / 4;
+  }
+  if (extra > 0) {
+    MI_LAUNCH("tail_bn_finalize_fwd_ride", k_bn_finalize_fwd<true>, nfin + (int)extra, kBlock, stream, part, M, N, gamma, beta,
+              mean_offset, running_mean, running_var, momentum, eps, num_batches_tracked, seed_bump, mu, sc, be, rstd, r);
+  } else {
+    MI_LAUNCH("tail_bn_finalize_fwd", k_bn_finalize_fwd<false>, nfin, kBlock, stream, part, M, N, gamma, beta,
+              mean_offset, running_mean, running_var, momentum, eps, num_batches_tracked, seed_bump, mu, sc, be, rstd, r);
+  }
   return launch_status();
 }
 

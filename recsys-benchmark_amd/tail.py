@@ -38,6 +38,9 @@ SALT = 7919          # per-layer salt of the dropout hash: SALT * (layer index +
 # same time cut to one round trip of loads: 5.3 -> 4.4 us each).  An all-gather among 256 CUs costs what a kernel
 # boundary costs on this machine; the launches stay the default.  MI_TAIL_MERGE_JOINS=1 selects the joined form.
 MERGE_JOINS = os.environ.get("MI_TAIL_MERGE_JOINS", "0") == "1"
+# The step's dropout keep bits + the zero fill of the backward pass's accumulation buffer as extra workgroups of the first
+# layer's finalize launch instead of a launch of their own (MI_TAIL_RIDE_MASKS=0: the separate launch).
+RIDE_MASKS = os.environ.get("MI_TAIL_RIDE_MASKS", "1") == "1"
 
 
 class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys.h)
@@ -49,6 +52,12 @@ class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys
 class _BnBwd(ctypes.Structure):          # mi_tail_bn_bwd
     _fields_ = [(n, ctypes.c_void_p) for n in ("part", "gamma", "rstd", "dgamma", "dbeta", "al", "bz", "de", "wpart", "dw", "db")] + \
                [("nblk", ctypes.c_int32), ("nwblk", ctypes.c_int32)]
+
+
+class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
+    _fields_ = [("seed", ctypes.c_void_p), ("nlayers", ctypes.c_int32), ("M", ctypes.c_int32), ("salts", ctypes.c_void_p),
+                ("ps", ctypes.c_void_p), ("lds", ctypes.c_void_p), ("bits", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p),
+                ("zero_floats", ctypes.c_int64)]
 
 
 def _bn_fwd_struct(part, L, c, seed_bump) -> "_BnFwd":
@@ -97,21 +106,28 @@ def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[Lis
     return plan
 
 
-def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Optional[torch.Tensor] = None, ride: bool = False):
     """Keep bits of every layer with dropout, one launch; `zero_buf` (optional, fp32, a multiple of 4 elements) is
-    zero-filled by the same launch.  Without any dropout layer nothing is launched and zero_buf is NOT touched."""
+    zero-filled by the same launch.  Without any dropout layer nothing is launched and zero_buf is NOT touched.
+    ride=True: nothing is launched here; returns (bits, job) with job the mi_tail_mask_ride (and the host arrays it points
+    at) for the first layer's mi_tail_bn_finalize_fwd_r, or None when there is nothing to do."""
     lib = _lib.load()
     n = len(plan)
     bits = [torch.empty(M * L.lin.out_features // 8, dtype=torch.uint8, device=dev) if L.p > 0 else None for L in plan]
     if not any(b is not None for b in bits):
-        return bits
+        return (bits, None) if ride else bits
     salts = (ctypes.c_int64 * n)(*[SALT * (i + 1) for i in range(n)])
     ps = (ctypes.c_float * n)(*[L.p for L in plan])
     lds = (ctypes.c_int32 * n)(*[L.lin.out_features for L in plan])
     ptrs = (ctypes.c_void_p * n)(*[0 if b is None else b.data_ptr() for b in bits])
+    nzero = zero_buf.numel() if zero_buf is not None else 0
+    if ride:
+        job = _MaskRide(seed.data_ptr(), n, M, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
+                        ctypes.addressof(ptrs), _lib.ptr(zero_buf), nzero)
+        return bits, (job, salts, ps, lds, ptrs)
     _lib.check(lib.mi_tail_dropout_masks_z(seed.data_ptr(), n, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
-                                           ctypes.addressof(ptrs), M, _lib.ptr(zero_buf), zero_buf.numel() if zero_buf is not None else 0,
-                                           _lib.stream_ptr(dev)), "mi_tail_dropout_masks_z")
+                                           ctypes.addressof(ptrs), M, _lib.ptr(zero_buf), nzero, _lib.stream_ptr(dev)),
+               "mi_tail_dropout_masks_z")
     return bits
 
 
@@ -139,13 +155,17 @@ class FusedTailFn(torch.autograd.Function):
         zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
         zsize = (zsize + 3) // 4 * 4
         zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if any(L.p > 0 for L in plan) else None
-        bits = _masks(seed, plan, M, dev, zeros)
+        # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that
+        # launch exists and a LATER finalize launch can advance the seed
+        merge = MERGE_JOINS
+        ride = RIDE_MASKS and not merge and k >= 2
+        bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
         ctx.zeros = zeros
         keep_inputs = not _kernels.DETERMINISTIC
         Zs, consts, acts = [], [], []
         prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
-        merge = MERGE_JOINS
         any_bits = any(b is not None for b in bits)
+        bump_at = 1 if job is not None else 0
         pending = None            # (part, layer, constants) of the layer whose statistics the next kernel joins
         for i, L in enumerate(plan):
             N, K = L.lin.out_features, L.lin.in_features
@@ -168,11 +188,12 @@ class FusedTailFn(torch.autograd.Function):
                 pending = (part, L, c)
             else:
                 bn = L.bn
-                _lib.check(lib.mi_tail_bn_finalize_fwd(
+                _lib.check(lib.mi_tail_bn_finalize_fwd_r(
                     part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                    bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (i == 0 and any_bits) else None,
-                    c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), s), "mi_tail_bn_finalize_fwd")
+                    bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (i == bump_at and any_bits) else None,
+                    c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                    ctypes.byref(job[0]) if (i == 0 and job is not None) else None, s), "mi_tail_bn_finalize_fwd_r")
             Zs.append(Z)
             consts.append(c)
             prev, prev_c, prev_p, prev_bits = Z, c, L.p, bits[i]

@@ -108,7 +108,8 @@ def test_header_compiles_as_plain_c_and_struct_layouts_match_the_bindings(tmp_pa
         pytest.skip("no gcc in this environment")
     from recsys_benchmark_amd import tail as _tailmod
 
-    for cname, ct in (("mi_tail_bn_fwd", _tailmod._BnFwd), ("mi_tail_bn_bwd", _tailmod._BnBwd)):
+    for cname, ct in (("mi_tail_bn_fwd", _tailmod._BnFwd), ("mi_tail_bn_bwd", _tailmod._BnBwd),
+                      ("mi_tail_mask_ride", _tailmod._MaskRide)):
         src2 = tmp_path / f"{cname}.c"
         lines2 = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "mi355x_recsys.h")}"',
                   'int main(void) {', f'  printf("%zu\\n", sizeof({cname}));']

@@ -1,5 +1,7 @@
 """GPU: the fp32 MFMA GEMM (mi_gemm_f32) against torch fp32 matmul on CPU (exact-fp32 MFMA:
 only the summation order differs, rtol 1e-5 / atol scaled with K)."""
+import os
+
 import pytest
 import torch
 
@@ -224,3 +226,40 @@ def test_multi_problem_launch_reduction_major_form():
     _kernels.gemm_multi(probs, transA=True)
     for q, ref in zip(probs, refs):
         assert torch.equal(q["C"].cpu(), ref), (q["M"], q["N"], q["K"])
+
+
+def test_multi_problem_launch_reduction_major_lds_dma_kernel():
+    """A launch whose problems ALL fit the LDS-DMA kernels (k_gemm_tn_multi: K % 32 == 0, M % 4 == N % 4 == 0, aligned) must
+    run there (checked through the launch's name in the dispatch-event ring) and be exact on integer-valued data: the C2
+    tail's shapes (400 x 416: the 64-row tiles' last 32-row block is empty, the one before half full), problems of 1, 2, 3
+    k-tiles, a 4 x 4 corner, batched column slices with strides, accumulate, explicit K-slices (also more slices than k-tiles: empty slices) and the library's cut."""
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    gen = torch.Generator().manual_seed(1234)
+    shapes = [(400, 416, 4096), (400, 400, 4096), (4, 352, 4096), (64, 64, 32), (100, 68, 64), (36, 8, 96), (352, 64, 4096),
+              (8, 4, 160), (4, 4, 32), (132, 260, 2048)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, B = _mk((K, M), gen), _mk((K, N), gen)
+        acc = i % 3 == 2
+        C = _mk((M, N), gen).to(DEV) if acc else torch.zeros(M, N, device=DEV)
+        ref = A.t() @ B + (C.cpu() if acc else 0)
+        probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, accumulate=acc,
+                          splitk=(0, 1, 3, 7)[i % 4]))
+        refs.append(ref)
+    A, B = _mk((512, 3 * 64), gen), _mk((512, 3 * 48), gen)
+    C = torch.zeros(3, 64, 48, device=DEV)
+    probs.append(dict(A=A.to(DEV), B=B.to(DEV), C=C, M=64, N=48, K=512, lda=192, ldb=144, ldc=48, batch=3, sA=64, sB=48, sC=64 * 48))
+    refs.append(torch.stack([A[:, 64 * e:64 * e + 64].t() @ B[:, 48 * e:48 * e + 48] for e in range(3)]))
+    with KernelTimer(64) as kt:
+        _kernels.gemm_multi(probs, transA=True)
+    names = [k for k, _ in kt.records]
+    assert names == ["gemm_f32_multi" if os.environ.get("MI_GEMM_TN_DMA") == "0" else "gemm_tn_multi"], names
+    for q, ref in zip(probs, refs):
+        assert torch.equal(q["C"].cpu(), ref), (q["M"], q["N"], q["K"])
+    # random fp32 at the tail's shape against float64: same bound as any fp32 product
+    A, B = torch.randn(4096, 400, generator=gen), torch.randn(4096, 416, generator=gen)
+    C = torch.zeros(400, 416, device=DEV)
+    _kernels.gemm_multi([dict(A=A.to(DEV), B=B.to(DEV), C=C, M=400, N=416, K=4096, lda=400, ldb=416, ldc=416)], transA=True)
+    ref = A.double().t() @ B.double()
+    assert_close(C, ref.float(), 1e-5, 1e-3)

@@ -347,24 +347,34 @@ def test_tt_approx_uniform_cores_are_the_references(name):
         TTRecTorch(100, 8, [4], tt_p_shapes=[10, 10], tt_q_shapes=[2, 4], weight_dist="approx-uniform")
 
 
-def test_multi_problem_launch_splits_for_the_whole_launch(monkeypatch):
-    """Host logic of mi_gemm_f32_multi's K-slices (recsys-benchmark_amd/_kernels.py: multi_splits): sized for the launch, a
-    slice keeps >= 4 k-tiles, explicit values are kept, deterministic mode does not split."""
+def test_multi_problem_launch_is_cut_for_the_whole_launch(monkeypatch):
+    """Host logic of mi_gemm_f32_multi's K-slices (csrc/gemm.hip auto_splitk through mi_gemm_f32_multi_plan: arithmetic
+    only, runs without a GPU): one slice count for the launch, the one that loads 256 CUs most evenly with the atomics of
+    every extra slice priced in — the C2 tail's three gradients (147 tiles of 64 x 64, 128 k-tiles) get 5 slices = 735
+    workgroups = 2.9 per CU (round 2's round(640 / tiles) = 4 put 3 on most CUs and 2 on the rest); a slice keeps >= 4
+    k-tiles; explicit values are kept; deterministic mode does not split; the weight-gradient form goes to the LDS-DMA
+    kernel exactly when every problem of the launch fits it."""
     from recsys_benchmark_amd import _kernels
 
-    M, d, E, r = 4096, 352, 4, 64
-    layer = [dict(M=E * r, N=d, K=M), dict(M=r, N=r, K=M, batch=E), dict(M=d, N=r, K=M, batch=E), dict(M=E, N=d, K=M)]
-    c3 = layer * 3                                          # the 12 weight gradients of a DCN-Mix backward
-    sp = _kernels.multi_splits(c3)
-    tiles = [-(-q["M"] // 64) * -(-q["N"] // 64) * q.get("batch", 1) for q in c3]
-    assert len(set(sp)) == 1 and sp[0] == 4                 # 174 tiles -> round(640 / 174)
-    assert 500 <= sum(t * k for t, k in zip(tiles, sp)) <= 800
-    tail = [dict(M=400, N=416, K=M), dict(M=400, N=400, K=M), dict(M=400, N=400, K=M)]
-    assert _kernels.multi_splits(tail) == [4, 4, 4]         # 147 tiles
-    assert _kernels.multi_splits([dict(M=64, N=64, K=96)]) == [1]           # 3 k-tiles: never below 4 per slice
-    assert _kernels.multi_splits([dict(M=64, N=64, K=M, splitk=7)]) == [7]
+    def q(M, N, K, **kw):
+        return dict(A=torch.zeros(4), B=torch.zeros(4), C=torch.zeros(4), M=M, N=N, K=K, lda=M, ldb=N, ldc=N, **kw)
+
+    B, d, E, r = 4096, 352, 4, 64
+    tail = [q(400, 416, B), q(400, 400, B), q(400, 400, B)]
+    assert _kernels.gemm_multi_plan(tail, transA=True) == (1, 735, [5, 5, 5])
+    assert _kernels.gemm_multi_plan(tail, transA=False) == (0, 735, [5, 5, 5])
+    layer = [q(E * r, d, B), q(r, r, B, batch=E, sA=r, sB=r, sC=r * r), q(d, r, B, batch=E, sB=r, sC=d * r), q(E, d, B)]
+    kind, wgs, sk = _kernels.gemm_multi_plan(layer * 3, transA=True)          # the 12 weight gradients of a DCN-Mix backward
+    assert kind == 1 and len(set(sk)) == 1 and 500 <= wgs <= 800, (kind, wgs, sk)            # 174 tiles
+    assert _kernels.gemm_multi_plan([q(64, 64, 96)], transA=True) == (1, 1, [1])              # 3 k-tiles: never below 4 per slice
+    assert _kernels.gemm_multi_plan([q(64, 64, B, splitk=7)], transA=True) == (1, 7, [7])
+    assert _kernels.gemm_multi_plan([q(64, 64, B), q(0, 64, B)], transA=True)[2][1] == 0     # an empty problem
+    # a K tail or a ragged width in ANY problem keeps the whole launch on the general kernel
+    assert _kernels.gemm_multi_plan([q(100, 70, 45)], transA=True)[0] == 0
+    assert _kernels.gemm_multi_plan(tail + [q(102, 64, B)], transA=True)[0] == 0
     monkeypatch.setattr(_kernels, "DETERMINISTIC", True)
-    assert _kernels.multi_splits(c3) == [1] * 12
+    assert _kernels.gemm_multi_plan(layer * 3, transA=True)[2] == [1] * 12
+    assert _kernels.gemm_multi_plan(tail, transA=False)[2] == [1] * 3
 
 
 def test_deterministic_switch_restores_the_fused_tail_setting_and_refuses_crossnet_training():
