@@ -161,6 +161,7 @@ MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const floa
                               int64_t n1, int64_t n2, int64_t mod1, int64_t div2,
                               int32_t op, int32_t xform, void *stream);
 
+
 /* ---- §8f rank 4 (first flavour): single-table gather with a per-element transform -------------
  * PEP (src/models/embeddings/pep_embedding.py:82-92): out = sign(w) relu(|w| - sigmoid(s)), w = W[idx],
  *   s = S[row*srs + d*scs] — strides (0,0) global, (0,1) dimension, (1,0) feature, (D,1) feature_dim.
@@ -250,6 +251,17 @@ MI_API int mi_spmm_csr(const int32_t *crow, const int32_t *col, const float *val
                        float *acc_out, float scale, int32_t n_rows, int32_t D,
                        const int32_t *short_rows, int32_t n_short,
                        const int32_t *long_rows, int32_t n_long, void *stream);
+/* The same product with a row mask of X: bit (r & 31) of xmask[r >> 5] == 0 promises that row r of X = [Xa; Xb] is all
+ * zeros, and the planned kernel does not fetch it (NULL: mi_spmm_csr).  mi_row_mask builds such a mask from X itself
+ * ((n_rows + 31) / 32 words; D / 4 a power of two <= 64).  Serves the FIRST layer of a backward propagation
+ * (src/models/lightgcn.py:82-88 through autograd): the incoming gradient is non-zero only on the batch's rows. */
+MI_API int mi_row_mask(const float *Xa, const float *Xb, int32_t x_split, int32_t n_rows, int32_t D, uint32_t *mask,
+                       void *stream);
+MI_API int mi_spmm_csr_masked(const int32_t *crow, const int32_t *col, const float *val, const float *Xa,
+                              const float *Xb, int32_t x_split, float *Y, const float *acc_in_a,
+                              const float *acc_in_b, int32_t acc_split, float *acc_out, float scale, int32_t n_rows,
+                              int32_t D, const int32_t *short_rows, int32_t n_short, const int32_t *long_rows,
+                              int32_t n_long, const uint32_t *xmask, void *stream);
 
 /* The same product (and fused epilogue) in the TILED form (round 3; csrc/spmm.hip): a workgroup owns a tile of consecutive
  * output rows whose sums live in LDS for the whole launch, the tile's edges — one per 16-lane group, gathered row of X

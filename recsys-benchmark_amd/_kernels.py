@@ -610,7 +610,8 @@ def csr_plan(matrix: torch.Tensor) -> CsrPlan:
     return plan
 
 
-def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D):
+def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D, xmask=None):
+    """xmask (optional, int32 words, one bit per row of X): rows whose bit is 0 are all zeros and are not fetched."""
     lib = _lib.load()
     tp = plan.tiles(D, transposed) if (TILED_SPMM and not DETERMINISTIC) else None
     if tp is not None:
@@ -629,16 +630,33 @@ def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b
         crow, col, sr, lr, n_rows = plan.crow, plan.col, plan.short_rows, plan.long_rows, plan.shape[0]
     dev = val.device
     _lib.check(
-        lib.mi_spmm_csr(crow.data_ptr(), col.data_ptr(), val.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split,
-                        _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale),
-                        n_rows, D, sr.data_ptr() if sr.numel() else None, sr.numel(),
-                        lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.stream_ptr(dev)),
-        "mi_spmm_csr",
+        lib.mi_spmm_csr_masked(crow.data_ptr(), col.data_ptr(), val.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split,
+                               _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale),
+                               n_rows, D, sr.data_ptr() if sr.numel() else None, sr.numel(),
+                               lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.ptr(xmask), _lib.stream_ptr(dev)),
+        "mi_spmm_csr_masked",
     )
 
 
-def _propagate(plan, transposed, val, Xa, Xb, num_layers):
-    """res = (sum_{k=0..L} A^k X) / (L+1) with X = [Xa; Xb] (Xb may be None)."""
+MASK_FIRST_BACKWARD_LAYER = _os.environ.get("MI_SPMM_ROW_MASK", "1") == "1"
+
+
+def _row_mask(Xa, Xb, D):
+    """Bit per row of [Xa; Xb]: 1 = the row has a non-zero element (mi_row_mask), or None where that kernel has no form."""
+    lpr = D // 4
+    if D % 4 or lpr > 64 or lpr & (lpr - 1):
+        return None
+    n = Xa.shape[0] + (Xb.shape[0] if Xb is not None else 0)
+    mask = torch.empty(((n + 31) // 32,), dtype=torch.int32, device=Xa.device)
+    _lib.check(_lib.load().mi_row_mask(Xa.data_ptr(), _lib.ptr(Xb), Xa.shape[0] if Xb is not None else 0, n, D, mask.data_ptr(),
+                                       _lib.stream_ptr(Xa.device)), "mi_row_mask")
+    return mask
+
+
+def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False):
+    """res = (sum_{k=0..L} A^k X) / (L+1) with X = [Xa; Xb] (Xb may be None).  sparse_input: X is expected to be zero on
+    most rows (the gradient entering a backward propagation is non-zero only on the batch's rows): a row mask of X is
+    built on the device (one pass over X) and the first layer does not fetch the zero rows — same result."""
     dev = Xa.device
     D = Xa.shape[1]
     n = Xa.shape[0] + (Xb.shape[0] if Xb is not None else 0)
@@ -653,7 +671,8 @@ def _propagate(plan, transposed, val, Xa, Xb, num_layers):
         Y = None if last else bufs[(k - 1) % len(bufs)]
         scale = 1.0 / (num_layers + 1) if last else 1.0
         if k == 1:
-            _spmm(plan, transposed, val, cur_a, cur_b, cur_split, Y, Xa, Xb, x_split, acc, scale, D)
+            xmask = _row_mask(Xa, Xb, D) if (sparse_input and MASK_FIRST_BACKWARD_LAYER) else None
+            _spmm(plan, transposed, val, cur_a, cur_b, cur_split, Y, Xa, Xb, x_split, acc, scale, D, xmask=xmask)
         else:
             _spmm(plan, transposed, val, cur_a, None, 0, Y, acc, None, 0, acc, scale, D)
         cur_a, cur_b, cur_split = Y, None, 0
@@ -693,7 +712,7 @@ class LightGCNPropagate(torch.autograd.Function):
         val_t = plan.transposed_values(valc)
         if ctx.split is None:
             g = _f32c(gs[0])
-            gX = _propagate(plan, True, val_t, g, None, ctx.num_layers)
+            gX = _propagate(plan, True, val_t, g, None, ctx.num_layers, sparse_input=True)
             return None, gX, None, None, None
         ga, gb = gs
         n_a, n_b = ctx.split, plan.shape[0] - ctx.split
@@ -701,7 +720,7 @@ class LightGCNPropagate(torch.autograd.Function):
         dev = valc.device
         ga = _f32c(ga) if ga is not None else torch.zeros((n_a, D), dtype=torch.float32, device=dev)
         gb = _f32c(gb) if gb is not None else torch.zeros((n_b, D), dtype=torch.float32, device=dev)
-        gX = _propagate(plan, True, val_t, ga, gb, ctx.num_layers)
+        gX = _propagate(plan, True, val_t, ga, gb, ctx.num_layers, sparse_input=True)
         return None, gX[: ctx.split], gX[ctx.split:], None, None
 
 

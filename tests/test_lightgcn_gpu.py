@@ -165,3 +165,43 @@ def test_consecutive_dropout_draws_use_their_own_transposed_values():
         (_kernels.lightgcn_propagate(drawn, d, None, 2) * G.to(DEV)).sum().backward()
         assert_close(d.grad, e.grad, 1e-4, 1e-5, f"draw {it}")
         del drawn, d
+
+
+@pytest.mark.parametrize("U,I,nnz,D,L", [(1500, 500, 20000, 64, 3), (50, 70, 300, 16, 2), (300, 200, 4000, 8, 1)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_backward_with_a_gradient_on_few_rows_skips_the_zero_rows_exactly(U, I, nnz, D, L, masked, monkeypatch):
+    """The gradient entering a backward propagation is non-zero only on the batch's rows (BPR, L2 reg): the first layer
+    of the backward takes a row mask built from that gradient (mi_row_mask) and does not fetch the zero rows
+    (mi_spmm_csr_masked).  The mask must equal `any(g != 0, dim=1)` bit for bit, and the gradients must be IDENTICAL to
+    the unmasked kernel's (a skipped row contributes +0 either way), for two-segment and one-segment tables, hub rows
+    included."""
+    monkeypatch.setattr(_kernels, "MASK_FIRST_BACKWARD_LAYER", masked)
+    adj = _random_graph(U, I, nnz, seed=3 * U + nnz).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    Eu, Ei = torch.randn(U, D, generator=gen), torch.randn(I, D, generator=gen)
+    rows = torch.randint(0, U + I, (max(4, (U + I) // 12),), generator=gen)
+    G = torch.zeros(U + I, D)
+    G[rows] = torch.randn(rows.numel(), D, generator=gen)
+    G[rows[0], 1:] = 0.0                                   # a row whose only non-zero is one element
+    eu, ei = Eu.clone().requires_grad_(True), Ei.clone().requires_grad_(True)
+    (ro.lightgcn_propagate(adj.cpu(), torch.cat([eu, ei]), L) * G).sum().backward()
+    du, di = Eu.to(DEV).requires_grad_(True), Ei.to(DEV).requires_grad_(True)
+    out_u, out_i = _kernels.lightgcn_propagate(adj, du, di, L)
+    (torch.cat([out_u, out_i]) * G.to(DEV)).sum().backward()
+    assert_close(du.grad, eu.grad, 1e-4, 1e-5, "grad user table")
+    assert_close(di.grad, ei.grad, 1e-4, 1e-5, "grad item table")
+    both = torch.cat([Eu, Ei]).to(DEV).requires_grad_(True)
+    (_kernels.lightgcn_propagate(adj, both, None, L) * G.to(DEV)).sum().backward()
+    assert torch.equal(both.grad, torch.cat([du.grad, di.grad])), "one-segment and two-segment backward agree bit for bit"
+    if masked:
+        Gd = G.to(DEV)
+        want = (Gd != 0).any(dim=1).cpu()
+        for a, b in ((Gd[:U].contiguous(), Gd[U:].contiguous()), (Gd, None)):
+            words = _kernels._row_mask(a, b, D).cpu()
+            bits = ((words.view(-1, 1) >> torch.arange(32, dtype=torch.int32)) & 1).bool().view(-1)[:U + I]
+            assert torch.equal(bits, want)
+        # and against the unmasked kernel: bit-identical gradients
+        monkeypatch.setattr(_kernels, "MASK_FIRST_BACKWARD_LAYER", False)
+        ref = torch.cat([Eu, Ei]).to(DEV).requires_grad_(True)
+        (_kernels.lightgcn_propagate(adj, ref, None, L) * Gd).sum().backward()
+        assert torch.equal(ref.grad, both.grad)
