@@ -587,8 +587,12 @@ def bench_c5(args, real_stdout):
 
     def step():
         model.zero_grad(set_to_none=True)
-        au, ai = model(adj)
-        (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * model.get_reg_loss(users, pos, neg)).backward(one)
+        if args.separate_reg:      # the reference's two calls: model(adj), then model.get_reg_loss(...)
+            au, ai = model(adj)
+            reg = model.get_reg_loss(users, pos, neg)
+        else:                      # what trainer.GraphedCFTrainStep runs: both as one autograd node
+            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg)
+        (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * reg).backward(one)
 
     elapsed = time_graphed(step, args, world, dev)
     pkg.check_index_errors()
@@ -711,6 +715,8 @@ def main():
                     "reference-faithful variant with 13 fields of 50 buckets prepended (src/dataset/criteo/utils.py:8-9)")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager pass that times every kernel by dispatch events "
                     "(so that a profiler run sees in-graph launches only)")
+    ap.add_argument("--separate-reg", action="store_true", help="c5: call model(adj) and model.get_reg_loss() separately (the "
+                    "reference's call shape) instead of LightGCN.forward_with_reg_loss (what the mirrored trainer runs)")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the roofline leg (graphs holding only gather+FM kernels), so "
                     "that a profiler run sees those kernels in the step's replays only")
     ap.add_argument("--probe-empties", action="store_true", help="diagnostic: empty kernels of grid 1, 2 (in front of the forward) "

@@ -724,6 +724,67 @@ class LightGCNPropagate(torch.autograd.Function):
         return None, gX[: ctx.split], gX[ctx.split:], None, None
 
 
+class LightGCNPropagateReg(torch.autograd.Function):
+    """LightGCNPropagate of two plain tables AND LightGCN.get_reg_loss over a batch's rows of those tables
+    (src/models/lightgcn.py:79-100) as one node: (res_a, res_b, reg).  The point is the backward: the regulariser's
+    gradient touches 3 B rows, and as a node of its own it reaches the tables as two zero-filled [N, D] tensors that
+    autograd then adds to the propagation's gradients (two fills + two adds of 8 - 10 MB each per step at Yelp2018 size);
+    here mi_rowsq_bwd adds those rows straight into the propagation's gradient."""
+
+    @staticmethod
+    def forward(ctx, val, Xa, Xb, plan, num_layers: int, users, pos, neg):
+        dev = _lib.require_gpu(val, Xa, Xb, users)
+        if val.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the adjacency values are not provided")
+        valc, Xac, Xbc = _f32c(val), _f32c(Xa), _f32c(Xb)
+        if Xac.shape[0] + Xbc.shape[0] != plan.shape[0] or plan.shape[0] != plan.shape[1]:
+            raise ValueError(f"adjacency is {plan.shape} but the embedding tables have {Xac.shape[0] + Xbc.shape[0]} rows")
+        ui, pi, ni = (_i64c(t).view(-1) for t in (users, pos, neg))
+        B, D = ui.numel(), Xac.shape[1]
+        if pi.numel() != B or ni.numel() != B or B == 0:
+            raise ValueError("reg loss: users / positives / negatives must be [B] indices")
+        lib = _lib.load()
+        res = _propagate(plan, False, valc, Xac, Xbc, num_layers)
+        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        reg = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_rowsq_fwd(Xac.data_ptr(), ui.data_ptr(), Xbc.data_ptr(), pi.data_ptr(), Xbc.data_ptr(), ni.data_ptr(),
+                                    B, D, Xac.shape[0], Xbc.shape[0], Xbc.shape[0], _lib.err_word(dev).data_ptr(),
+                                    ws.data_ptr(), reg.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
+        ctx.plan, ctx.num_layers, ctx.split = plan, num_layers, Xac.shape[0]
+        ctx.save_for_backward(valc, Xac, Xbc, ui, pi, ni)
+        return res[: ctx.split], res[ctx.split:], reg.view(())
+
+    @staticmethod
+    def backward(ctx, ga, gb, greg):
+        valc, Xac, Xbc, ui, pi, ni = ctx.saved_tensors
+        plan, split = ctx.plan, ctx.split
+        dev, D = valc.device, Xac.shape[1]
+        if ga is None and gb is None:
+            gX = torch.zeros((plan.shape[0], D), dtype=torch.float32, device=dev)
+        else:
+            ga = _f32c(ga) if ga is not None else torch.zeros((split, D), dtype=torch.float32, device=dev)
+            gb = _f32c(gb) if gb is not None else torch.zeros((plan.shape[0] - split, D), dtype=torch.float32, device=dev)
+            gX = _propagate(plan, True, plan.transposed_values(valc), ga, gb, ctx.num_layers, sparse_input=True)
+        gXa, gXb = gX[:split], gX[split:]
+        if greg is not None:
+            g = _f32c(greg).view(1)
+            _lib.check(_lib.load().mi_rowsq_bwd(Xac.data_ptr(), ui.data_ptr(), Xbc.data_ptr(), pi.data_ptr(), Xbc.data_ptr(),
+                                                ni.data_ptr(), ui.numel(), D, Xac.shape[0], Xbc.shape[0], Xbc.shape[0],
+                                                g.data_ptr(), gXa.data_ptr(), gXb.data_ptr(), gXb.data_ptr(),
+                                                _lib.stream_ptr(dev)), "mi_rowsq_bwd")
+        return None, gXa, gXb, None, None, None, None, None
+
+
+def lightgcn_propagate_reg(matrix: torch.Tensor, Xa: torch.Tensor, Xb: torch.Tensor, num_layers: int, users, pos, neg):
+    """(all_user_emb, all_item_emb, reg_loss) — see LightGCNPropagateReg."""
+    if matrix.layout != torch.sparse_csr:
+        if matrix.layout == torch.sparse_coo:
+            matrix = matrix.coalesce().to_sparse_csr()
+        else:
+            raise ValueError(f"Not supported matrix layout: {matrix.layout}")
+    return LightGCNPropagateReg.apply(matrix.values(), Xa, Xb, csr_plan(matrix), num_layers, users, pos, neg)
+
+
 def lightgcn_propagate(matrix: torch.Tensor, Xa: torch.Tensor, Xb: Optional[torch.Tensor], num_layers: int):
     if matrix.layout != torch.sparse_csr:
         if matrix.layout == torch.sparse_coo:

@@ -93,16 +93,25 @@ class _BPRFn(torch.autograd.Function):
         idx = [next(it) if h else None for h in ctx.has_idx]
         B, D = ctx.meta
         g = _kernels._f32c(g).view(1)
+        # positives and negatives picked from ONE table (bpr_loss_rows): one zero-filled gradient takes both contributions
+        # — a second one would cost a fill and the add autograd then makes of the two
+        need = ctx.needs_input_grad
+        same = (idx[1] is not None and idx[2] is not None and need[1] and need[2]
+                and P.data_ptr() == Nn.data_ptr() and P.shape == Nn.shape)
         grads = []
-        for need, t, i in zip(ctx.needs_input_grad[:3], (U, P, Nn), idx):
-            # rows repeat under an index array: the kernel accumulates with atomics into zeros
-            grads.append(None if not need else (torch.zeros_like(t) if i is not None else torch.empty_like(t)))
+        for k, (t, i) in enumerate(zip((U, P, Nn), idx)):
+            if not need[k]:
+                grads.append(None)
+            elif k == 2 and same:
+                grads.append(grads[1])
+            else:   # rows repeat under an index array: the kernel accumulates with atomics into zeros
+                grads.append(torch.zeros_like(t) if i is not None else torch.empty_like(t))
         _lib.check(_lib.load().mi_bpr_bwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
                                           _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
                                           sig.data_ptr(), g.data_ptr(), _lib.ptr(grads[0]),
                                           _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.stream_ptr(U.device)),
                    "mi_bpr_bwd")
-        return grads[0], grads[1], grads[2], None, None, None
+        return grads[0], grads[1], (None if same else grads[2]), None, None, None
 
 
 def bpr_loss(user_embs, pos_embs, neg_embs):

@@ -302,10 +302,15 @@ class GraphedCFTrainStep:
         self._graph, self._static, self._shape, self._seen = None, None, None, 0
 
     def _body(self, users, pos_items, neg_items):
-        all_user_emb, all_item_emb = self.model(self.adj)
+        fused = self.weight_decay > 0 and hasattr(self.model, "forward_with_reg_loss")
+        if fused:      # propagation + regulariser as one node: the regulariser's gradient rows join the propagation's
+            all_user_emb, all_item_emb, reg_loss = self.model.forward_with_reg_loss(self.adj, users, pos_items, neg_items)
+        else:
+            all_user_emb, all_item_emb = self.model(self.adj)
         rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items)
         zero = torch.zeros((), device=rec_loss.device)
-        reg_loss = self.model.get_reg_loss(users, pos_items, neg_items) if self.weight_decay > 0 else zero
+        if not fused:
+            reg_loss = self.model.get_reg_loss(users, pos_items, neg_items) if self.weight_decay > 0 else zero
         cl_loss = zero
         if self.info_nce_weight > 0:           # SGL without augmentation (src/trainer/lightgcn.py:405-417)
             # view1 = rows of the batch's DISTINCT users and positives; here: all batch rows, repeats masked out (the loss is

@@ -205,3 +205,34 @@ def test_backward_with_a_gradient_on_few_rows_skips_the_zero_rows_exactly(U, I, 
         ref = torch.cat([Eu, Ei]).to(DEV).requires_grad_(True)
         (_kernels.lightgcn_propagate(adj, ref, None, L) * Gd).sum().backward()
         assert torch.equal(ref.grad, both.grad)
+
+
+def test_propagation_and_regulariser_as_one_node_equal_the_two_calls():
+    """LightGCN.forward_with_reg_loss == (model(adj), model.get_reg_loss(...)): same outputs bit for bit, and the table
+    gradients of the full BPR + weight_decay * reg objective within float-atomic ordering (the regulariser's rows are added
+    into the propagation's gradient instead of arriving as two dense tensors); repeated ids in the batch included."""
+    from recsys_benchmark_amd.losses import bpr_loss_rows
+
+    U, I, D, L, B = 300, 500, 64, 3, 256
+    adj = _random_graph(U, I, 6000, seed=9).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    users = torch.randint(0, U, (B,), generator=gen).to(DEV)
+    pos = torch.randint(0, I, (B,), generator=gen).to(DEV)
+    neg = torch.randint(0, 40, (B,), generator=gen).to(DEV)          # many repeats
+    grads = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = LightGCN(U, I, num_layers=L, hidden_size=D).to(DEV)
+        if fused:
+            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg)
+        else:
+            au, ai = model(adj)
+            reg = model.get_reg_loss(users, pos, neg)
+        loss = bpr_loss_rows(au, ai, users, pos, neg) + 0.05 * reg
+        loss.backward()
+        grads.append((au.detach(), ai.detach(), reg.detach(), model.user_emb_table.get_weight().grad.clone(),
+                      model.item_emb_table.get_weight().grad.clone()))
+    for a, b, what in zip(grads[0][:3], grads[1][:3], ("user emb", "item emb", "reg")):
+        assert torch.equal(a, b), what
+    assert_close(grads[1][3], grads[0][3], 1e-5, 1e-7, "user table gradient")
+    assert_close(grads[1][4], grads[0][4], 1e-5, 1e-7, "item table gradient")
