@@ -292,21 +292,36 @@ def dcn_mix_head(x0: torch.Tensor, p: Params, num_layers: int, prefix: str = "")
     return x_l
 
 
-def bn_mlp(x, p: Params, prefix: str, n_hidden: int, training: bool) -> torch.Tensor:
-    """(Linear, BatchNorm1d, ReLU, Dropout(0)) x n — the `_dnn` stacks of src/models/dcn.py:56-66,179-186."""
+def bn_mlp(x, p: Params, prefix: str, n_hidden: int, training: bool, relu_keep=None, pre_out=None) -> torch.Tensor:
+    """(Linear, BatchNorm1d, ReLU, Dropout(0)) x n — the `_dnn` stacks of src/models/dcn.py:56-66,179-186.
+
+    Test hooks (not part of the reference): `pre_out` (a list) receives, per layer, (z, s): the pre-activation entering the
+    ReLU and the sum of the magnitudes of the terms it was formed from (what a float32 evaluation's rounding error scales
+    with); `relu_keep` (a list of bool tensors) replaces the decisions `z > 0` of the ReLUs by given ones — a float32
+    implementation takes the other side of the kink where z is within rounding of 0, and the comparison must hold the
+    decisions fixed to see anything else."""
     for k in range(n_hidden):
         i = 4 * k
-        x = F.linear(x, p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"])
-        x = F.batch_norm(x, p[f"{prefix}.{i+1}.running_mean"].clone(), p[f"{prefix}.{i+1}.running_var"].clone(),
+        W, b = p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"]
+        lin = F.linear(x, W, b)
+        z = F.batch_norm(lin, p[f"{prefix}.{i+1}.running_mean"].clone(), p[f"{prefix}.{i+1}.running_var"].clone(),
                          p[f"{prefix}.{i+1}.weight"], p[f"{prefix}.{i+1}.bias"], training=training)
-        x = F.relu(x)
+        if pre_out is not None:
+            with torch.no_grad():
+                mean = lin.mean(0) if training else p[f"{prefix}.{i+1}.running_mean"]
+                var = lin.var(0, unbiased=False) if training else p[f"{prefix}.{i+1}.running_var"]
+                scale = (p[f"{prefix}.{i+1}.weight"] * torch.rsqrt(var + 1e-5)).abs()
+                s_lin = F.linear(x.abs(), W.abs(), b.abs())
+                pre_out.append((z.detach(), (s_lin + mean.abs()) * scale + p[f"{prefix}.{i+1}.bias"].abs()))
+        x = F.relu(z) if relu_keep is None else z * relu_keep[k].to(z.dtype)
     return x
 
 
-def dcn_mix_forward(x, p: Params, emb: torch.Tensor, num_layers: int, n_hidden: int, training: bool) -> torch.Tensor:
-    """DCN_Mix.forward after the embedding lookup — src/models/dcn.py:89-96."""
+def dcn_mix_forward(x, p: Params, emb: torch.Tensor, num_layers: int, n_hidden: int, training: bool, relu_keep=None,
+                    pre_out=None) -> torch.Tensor:
+    """DCN_Mix.forward after the embedding lookup — src/models/dcn.py:89-96 (relu_keep / pre_out: see bn_mlp)."""
     h = dcn_mix_head(emb.reshape(x.shape[0], -1), p, num_layers, "cross_head.")
-    h = bn_mlp(h, p, "_dnn", n_hidden, training)
+    h = bn_mlp(h, p, "_dnn", n_hidden, training, relu_keep=relu_keep, pre_out=pre_out)
     i = 4 * n_hidden
     return F.linear(h, p[f"_dnn.{i}.weight"], p[f"_dnn.{i}.bias"]).squeeze(-1)
 
