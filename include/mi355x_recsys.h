@@ -633,7 +633,9 @@ MI_API int mi_mask_topk_rows(float *scores, int64_t ld, int64_t nrows, int64_t n
  * mi_slot_fm_fwd: mi_gather_fm_fwd over the received packed rows buf[nrows, D+4] addressed by slot
  *   (row nrows-1 = the zeroed dump row): emb[B,F,D], yfm[B].
  * mi_slot_fm_bwd: zero gbuf[nslot, D+4], then the row gradients of mi_gather_fm_bwd_rows written to
- *   gbuf[slot[b,f]] (first-order gradient in column D); slots >= nslot are skipped.               */
+ *   gbuf[slot[b,f]] (first-order gradient in column D); slots >= nslot are skipped.
+ * mi_unpack_rows: vals[i, 0:D] = packed[i, 0:D], lin[i] = packed[i, D] for m rows of D + 4 floats: the gradient rows
+ *   received by the owner as the two contiguous value arrays of its shards' row-form gradients.  */
 MI_API int64_t mi_route_workspace_elems(int64_t n, int32_t world);
 MI_API int mi_route_buckets(const int64_t *idx, const int64_t *offsets, int64_t n, int32_t F,
                             int32_t world, int64_t N, int64_t cap, int32_t *workspace,
@@ -641,6 +643,7 @@ MI_API int mi_route_buckets(const int64_t *idx, const int64_t *offsets, int64_t 
                             void *stream);
 MI_API int mi_gather_pack_rows(const int64_t *rows, const float *W, const float *w1, float *out,
                                int64_t m, int32_t D, int64_t Nl, int32_t *err, void *stream);
+MI_API int mi_unpack_rows(const float *packed, float *vals, float *lin, int64_t m, int32_t D, void *stream);
 MI_API int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const float *bias,
                           float *emb_out, float *yfm_out, int64_t B, int32_t F, int32_t D,
                           int32_t *err, void *stream);

@@ -52,6 +52,10 @@ class TorchOps:
         return torch.cat([W.detach()[r], w1.detach().reshape(-1, 1)[r], W.new_zeros(r.numel(), 3)], 1)
 
     @staticmethod
+    def unpack_rows(packed, D: int):
+        return packed[:, :D].contiguous(), packed[:, D].contiguous()
+
+    @staticmethod
     def slot_fm(buf, slot, bias):
         D = buf.shape[1] - 4
         got = buf[slot]                                   # [B, F, D+4]; autograd scatters the gradient rows back

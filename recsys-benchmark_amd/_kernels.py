@@ -1411,6 +1411,20 @@ def gather_pack_rows(local_rows: torch.Tensor, W: torch.Tensor, w1: torch.Tensor
     return out
 
 
+def unpack_rows(packed: torch.Tensor, D: int):
+    """([m, D], [m]) contiguous copies of columns 0..D-1 and column D of packed rows [m, D+4] — one launch (mi_unpack_rows)."""
+    dev = _lib.require_gpu(packed)
+    pc = _f32c(packed)
+    if pc.dim() != 2 or pc.shape[1] != D + 4:
+        raise ValueError("unpack_rows: rows of D + 4 floats expected")
+    m = pc.shape[0]
+    vals = torch.empty((m, D), dtype=torch.float32, device=dev)
+    lin = torch.empty((m,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().mi_unpack_rows(pc.data_ptr(), vals.data_ptr(), lin.data_ptr(), m, D, _lib.stream_ptr(dev)),
+               "mi_unpack_rows")
+    return vals, lin
+
+
 class SlotFM(torch.autograd.Function):
     """(emb[B,F,D], y_fm[B]) from the packed rows a sharded lookup received, addressed by slot
     (src/models/deepfm.py:88-98 on exchanged rows).  buf is [S+1, D+4] with row S all zeros (the

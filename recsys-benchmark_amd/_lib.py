@@ -96,6 +96,7 @@ SIGNATURES = {
     "mi_optembed_bwd": [_p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i64, _p],
     "mi_route_workspace_elems": [_i64, _i32],
     "mi_route_buckets": [_p, _p, _i64, _i32, _i32, _i64, _i64, _p, _p, _p, _p, _p, _p],
+    "mi_unpack_rows": [_p, _p, _p, _i64, _i32, _p],
     "mi_gather_pack_rows": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p],
     "mi_slot_fm_fwd": [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],

@@ -24,6 +24,7 @@ using namespace mi;
 constexpr int kIt = 4;                    // lookups per thread
 constexpr int kChunk = kBlock * kIt;      // lookups per workgroup
 constexpr int kMaxWorld = 64;
+constexpr int kSelfScanGroups = 512;    // up to this many count workgroups the assign launch scans the counts itself
 
 // floor-mod owner / floor-div local row; own = -1 for an out-of-range or inactive lookup
 __device__ __forceinline__ void classify(const int64_t *__restrict__ idx,
@@ -98,13 +99,35 @@ __global__ __launch_bounds__(kBlock) void k_route_scan(const int32_t *__restrict
   }
 }
 
+// SELF_SCAN: no k_route_scan launch ran — every workgroup adds up the counts of the workgroups before it (its base) and of
+// all of them (the totals) itself: G x world integers, a few KB while G is a few hundred (B F = 106 K lookups: G = 104).
+// One launch (~4 us of boundary + a one-workgroup kernel) less on the critical path of every sharded step.
+template <bool SELF_SCAN>
 __global__ __launch_bounds__(kBlock) void k_route_assign(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets, int F, int64_t n,
     int world, int64_t N, int64_t cap, const int32_t *__restrict__ base,
     const int32_t *__restrict__ total, int64_t *__restrict__ send_rows,
-    int64_t *__restrict__ slot, int32_t *overflow, int32_t *err) {
+    int64_t *__restrict__ slot, int32_t *overflow, int32_t *err, const int32_t *__restrict__ counts) {
   __shared__ int cnt[kIt][kWavesPerBlock][kMaxWorld];
+  __shared__ int sbase[kMaxWorld], stotal[kMaxWorld];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if constexpr (SELF_SCAN) {
+    const int G = gridDim.x;
+    for (int w = wv; w < world; w += kWavesPerBlock) {
+      int b = 0, t = 0;
+      for (int g = lane; g < G; g += kWave) {
+        const int v = counts[(int64_t)g * world + w];
+        t += v;
+        b += g < (int)blockIdx.x ? v : 0;
+      }
+#pragma unroll
+      for (int off = 32; off; off >>= 1) {
+        b += __shfl_xor(b, off);
+        t += __shfl_xor(t, off);
+      }
+      if (lane == 0) { sbase[w] = b; stotal[w] = t; }
+    }
+  }
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
   int own[kIt], rank[kIt];
   int64_t loc[kIt];
@@ -129,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_route_assign(
     const int64_t i = (int64_t)blockIdx.x * kChunk + k * kBlock + threadIdx.x;
     int64_t s = dump;
     if (own[k] >= 0) {
-      int64_t pos = base[(int64_t)blockIdx.x * world + own[k]] + rank[k];
+      int64_t pos = (SELF_SCAN ? sbase[own[k]] : base[(int64_t)blockIdx.x * world + own[k]]) + rank[k];
       // lookups before this one in index order: earlier k, or same k and an earlier wave
       for (int kk = 0; kk <= k; ++kk) {
         const int wend = kk < k ? kWavesPerBlock : wv;
@@ -148,7 +171,8 @@ __global__ __launch_bounds__(kBlock) void k_route_assign(
   }
   // unused slots of every bucket point at the owner's sink row
   for (int w = 0; w < world; ++w) {
-    const int64_t used = total[w] < cap ? total[w] : cap;
+    const int64_t tw = SELF_SCAN ? stotal[w] : total[w];
+    const int64_t used = tw < cap ? tw : cap;
     const int64_t sink = (N - w + world - 1) / world;   // rows the owner really has
     for (int64_t j = used + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < cap;
          j += (int64_t)gridDim.x * kBlock)
@@ -204,6 +228,27 @@ __global__ __launch_bounds__(kBlock) void k_gather_pack(
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
 }
 
+// vals[i, 0:D] = packed[i, 0:D], lin[i] = packed[i, D]: the received gradient rows as the two contiguous value arrays of
+// the shards' row-form gradients, one launch (two strided torch copies before: 2 x ~5 us, launch-bound)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_unpack_rows(const float *__restrict__ packed, float *__restrict__ vals,
+                                                        float *__restrict__ lin, int64_t m) {
+  constexpr int RS = kWave / LPR;
+  constexpr int D = LPR * 4;
+  constexpr int LDO = D + 4;
+  const int lane = threadIdx.x & 63;
+  const int q = lane % LPR, r = lane / LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t t = wave0; t * RS < m; t += nwaves) {
+    const int64_t i = t * RS + r;
+    if (i < m) {
+      st4(vals + i * D + q * 4, ld4(packed + i * LDO + q * 4));
+      if (q == 0) lin[i] = packed[i * LDO + D];
+    }
+  }
+}
+
 inline bool vec_ok(int D) {
   return D >= 4 && D <= 256 && (D & 3) == 0 && ((D >> 2) & ((D >> 2) - 1)) == 0;
 }
@@ -231,9 +276,14 @@ int mi_route_buckets(const int64_t *idx, const int64_t *offsets, int64_t n, int3
   const int G = (int)G64;
   int32_t *counts = workspace, *base = workspace + G64 * world, *total = base + G64 * world;
   MI_LAUNCH("route_count", k_route_count, G, kBlock, stream, idx, offsets, F, n, world, N, counts);
+  if (G <= kSelfScanGroups) {      // two launches: the assigning workgroups scan the counts themselves
+    MI_LAUNCH("route_assign", k_route_assign<true>, G, kBlock, stream, idx, offsets, F, n, world, N, cap, base, total,
+              send_rows, slot, overflow, err, counts);
+    return launch_status();
+  }
   MI_LAUNCH("route_scan", k_route_scan, 1, kBlock, stream, counts, G, world, base, total);
-  MI_LAUNCH("route_assign", k_route_assign, G, kBlock, stream, idx, offsets, F, n, world, N, cap,
-            base, total, send_rows, slot, overflow, err);
+  MI_LAUNCH("route_assign", k_route_assign<false>, G, kBlock, stream, idx, offsets, F, n, world, N, cap,
+            base, total, send_rows, slot, overflow, err, counts);
   return launch_status();
 }
 
@@ -250,6 +300,25 @@ int mi_gather_pack_rows(const int64_t *rows, const float *W, const float *w1, fl
   case LPR:                                                                                  \
     MI_LAUNCH("gather_pack", (k_gather_pack<LPR>), grid, kBlock, stream, rows, W, w1, out, m, \
               Nl, err);                                                                      \
+    break;
+    CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    default: return MI_ERR_UNSUPPORTED;
+  }
+  return launch_status();
+}
+
+int mi_unpack_rows(const float *packed, float *vals, float *lin, int64_t m, int32_t D, void *stream) {
+  if (m < 0 || D <= 0) return MI_ERR_INVALID_ARG;
+  if (m == 0) return MI_OK;
+  if (!packed || !vals || !lin) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(D) || !aligned16(packed) || !aligned16(vals)) return MI_ERR_UNSUPPORTED;
+  const int64_t rows_per_wave = kWave / (D / 4);
+  const int grid = grid_for_waves((m + rows_per_wave - 1) / rows_per_wave);
+  switch (D / 4) {
+#define CASE(LPR)                                                                                 \
+  case LPR:                                                                                       \
+    MI_LAUNCH("unpack_rows", (k_unpack_rows<LPR>), grid, kBlock, stream, packed, vals, lin, m);  \
     break;
     CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
 #undef CASE

@@ -46,6 +46,7 @@ class HipOps:
 
     route_buckets = staticmethod(_kernels.route_buckets)
     gather_pack_rows = staticmethod(_kernels.gather_pack_rows)
+    unpack_rows = staticmethod(_kernels.unpack_rows)
     slot_fm = staticmethod(_kernels.slot_fm)
 
     @staticmethod
@@ -550,7 +551,7 @@ class ShardedDeepFM(nn.Module):
             send_rows, _ = self.ops.route_buckets(x, self.offsets, world, self.num_rows, cap, self.bucket_overflow,
                                                   slot_out=slot)
             local_rows = torch.empty_like(send_rows)
-            if mark: mark("route (3 launches)")
+            if mark: mark("route (2 launches)")
             _all_to_all(self, local_rows, send_rows)
             if mark: mark("all-to-all #1: row ids")
             packed = self.ops.gather_pack_rows(local_rows, self.embedding_shard, self.fc_shard)
@@ -565,10 +566,10 @@ class ShardedDeepFM(nn.Module):
                 if mark: mark("all-to-all #3: gradient rows")
                 idx = local_rows.view(1, -1)
                 # the received rows are already scaled by 1/world; COO values must be contiguous (torch's sparse
-                # kernels read strided values wrongly), so the two column blocks are copied out
-                self.embedding_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, :D].contiguous(), Wshape,
-                                                                    check_invariants=False)
-                self.fc_shard.grad = torch.sparse_coo_tensor(idx, g_owner[:, D:D + 1].contiguous(), w1shape,
+                # kernels read strided values wrongly), so the two column blocks are copied out (one launch)
+                gvals, glin = self.ops.unpack_rows(g_owner, D)
+                self.embedding_shard.grad = torch.sparse_coo_tensor(idx, gvals, Wshape, check_invariants=False)
+                self.fc_shard.grad = torch.sparse_coo_tensor(idx, glin.view((-1,) + tuple(w1shape[1:])), w1shape,
                                                              check_invariants=False)
                 if mark: mark("COO gradient column copies")
                 if self.__dict__.get("_comm") is not None:

@@ -90,6 +90,31 @@ def test_gather_pack_rows(D):
     pkg.check_index_errors()
 
 
+@pytest.mark.parametrize("D,m", [(4, 1), (8, 63), (16, 777), (64, 1000), (256, 5)])
+def test_unpack_rows_is_the_two_column_block_copies(D, m):
+    g = torch.Generator().manual_seed(D + m)
+    packed = torch.randn(m, D + 4, generator=g)
+    vals, lin = _kernels.unpack_rows(packed.to(DEV), D)
+    ref_vals, ref_lin = TorchOps.unpack_rows(packed, D)
+    assert vals.is_contiguous() and lin.is_contiguous()
+    assert torch.equal(vals.cpu(), ref_vals) and torch.equal(lin.cpu(), ref_lin)
+
+
+@pytest.mark.parametrize("B,F,world", [(4096, 26, 8), (4096, 26, 3), (700000, 1, 4)])
+def test_route_two_launch_and_three_launch_forms_agree_with_the_restatement(B, F, world):
+    """Up to 512 count workgroups (524 288 lookups) the assigning workgroups scan the counts themselves (two launches);
+    beyond, a scan launch sits in between (three): both against the torch restatement, bit for bit."""
+    g = torch.Generator().manual_seed(B + F + world)
+    dims = [int(v) for v in torch.randint(1, 5000, (F,), generator=g)]
+    x = torch.stack([torch.randint(0, d, (B,), generator=g) for d in dims], 1)
+    offsets = torch.tensor([0] + dims[:-1]).cumsum(0)
+    N = sum(dims)
+    cap = (B * F) // world + 512
+    ref = TorchOps.route_buckets(x, offsets, world, N, cap, torch.zeros(1, dtype=torch.int32))
+    got = _kernels.route_buckets(x.to(DEV), offsets.to(DEV), world, N, cap, _flag())
+    assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+
+
 def test_gather_pack_rejects_unsupported_width_loudly():
     with pytest.raises(_lib.MI355XLibraryError):
         _kernels.gather_pack_rows(torch.zeros(3, dtype=torch.int64, device=DEV), torch.zeros(5, 6, device=DEV),
