@@ -973,7 +973,7 @@ def main():
     # the timed steps really produced gradients (a replayed graph reading a freed seed tensor would give zeros)
     # (weights only: a Linear bias in front of a training-mode BatchNorm has an exactly zero gradient)
     probe = [model._bias.grad] + [p.grad for p in model._deep_branch.parameters() if p.grad is not None and p.dim() == 2][:2]
-    for gprobe in ([] if os.environ.get("MI_BENCH_KNOCKOUT") else probe):      # (knock-out builds compute garbage on purpose)
+    for gprobe in probe:
         if gprobe is None or not bool(torch.isfinite(gprobe).all()) or float(gprobe.abs().sum()) == 0.0:
             raise SystemExit("bench: a gradient of the timed steps is missing, zero or non-finite")
 

@@ -104,9 +104,6 @@ struct NoConsts {};
 //   Consts consts_u(ub, c)           per-column constants of column c relative to ub (KC operands: c = the thread's column
 //                                    inside the slice)
 //   float4 finish_u(raw, k, ub, tc)  form the operand value
-// An empty volatile asm keeps hipcc from turning the (uniform, rarely taken) partial-slice branches into selects that every
-// slice would execute: a block with a volatile asm cannot be speculated.
-#define PARTIAL_SLICE_ONLY() asm volatile("; partial slice only" ::: "memory")
 __device__ __forceinline__ float4 vld4u(const float *base, uint32_t boff) {
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + boff);
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the weight-gradient multi-GEMM variants on a GPU box: exactness tests, then C2 and C3 steps per variant
-# (MI_GEMM_TN_DMA = 0 general 64x64 kernel, 1 LDS-DMA 64x64, 2 LDS-DMA 128x128)
+# (MI_GEMM_TN_DMA = 0 general 64x64-tile kernel, 1 (default) the LDS-DMA kernel of the weight-gradient form)
 R=${GRAFT_REPO_ROOT:-.}
 mkdir -p $R/gpurun_out/ab
 for v in "$@"; do
