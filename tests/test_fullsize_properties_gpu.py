@@ -178,6 +178,61 @@ def test_c5_adjointness_and_transposed_backward(yelp):
     assert plan.long_rows.numel() > 0 and plan.pattern_symmetric
 
 
+def test_c5_masked_backward_layer_at_full_size_is_bit_identical(yelp, monkeypatch):
+    """A gradient that lives on 3 x 2048 rows of the 69 716 (what BPR + L2 reg hand to the propagation's backward at the
+    C5 batch size): the backward with the row mask (first layer skips the zero rows) and without it give the same bits,
+    and the mask has exactly the batch's rows set."""
+    A, deg, U, I = yelp
+    gen = torch.Generator().manual_seed(17)
+    n = U + I
+    rows = torch.cat([torch.randint(0, U, (2048,), generator=gen), U + torch.randint(0, I, (4096,), generator=gen)]).to(DEV)
+    G = torch.zeros(n, 64, device=DEV)
+    G[rows] = torch.randn(rows.numel(), 64, generator=gen).to(DEV)
+    grads = []
+    for masked in (True, False):
+        monkeypatch.setattr(_kernels, "MASK_FIRST_BACKWARD_LAYER", masked)
+        x = torch.ones(n, 64, device=DEV).requires_grad_(True)
+        (torch.cat(_kernels.lightgcn_propagate(A, x[:U], x[U:], 3)) * G).sum().backward()
+        grads.append(x.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    words = _kernels._row_mask(G[:U].contiguous(), G[U:].contiguous(), 64).cpu()
+    bits = ((words.view(-1, 1) >> torch.arange(32, dtype=torch.int32)) & 1).bool().view(-1)[:n]
+    want = torch.zeros(n, dtype=torch.bool)
+    want[rows.cpu()] = True
+    assert torch.equal(bits, want)
+
+
+def test_c2_packed_table_at_full_size_equals_the_two_tensor_layout(c2):
+    """The packed fp32[N, 32] table (row = 16 embedding floats + first-order weight) at the full C2 size (33.8 M rows,
+    4.3 GB): forward outputs and both row-form gradients through the strided entry points are bit-identical to the
+    two-tensor layout's, ids at both ends of every field included (64-bit row addressing with a 128-byte pitch)."""
+    W, w1, bias, off, x = c2
+    N, D = W.shape
+    xe = x.clone()
+    dims = torch.tensor(CRITEO, device=DEV)
+    xe[0] = 0
+    xe[1] = dims - 1
+    packed = torch.zeros(N, 32, device=DEV)
+    packed[:, :D] = W
+    packed[:, D] = w1.view(-1)
+    Wp, w1p = packed[:, :D], packed[:, D:D + 1]
+    assert not Wp.is_contiguous()
+    outs = []
+    for Wt, wt in ((W, w1), (Wp, w1p)):
+        Wt = Wt.detach().requires_grad_(True)
+        wt = wt.detach().requires_grad_(True)
+        emb, yfm = _kernels.gather_fm(xe, off, Wt, wt, bias, sparse_W=True, sparse_w1=True)
+        gen = torch.Generator().manual_seed(4)
+        ge, gy = torch.randn(emb.shape, generator=gen).to(DEV), torch.randn(yfm.shape, generator=gen).to(DEV)
+        ((emb * ge).sum() + (yfm * gy).sum()).backward()
+        outs.append((emb.detach(), yfm.detach(), Wt.grad, wt.grad))
+    for a, b, what in zip(outs[0][:2], outs[1][:2], ("emb", "y_fm")):
+        assert torch.equal(a, b), what
+    for a, b, what in zip(outs[0][2:], outs[1][2:], ("table gradient", "first-order gradient")):
+        assert torch.equal(a._indices(), b._indices()) and torch.equal(a._values(), b._values()), what
+    _lib.check_index_errors()
+
+
 def test_c4_billion_row_table_addressing():
     """BASELINE config 4's table on ONE MI355X (288 GB HBM): N = 1e9 rows x 16 fp32 = 64 GB, element offsets far
     beyond 2^31.  The table is never initialised as a whole (only the looked-up rows and their neighbours are
