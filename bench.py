@@ -591,7 +591,7 @@ def bench_c5(args, real_stdout):
             au, ai = model(adj)
             reg = model.get_reg_loss(users, pos, neg)
         else:                      # what trainer.GraphedCFTrainStep runs: both as one autograd node
-            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg)
+            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg, batch_rows_only=True)
         (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * reg).backward(one)
 
     elapsed = time_graphed(step, args, world, dev)

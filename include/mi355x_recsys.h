@@ -262,6 +262,20 @@ MI_API int mi_spmm_csr_masked(const int32_t *crow, const int32_t *col, const flo
                               const float *acc_in_b, int32_t acc_split, float *acc_out, float scale, int32_t n_rows,
                               int32_t D, const int32_t *short_rows, int32_t n_short, const int32_t *long_rows,
                               int32_t n_long, const uint32_t *xmask, void *stream);
+/* The same with a selection of OUTPUT rows for the LAST layer of a training step's propagation, which is read at the
+ * batch's rows only: short_rows = the batch's non-hub rows (repeats allowed — Y / acc_out must then not alias the
+ * inputs), long_rows = the graph's hub rows, of which only those whose byte in hub_need is set are computed (the byte is
+ * cleared again by the kernel; NULL: all of them).  mi_batch_row_list builds both from a batch: out[3B] = users | U + pos |
+ * U + neg with hubs (is_hub[row] != 0) and out-of-range ids replaced by `filler` (any non-hub row) and hub_need[row] = 1
+ * for the hubs.  Rows that are not selected keep whatever Y / acc_out held. */
+MI_API int mi_batch_row_list(const int64_t *users, const int64_t *pos, const int64_t *neg, int64_t B, int64_t U,
+                             int64_t n_rows, const uint8_t *is_hub, int32_t filler, int32_t *out, uint8_t *hub_need,
+                             void *stream);
+MI_API int mi_spmm_csr_sel(const int32_t *crow, const int32_t *col, const float *val, const float *Xa,
+                           const float *Xb, int32_t x_split, float *Y, const float *acc_in_a,
+                           const float *acc_in_b, int32_t acc_split, float *acc_out, float scale, int32_t n_rows,
+                           int32_t D, const int32_t *short_rows, int32_t n_short, const int32_t *long_rows,
+                           int32_t n_long, const uint32_t *xmask, uint8_t *hub_need, void *stream);
 
 /* The same product (and fused epilogue) in the TILED form (round 3; csrc/spmm.hip): a workgroup owns a tile of consecutive
  * output rows whose sums live in LDS for the whole launch, the tile's edges — one per 16-lane group, gathered row of X

@@ -481,6 +481,9 @@ class CsrPlan:
         self.col = col.to(torch.int32).contiguous()
         deg = (crow[1:] - crow[:-1])
         self.short_rows, self.long_rows = self._split(deg)
+        self.is_hub = (deg > HUB_DEGREE).to(torch.uint8)          # per row of A: handled by a whole workgroup
+        self.hub_need = torch.zeros(n_rows, dtype=torch.uint8, device=dev)     # mi_spmm_csr_sel's flags: zero between launches
+        self.filler_row = int(self.short_rows[0]) if self.short_rows.numel() else -1
         # transpose: sort entries by (col, row); perm maps transposed entry -> original entry
         rows = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
         key = col.to(torch.int64) * n_rows + rows
@@ -610,10 +613,14 @@ def csr_plan(matrix: torch.Tensor) -> CsrPlan:
     return plan
 
 
-def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D, xmask=None):
-    """xmask (optional, int32 words, one bit per row of X): rows whose bit is 0 are all zeros and are not fetched."""
+def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b, acc_split, acc_out, scale, D, xmask=None,
+          rows=None):
+    """xmask (optional, int32 words, one bit per row of X): rows whose bit is 0 are all zeros and are not fetched.
+    rows (optional, (short int32 list, hub int32 list, hub_need bytes)): only these OUTPUT rows are computed — of the hubs
+    those whose hub_need byte is set (repeats allowed: the outputs must then not alias the inputs); the other rows of Y /
+    acc_out are left untouched."""
     lib = _lib.load()
-    tp = plan.tiles(D, transposed) if (TILED_SPMM and not DETERMINISTIC) else None
+    tp = plan.tiles(D, transposed) if (TILED_SPMM and not DETERMINISTIC and rows is None) else None
     if tp is not None:
         ev = plan.tile_values(val, D, transposed)
         _lib.check(
@@ -628,13 +635,17 @@ def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b
         crow, col, sr, lr, n_rows = plan.crow_t, plan.col_t, plan.short_rows_t, plan.long_rows_t, plan.shape[1]
     else:
         crow, col, sr, lr, n_rows = plan.crow, plan.col, plan.short_rows, plan.long_rows, plan.shape[0]
+    need = None
+    if rows is not None:
+        sr, lr, need = rows
     dev = val.device
     _lib.check(
-        lib.mi_spmm_csr_masked(crow.data_ptr(), col.data_ptr(), val.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split,
-                               _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale),
-                               n_rows, D, sr.data_ptr() if sr.numel() else None, sr.numel(),
-                               lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.ptr(xmask), _lib.stream_ptr(dev)),
-        "mi_spmm_csr_masked",
+        lib.mi_spmm_csr_sel(crow.data_ptr(), col.data_ptr(), val.data_ptr(), Xa.data_ptr(), _lib.ptr(Xb), x_split,
+                            _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale),
+                            n_rows, D, sr.data_ptr() if sr.numel() else None, sr.numel(),
+                            lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.ptr(xmask), _lib.ptr(need),
+                            _lib.stream_ptr(dev)),
+        "mi_spmm_csr_sel",
     )
 
 
@@ -653,10 +664,12 @@ def _row_mask(Xa, Xb, D):
     return mask
 
 
-def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False):
+def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False, last_rows=None):
     """res = (sum_{k=0..L} A^k X) / (L+1) with X = [Xa; Xb] (Xb may be None).  sparse_input: X is expected to be zero on
     most rows (the gradient entering a backward propagation is non-zero only on the batch's rows): a row mask of X is
-    built on the device (one pass over X) and the first layer does not fetch the zero rows — same result."""
+    built on the device (one pass over X) and the first layer does not fetch the zero rows — same result.
+    last_rows ((users, pos, neg) int64 ids into Xa / Xb / Xb, forward only): the caller reads the result at these rows only,
+    so the LAST layer computes only them; every other row of the result is undefined."""
     dev = Xa.device
     D = Xa.shape[1]
     n = Xa.shape[0] + (Xb.shape[0] if Xb is not None else 0)
@@ -670,11 +683,23 @@ def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False):
         last = k == num_layers
         Y = None if last else bufs[(k - 1) % len(bufs)]
         scale = 1.0 / (num_layers + 1) if last else 1.0
+        rows, out = None, acc
+        if last and last_rows is not None and not transposed and plan.filler_row >= 0 and _float4_rows(D):
+            # one launch turns the batch into the one-wave-per-row list (hubs -> a filler row + their hub_need flag)
+            users, pos, neg = last_rows
+            short = torch.empty((3 * users.numel(),), dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().mi_batch_row_list(users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.numel(),
+                                                     Xa.shape[0] if Xb is not None else 0, n, plan.is_hub.data_ptr(),
+                                                     plan.filler_row, short.data_ptr(), plan.hub_need.data_ptr(),
+                                                     _lib.stream_ptr(dev)), "mi_batch_row_list")
+            rows = (short, plan.long_rows, plan.hub_need)
+            out = torch.empty_like(acc)          # repeats in the list: the result must not be updated in place
         if k == 1:
             xmask = _row_mask(Xa, Xb, D) if (sparse_input and MASK_FIRST_BACKWARD_LAYER) else None
-            _spmm(plan, transposed, val, cur_a, cur_b, cur_split, Y, Xa, Xb, x_split, acc, scale, D, xmask=xmask)
+            _spmm(plan, transposed, val, cur_a, cur_b, cur_split, Y, Xa, Xb, x_split, out, scale, D, xmask=xmask, rows=rows)
         else:
-            _spmm(plan, transposed, val, cur_a, None, 0, Y, acc, None, 0, acc, scale, D)
+            _spmm(plan, transposed, val, cur_a, None, 0, Y, acc, None, 0, out, scale, D, rows=rows)
+        acc = out
         cur_a, cur_b, cur_split = Y, None, 0
     return acc
 
@@ -732,7 +757,7 @@ class LightGCNPropagateReg(torch.autograd.Function):
     here mi_rowsq_bwd adds those rows straight into the propagation's gradient."""
 
     @staticmethod
-    def forward(ctx, val, Xa, Xb, plan, num_layers: int, users, pos, neg):
+    def forward(ctx, val, Xa, Xb, plan, num_layers: int, users, pos, neg, batch_rows_only: bool = False):
         dev = _lib.require_gpu(val, Xa, Xb, users)
         if val.requires_grad:
             raise NotImplementedError("gradients w.r.t. the adjacency values are not provided")
@@ -744,7 +769,8 @@ class LightGCNPropagateReg(torch.autograd.Function):
         if pi.numel() != B or ni.numel() != B or B == 0:
             raise ValueError("reg loss: users / positives / negatives must be [B] indices")
         lib = _lib.load()
-        res = _propagate(plan, False, valc, Xac, Xbc, num_layers)
+        last_rows = (ui, pi, ni) if batch_rows_only else None
+        res = _propagate(plan, False, valc, Xac, Xbc, num_layers, last_rows=last_rows)
         ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
         reg = torch.empty(1, dtype=torch.float32, device=dev)
         _lib.check(lib.mi_rowsq_fwd(Xac.data_ptr(), ui.data_ptr(), Xbc.data_ptr(), pi.data_ptr(), Xbc.data_ptr(), ni.data_ptr(),
@@ -772,17 +798,20 @@ class LightGCNPropagateReg(torch.autograd.Function):
                                                 ni.data_ptr(), ui.numel(), D, Xac.shape[0], Xbc.shape[0], Xbc.shape[0],
                                                 g.data_ptr(), gXa.data_ptr(), gXb.data_ptr(), gXb.data_ptr(),
                                                 _lib.stream_ptr(dev)), "mi_rowsq_bwd")
-        return None, gXa, gXb, None, None, None, None, None
+        return None, gXa, gXb, None, None, None, None, None, None
 
 
-def lightgcn_propagate_reg(matrix: torch.Tensor, Xa: torch.Tensor, Xb: torch.Tensor, num_layers: int, users, pos, neg):
-    """(all_user_emb, all_item_emb, reg_loss) — see LightGCNPropagateReg."""
+def lightgcn_propagate_reg(matrix: torch.Tensor, Xa: torch.Tensor, Xb: torch.Tensor, num_layers: int, users, pos, neg,
+                           batch_rows_only: bool = False):
+    """(all_user_emb, all_item_emb, reg_loss) — see LightGCNPropagateReg.  batch_rows_only: the two tables are valid ONLY at
+    rows `users` / `pos`, `neg` (what BPR and InfoNCE over the batch read): the last propagation layer computes just those
+    rows (and the graph's hub rows) instead of all of them."""
     if matrix.layout != torch.sparse_csr:
         if matrix.layout == torch.sparse_coo:
             matrix = matrix.coalesce().to_sparse_csr()
         else:
             raise ValueError(f"Not supported matrix layout: {matrix.layout}")
-    return LightGCNPropagateReg.apply(matrix.values(), Xa, Xb, csr_plan(matrix), num_layers, users, pos, neg)
+    return LightGCNPropagateReg.apply(matrix.values(), Xa, Xb, csr_plan(matrix), num_layers, users, pos, neg, batch_rows_only)
 
 
 def lightgcn_propagate(matrix: torch.Tensor, Xa: torch.Tensor, Xb: Optional[torch.Tensor], num_layers: int):

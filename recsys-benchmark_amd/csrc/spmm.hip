@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val, Seg2 X,
     float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out, float scale,
     const int *__restrict__ short_rows, int n_short, const int *__restrict__ long_rows, int n_long,
-    const uint32_t *__restrict__ xmask) {
+    const uint32_t *__restrict__ xmask, uint8_t *__restrict__ hub_need) {
   constexpr int NPW = kWave / LPR;
   constexpr int D = LPR * 4;
   __shared__ float4 part[kHubWaves][LPR];
@@ -146,6 +146,9 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
   const int q = lane % LPR, k = lane / LPR;
   if ((int)blockIdx.x < n_long) {
     const int row = long_rows[blockIdx.x];
+    // hub_need (nullable, one byte per row): a hub row is computed only when its byte is set (mi_batch_row_list sets it for
+    // the hubs of the batch) and the byte is cleared again here: the array is all zeros between launches
+    if (hub_need && !hub_need[row]) return;
     const int lo = crow[row], hi = crow[row + 1];
     float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q, xmask);
     a = slot_sum<LPR>(a);
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
       }
       epilogue4(s, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
     }
+    if (hub_need && threadIdx.x == 0) hub_need[row] = 0;
     return;
   }
   const int nblk = gridDim.x - n_long;
@@ -307,6 +311,43 @@ int mi_spmm_csr_masked(const int32_t *crow, const int32_t *col, const float *val
                        int32_t acc_split, float *acc_out, float scale, int32_t n_rows, int32_t D,
                        const int32_t *short_rows, int32_t n_short, const int32_t *long_rows, int32_t n_long,
                        const uint32_t *xmask, void *stream) {
+  return mi_spmm_csr_sel(crow, col, val, Xa, Xb, x_split, Y, acc_in_a, acc_in_b, acc_split, acc_out, scale, n_rows, D,
+                         short_rows, n_short, long_rows, n_long, xmask, nullptr, stream);
+}
+
+// k_batch_row_list: the one-wave-per-row list of a training batch for mi_spmm_csr_sel: out[j] = row j of
+// (users | U + pos | U + neg) unless that row is a hub (is_hub byte set), whose place takes `filler` (any non-hub row:
+// computing it is harmless) and whose hub_need byte is set instead.  Rows outside [0, n_rows) take the filler too.
+__global__ __launch_bounds__(kBlock) void k_batch_row_list(const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+                                                           const int64_t *__restrict__ neg, int64_t B, int64_t U,
+                                                           int64_t n_rows, const uint8_t *__restrict__ is_hub, int filler,
+                                                           int32_t *__restrict__ out, uint8_t *__restrict__ hub_need) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= 3 * B) return;
+  const int64_t r = j < B ? users[j] : (j < 2 * B ? U + pos[j - B] : U + neg[j - 2 * B]);
+  int o = filler;
+  if ((uint64_t)r < (uint64_t)n_rows) {
+    if (is_hub[r]) hub_need[r] = 1;
+    else o = (int)r;
+  }
+  out[j] = o;
+}
+
+int mi_batch_row_list(const int64_t *users, const int64_t *pos, const int64_t *neg, int64_t B, int64_t U, int64_t n_rows,
+                      const uint8_t *is_hub, int32_t filler, int32_t *out, uint8_t *hub_need, void *stream) {
+  if (B < 0 || U < 0 || n_rows <= 0 || filler < 0 || filler >= n_rows) return MI_ERR_INVALID_ARG;
+  if (B == 0) return MI_OK;
+  if (!users || !pos || !neg || !is_hub || !out || !hub_need) return MI_ERR_INVALID_ARG;
+  MI_LAUNCH("batch_row_list", k_batch_row_list, (int)((3 * B + kBlock - 1) / kBlock), kBlock, stream, users, pos, neg, B, U, n_rows,
+            is_hub, filler, out, hub_need);
+  return launch_status();
+}
+
+int mi_spmm_csr_sel(const int32_t *crow, const int32_t *col, const float *val, const float *Xa,
+                    const float *Xb, int32_t x_split, float *Y, const float *acc_in_a, const float *acc_in_b,
+                    int32_t acc_split, float *acc_out, float scale, int32_t n_rows, int32_t D,
+                    const int32_t *short_rows, int32_t n_short, const int32_t *long_rows, int32_t n_long,
+                    const uint32_t *xmask, uint8_t *hub_need, void *stream) {
   if (n_rows < 0 || D <= 0 || n_short < 0 || n_long < 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
   if (n_rows == 0) return MI_OK;
   if (!crow || !Xa || (!Y && !acc_out)) return MI_ERR_INVALID_ARG;
@@ -330,7 +371,8 @@ int mi_spmm_csr_masked(const int32_t *crow, const int32_t *col, const float *val
       int sb = (n_short + kHubWaves - 1) / kHubWaves;                                                   \
       if (sb > 1024) sb = 1024;                                                                         \
       MI_LAUNCH("spmm_csr", (k_spmm_planned<LPR>), n_long + sb, kHubWaves * kWave, stream, crow, col,   \
-                val, X, Y, A, has_acc, acc_out, scale, short_rows, n_short, long_rows, n_long, xmask);  \
+                val, X, Y, A, has_acc, acc_out, scale, short_rows, n_short, long_rows, n_long, xmask,   \
+                hub_need);                                                                              \
     }                                                                                                   \
   } while (0)
     switch (D / 4) {

@@ -85,14 +85,20 @@ class LightGCN(_Propagating):
         total = _squared_l2(users_t(users)) + _squared_l2(items_t(pos_items)) + _squared_l2(items_t(neg_items))
         return total / (2 * len(users))
 
-    def forward_with_reg_loss(self, matrix, users, pos_items, neg_items):
+    def forward_with_reg_loss(self, matrix, users, pos_items, neg_items, batch_rows_only: bool = False):
         """(user_emb, item_emb, reg_loss) = (*self(matrix), self.get_reg_loss(users, pos_items, neg_items)) — the two calls
         of the reference's `_train_step` (src/trainer/lightgcn.py:389-402) as one autograd node when the tables are plain,
         so that the regulariser's 3 B gradient rows are added into the propagation's gradient instead of travelling as two
-        zero-filled dense tensors (an extension: the two separate calls stay valid and give the same numbers)."""
+        zero-filled dense tensors (an extension: the two separate calls stay valid and give the same numbers).
+
+        batch_rows_only=True: the caller promises to read user_emb only at `users` and item_emb only at `pos_items` /
+        `neg_items` (the BPR and InfoNCE terms of the training step do exactly that): the last propagation layer then
+        computes only those rows — every other row of the two returned tables is UNDEFINED.  Same values at the rows
+        that are read, same gradients."""
         if self._plain_tables() and users.dim() == 1 and self.num_layers > 0:
             return _kernels.lightgcn_propagate_reg(self.sparse_dropout(matrix), self.user_emb_table.get_weight(),
-                                                   self.item_emb_table.get_weight(), self.num_layers, users, pos_items, neg_items)
+                                                   self.item_emb_table.get_weight(), self.num_layers, users, pos_items, neg_items,
+                                                   batch_rows_only=batch_rows_only)
         user_emb, item_emb = self(matrix)
         return user_emb, item_emb, self.get_reg_loss(users, pos_items, neg_items)
 

@@ -303,8 +303,10 @@ class GraphedCFTrainStep:
 
     def _body(self, users, pos_items, neg_items):
         fused = self.weight_decay > 0 and hasattr(self.model, "forward_with_reg_loss")
-        if fused:      # propagation + regulariser as one node: the regulariser's gradient rows join the propagation's
-            all_user_emb, all_item_emb, reg_loss = self.model.forward_with_reg_loss(self.adj, users, pos_items, neg_items)
+        if fused:      # propagation + regulariser as one node: the regulariser's gradient rows join the propagation's; every
+            # term below reads the propagated tables at the batch's rows only, so the last layer computes only those
+            all_user_emb, all_item_emb, reg_loss = self.model.forward_with_reg_loss(self.adj, users, pos_items, neg_items,
+                                                                                    batch_rows_only=True)
         else:
             all_user_emb, all_item_emb = self.model(self.adj)
         rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items)

@@ -236,3 +236,37 @@ def test_propagation_and_regulariser_as_one_node_equal_the_two_calls():
         assert torch.equal(a, b), what
     assert_close(grads[1][3], grads[0][3], 1e-5, 1e-7, "user table gradient")
     assert_close(grads[1][4], grads[0][4], 1e-5, 1e-7, "item table gradient")
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_last_layer_restricted_to_the_batch_rows_gives_the_same_rows_and_gradients(L):
+    """forward_with_reg_loss(..., batch_rows_only=True): the last propagation layer computes only the rows the step reads
+    (users / positives / negatives, hubs among them, repeats among them).  Those rows must be bit-identical to the full
+    propagation's, and the table gradients of BPR + reg bit-identical too (the backward is the same code on the same
+    gradient, which is zero off the batch's rows either way)."""
+    from recsys_benchmark_amd.losses import bpr_loss_rows
+
+    U, I, D, B = 1500, 500, 64, 128
+    adj = _random_graph(U, I, 20000, seed=21).to(DEV)               # has hub rows (> 256 nnz)
+    plan = _kernels.csr_plan(adj)
+    assert plan.long_rows.numel() > 0
+    hubs_items = plan.long_rows[plan.long_rows >= U].to(torch.int64) - U
+    gen = torch.Generator().manual_seed(8)
+    users = torch.randint(0, U, (B,), generator=gen).to(DEV)
+    pos = torch.randint(0, I, (B,), generator=gen).to(DEV)
+    neg = torch.randint(0, 30, (B,), generator=gen).to(DEV)          # many repeats
+    if hubs_items.numel():
+        pos[:2] = hubs_items[:1]                                        # a hub row in the batch, twice
+    outs = []
+    for only in (False, True):
+        torch.manual_seed(0)
+        model = LightGCN(U, I, num_layers=L, hidden_size=D).to(DEV)
+        au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg, batch_rows_only=only)
+        (bpr_loss_rows(au, ai, users, pos, neg) + 0.05 * reg).backward()
+        outs.append((au.detach()[users], ai.detach()[pos], ai.detach()[neg], reg.detach(),
+                     model.user_emb_table.get_weight().grad.clone(), model.item_emb_table.get_weight().grad.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("user rows", "positive rows", "negative rows", "reg", "user table grad", "item table grad")):
+        if "grad" in what:
+            assert_close(b, a, 1e-6, 1e-8, what)      # (BPR / reg rows are scattered with float atomics: order may differ)
+        else:
+            assert torch.equal(a, b), what
