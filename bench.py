@@ -573,6 +573,7 @@ def bench_c5(args, real_stdout):
     from recsys_benchmark_amd.lightgcn import LightGCN
     from recsys_benchmark_amd.losses import bpr_loss_rows, unit_scalar
     from recsys_benchmark_amd.profiling import KernelTimer
+    from recsys_benchmark_amd._kernels import spmm as _kernels_spmm
 
     U, I, D, nl, B = 31668, 38048, 64, 3, 2048
     adj_cpu = yelp_graph(U, I)
@@ -590,8 +591,9 @@ def bench_c5(args, real_stdout):
         if args.separate_reg:      # the reference's two calls: model(adj), then model.get_reg_loss(...)
             au, ai = model(adj)
             reg = model.get_reg_loss(users, pos, neg)
-        else:                      # what trainer.GraphedCFTrainStep runs: both as one autograd node
-            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg, batch_rows_only=True)
+        else:                      # what trainer.GraphedCFTrainStep runs: both as one autograd node, the last layer at the
+            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg,          # rows the losses read
+                                                      batch_rows_only=not args.full_last_layer)
         (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * reg).backward(one)
 
     elapsed = time_graphed(step, args, world, dev)
@@ -602,12 +604,21 @@ def bench_c5(args, real_stdout):
             step()
             L.load().mi_prof_empty_launch(256, 256, L.stream_ptr(dev))
         torch.cuda.synchronize()
+    # roofline leg: FULL layers only (in the step one backward layer skips the zero rows of its operand and — unless
+    # --full-last-layer — the last forward layer computes the batch's rows only: both move fewer bytes than a layer's
+    # algorithmic count), each the product of the whole adjacency with a dense [N, D] operand
+    Xfull = torch.randn(N, D, device=dev)
+    with torch.no_grad(), KernelTimer(capacity=4 * n_prof + 16) as kt_full:
+        for _ in range(n_prof):
+            Xfull = _kernels_spmm(adj, Xfull)
+        torch.cuda.synchronize()
     if rank != 0:
         return
     kernels = kernel_table(kt)
+    full = kernel_table(kt_full)
     alg = 8 * nnz + 4 * (N + 1) + 8 * N * D
-    kname = "spmm_tiled" if "spmm_tiled" in kernels else "spmm_csr"
-    k = kernels.get(kname)
+    kname = "spmm_tiled" if "spmm_tiled" in full else "spmm_csr"
+    k = full.get(kname)
     roofline = None
     if k:
         ach = alg / (k["avg_us"] * 1e-6) / 1e9
@@ -615,15 +626,20 @@ def bench_c5(args, real_stdout):
         traffic = json.load(open(tpath)).get(kname) if os.path.exists(tpath) else None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_us": k["avg_us"], "alg_bytes": alg,
-                    "launches_per_step": k["launches"] / n_prof, "nnz": nnz,
+                    "what": "full layers (A x dense [N, D]) launched back to back outside the step; the step's own six launches "
+                            "are in `kernels` (one skips zero operand rows, one computes the batch's rows only)",
+                    "launches_per_step": kernels.get(kname, {}).get("launches", 0) / n_prof, "nnz": nnz,
                     "gather_bytes_without_reuse": nnz * (8 + 4 * D), "G_nnz_per_s": round(nnz / (k["avg_us"] * 1e-6) / 1e9, 2),
                     "floor_us": kernels.get("empty", {}).get("avg_us")}
-    out = {"metric": "BPR triples/sec fwd+bwd, LightGCN Yelp2018-shaped 3-layer (full propagation every step); HBM GB/s vs roofline",
+    out = {"metric": "BPR triples/sec fwd+bwd, LightGCN Yelp2018-shaped 3-layer (propagation over the whole graph every step); HBM GB/s vs roofline",
            "value": round(B * world * args.steps / elapsed, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay",
            "config": {"workload": f"C5 LightGCN Yelp2018-shaped: U={U}, I={I}, N={N}, nnz(A)={nnz}, D={D}, L={nl}, {B} BPR triples/step "
-                                  "+ L2 reg, fwd+bwd (no optimizer)",
+                                  "+ L2 reg, fwd+bwd (no optimizer); " +
+                                  ("the reference's two calls model(adj) + get_reg_loss()" if args.separate_reg else
+                                   "propagation + regulariser as one autograd node" +
+                                   ("" if args.full_last_layer else ", last layer at the rows the losses read (the batch's)")),
                       "global_batch": B * world, "parallelism": "single" if world == 1 else f"{world} independent replicas (the path does not shard: SURVEY.md §8e)"},
            "roofline": roofline, "kernels": kernels}
     if not args.no_cpu_baseline and world == 1:
@@ -715,6 +731,8 @@ def main():
                     "reference-faithful variant with 13 fields of 50 buckets prepended (src/dataset/criteo/utils.py:8-9)")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager pass that times every kernel by dispatch events "
                     "(so that a profiler run sees in-graph launches only)")
+    ap.add_argument("--full-last-layer", action="store_true", help="c5: compute every row of the last propagation layer (the "
+                    "default computes the rows the losses read: the batch's)")
     ap.add_argument("--separate-reg", action="store_true", help="c5: call model(adj) and model.get_reg_loss() separately (the "
                     "reference's call shape) instead of LightGCN.forward_with_reg_loss (what the mirrored trainer runs)")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the roofline leg (graphs holding only gather+FM kernels), so "
