@@ -668,8 +668,8 @@ def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False, la
     """res = (sum_{k=0..L} A^k X) / (L+1) with X = [Xa; Xb] (Xb may be None).  sparse_input: X is expected to be zero on
     most rows (the gradient entering a backward propagation is non-zero only on the batch's rows): a row mask of X is
     built on the device (one pass over X) and the first layer does not fetch the zero rows — same result.
-    last_rows ((users, pos, neg) int64 ids into Xa / Xb / Xb, forward only): the caller reads the result at these rows only,
-    so the LAST layer computes only them; every other row of the result is undefined."""
+    last_rows ((users, pos, neg, item_base): int64 ids, row = user id / item_base + item id; forward only): the caller reads
+    the result at these rows only, so the LAST layer computes only them; every other row of the result is undefined."""
     dev = Xa.device
     D = Xa.shape[1]
     n = Xa.shape[0] + (Xb.shape[0] if Xb is not None else 0)
@@ -686,10 +686,10 @@ def _propagate(plan, transposed, val, Xa, Xb, num_layers, sparse_input=False, la
         rows, out = None, acc
         if last and last_rows is not None and not transposed and plan.filler_row >= 0 and _float4_rows(D):
             # one launch turns the batch into the one-wave-per-row list (hubs -> a filler row + their hub_need flag)
-            users, pos, neg = last_rows
+            users, pos, neg, item_base = last_rows
             short = torch.empty((3 * users.numel(),), dtype=torch.int32, device=dev)
             _lib.check(_lib.load().mi_batch_row_list(users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.numel(),
-                                                     Xa.shape[0] if Xb is not None else 0, n, plan.is_hub.data_ptr(),
+                                                     item_base, n, plan.is_hub.data_ptr(),
                                                      plan.filler_row, short.data_ptr(), plan.hub_need.data_ptr(),
                                                      _lib.stream_ptr(dev)), "mi_batch_row_list")
             rows = (short, plan.long_rows, plan.hub_need)
@@ -750,68 +750,91 @@ class LightGCNPropagate(torch.autograd.Function):
 
 
 class LightGCNPropagateReg(torch.autograd.Function):
-    """LightGCNPropagate of two plain tables AND LightGCN.get_reg_loss over a batch's rows of those tables
-    (src/models/lightgcn.py:79-100) as one node: (res_a, res_b, reg).  The point is the backward: the regulariser's
-    gradient touches 3 B rows, and as a node of its own it reaches the tables as two zero-filled [N, D] tensors that
+    """LightGCNPropagate of plain tables AND get_reg_loss over a batch's rows of those tables
+    (src/models/lightgcn.py:79-100,166-173) as one node: (res_a, res_b, reg) for two tables, (res, reg) for one table
+    (Xb None: SingleLightGCN, items follow the `item_base` users).  The point is the backward: the regulariser's
+    gradient touches 3 B rows, and as a node of its own it reaches the tables as zero-filled [N, D] tensors that
     autograd then adds to the propagation's gradients (two fills + two adds of 8 - 10 MB each per step at Yelp2018 size);
     here mi_rowsq_bwd adds those rows straight into the propagation's gradient."""
 
     @staticmethod
-    def forward(ctx, val, Xa, Xb, plan, num_layers: int, users, pos, neg, batch_rows_only: bool = False):
+    def forward(ctx, val, Xa, Xb, plan, num_layers: int, users, pos, neg, batch_rows_only: bool = False, item_base: int = 0):
         dev = _lib.require_gpu(val, Xa, Xb, users)
         if val.requires_grad:
             raise NotImplementedError("gradients w.r.t. the adjacency values are not provided")
-        valc, Xac, Xbc = _f32c(val), _f32c(Xa), _f32c(Xb)
-        if Xac.shape[0] + Xbc.shape[0] != plan.shape[0] or plan.shape[0] != plan.shape[1]:
-            raise ValueError(f"adjacency is {plan.shape} but the embedding tables have {Xac.shape[0] + Xbc.shape[0]} rows")
+        valc, Xac = _f32c(val), _f32c(Xa)
+        Xbc = None if Xb is None else _f32c(Xb)
+        n = Xac.shape[0] + (Xbc.shape[0] if Xbc is not None else 0)
+        if n != plan.shape[0] or plan.shape[0] != plan.shape[1]:
+            raise ValueError(f"adjacency is {plan.shape} but the embedding tables have {n} rows")
         ui, pi, ni = (_i64c(t).view(-1) for t in (users, pos, neg))
         B, D = ui.numel(), Xac.shape[1]
         if pi.numel() != B or ni.numel() != B or B == 0:
             raise ValueError("reg loss: users / positives / negatives must be [B] indices")
         lib = _lib.load()
-        last_rows = (ui, pi, ni) if batch_rows_only else None
+        if Xbc is None:              # one table: the item rows start at item_base
+            item_tab, pr, nr = Xac, pi + item_base, ni + item_base
+        else:
+            item_tab, pr, nr, item_base = Xbc, pi, ni, Xac.shape[0]
+        last_rows = (ui, pi, ni, item_base) if batch_rows_only else None
         res = _propagate(plan, False, valc, Xac, Xbc, num_layers, last_rows=last_rows)
         ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
         reg = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_rowsq_fwd(Xac.data_ptr(), ui.data_ptr(), Xbc.data_ptr(), pi.data_ptr(), Xbc.data_ptr(), ni.data_ptr(),
-                                    B, D, Xac.shape[0], Xbc.shape[0], Xbc.shape[0], _lib.err_word(dev).data_ptr(),
-                                    ws.data_ptr(), reg.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
-        ctx.plan, ctx.num_layers, ctx.split = plan, num_layers, Xac.shape[0]
-        ctx.save_for_backward(valc, Xac, Xbc, ui, pi, ni)
+        _lib.check(lib.mi_rowsq_fwd(Xac.data_ptr(), ui.data_ptr(), item_tab.data_ptr(), pr.data_ptr(), item_tab.data_ptr(),
+                                    nr.data_ptr(), B, D, Xac.shape[0], item_tab.shape[0], item_tab.shape[0],
+                                    _lib.err_word(dev).data_ptr(), ws.data_ptr(), reg.data_ptr(), _lib.stream_ptr(dev)),
+                   "mi_rowsq_fwd")
+        ctx.plan, ctx.num_layers = plan, num_layers
+        ctx.split = None if Xbc is None else Xac.shape[0]
+        ctx.save_for_backward(valc, Xac, item_tab, ui, pr, nr)
+        if ctx.split is None:
+            return res, reg.view(())
         return res[: ctx.split], res[ctx.split:], reg.view(())
 
     @staticmethod
-    def backward(ctx, ga, gb, greg):
-        valc, Xac, Xbc, ui, pi, ni = ctx.saved_tensors
+    def backward(ctx, *gs):
+        valc, Xac, item_tab, ui, pr, nr = ctx.saved_tensors
         plan, split = ctx.plan, ctx.split
         dev, D = valc.device, Xac.shape[1]
-        if ga is None and gb is None:
-            gX = torch.zeros((plan.shape[0], D), dtype=torch.float32, device=dev)
+        greg = gs[-1]
+        val_t = plan.transposed_values(valc)
+        if split is None:
+            g = gs[0]
+            gX = (_propagate(plan, True, val_t, _f32c(g), None, ctx.num_layers, sparse_input=True) if g is not None
+                  else torch.zeros((plan.shape[0], D), dtype=torch.float32, device=dev))
+            gXa = gXb = gX
         else:
-            ga = _f32c(ga) if ga is not None else torch.zeros((split, D), dtype=torch.float32, device=dev)
-            gb = _f32c(gb) if gb is not None else torch.zeros((plan.shape[0] - split, D), dtype=torch.float32, device=dev)
-            gX = _propagate(plan, True, plan.transposed_values(valc), ga, gb, ctx.num_layers, sparse_input=True)
-        gXa, gXb = gX[:split], gX[split:]
+            ga, gb = gs[0], gs[1]
+            if ga is None and gb is None:
+                gX = torch.zeros((plan.shape[0], D), dtype=torch.float32, device=dev)
+            else:
+                ga = _f32c(ga) if ga is not None else torch.zeros((split, D), dtype=torch.float32, device=dev)
+                gb = _f32c(gb) if gb is not None else torch.zeros((plan.shape[0] - split, D), dtype=torch.float32, device=dev)
+                gX = _propagate(plan, True, val_t, ga, gb, ctx.num_layers, sparse_input=True)
+            gXa, gXb = gX[:split], gX[split:]
         if greg is not None:
             g = _f32c(greg).view(1)
-            _lib.check(_lib.load().mi_rowsq_bwd(Xac.data_ptr(), ui.data_ptr(), Xbc.data_ptr(), pi.data_ptr(), Xbc.data_ptr(),
-                                                ni.data_ptr(), ui.numel(), D, Xac.shape[0], Xbc.shape[0], Xbc.shape[0],
-                                                g.data_ptr(), gXa.data_ptr(), gXb.data_ptr(), gXb.data_ptr(),
-                                                _lib.stream_ptr(dev)), "mi_rowsq_bwd")
-        return None, gXa, gXb, None, None, None, None, None, None
+            _lib.check(_lib.load().mi_rowsq_bwd(Xac.data_ptr(), ui.data_ptr(), item_tab.data_ptr(), pr.data_ptr(),
+                                                item_tab.data_ptr(), nr.data_ptr(), ui.numel(), D, Xac.shape[0],
+                                                item_tab.shape[0], item_tab.shape[0], g.data_ptr(), gXa.data_ptr(),
+                                                gXb.data_ptr(), gXb.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_bwd")
+        if split is None:
+            return None, gX, None, None, None, None, None, None, None, None
+        return None, gXa, gXb, None, None, None, None, None, None, None
 
 
-def lightgcn_propagate_reg(matrix: torch.Tensor, Xa: torch.Tensor, Xb: torch.Tensor, num_layers: int, users, pos, neg,
-                           batch_rows_only: bool = False):
-    """(all_user_emb, all_item_emb, reg_loss) — see LightGCNPropagateReg.  batch_rows_only: the two tables are valid ONLY at
-    rows `users` / `pos`, `neg` (what BPR and InfoNCE over the batch read): the last propagation layer computes just those
-    rows (and the graph's hub rows) instead of all of them."""
+def lightgcn_propagate_reg(matrix: torch.Tensor, Xa: torch.Tensor, Xb: Optional[torch.Tensor], num_layers: int, users, pos, neg,
+                           batch_rows_only: bool = False, item_base: int = 0):
+    """(all_user_emb, all_item_emb, reg_loss), or (all_emb, reg_loss) for ONE table (Xb None; item row = item_base + item id)
+    — see LightGCNPropagateReg.  batch_rows_only: the result is valid ONLY at rows `users` / `pos`, `neg` (what BPR and
+    InfoNCE over the batch read): the last propagation layer computes just those rows instead of all of them."""
     if matrix.layout != torch.sparse_csr:
         if matrix.layout == torch.sparse_coo:
             matrix = matrix.coalesce().to_sparse_csr()
         else:
             raise ValueError(f"Not supported matrix layout: {matrix.layout}")
-    return LightGCNPropagateReg.apply(matrix.values(), Xa, Xb, csr_plan(matrix), num_layers, users, pos, neg, batch_rows_only)
+    return LightGCNPropagateReg.apply(matrix.values(), Xa, Xb, csr_plan(matrix), num_layers, users, pos, neg, batch_rows_only,
+                                      int(item_base))
 
 
 def lightgcn_propagate(matrix: torch.Tensor, Xa: torch.Tensor, Xb: Optional[torch.Tensor], num_layers: int):

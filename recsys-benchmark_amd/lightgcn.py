@@ -121,6 +121,19 @@ class SingleLightGCN(_Propagating):
         batch_rows = torch.cat([users, pos_items + item_base, neg_items + item_base])
         return _squared_l2(self.emb_table(batch_rows)) / (2 * len(users))
 
+    def forward_with_reg_loss(self, matrix, users, pos_items, neg_items, batch_rows_only: bool = False):
+        """LightGCN.forward_with_reg_loss for the one-table model: (user_emb, item_emb, reg_loss) with propagation and
+        regulariser as one autograd node when the table is plain."""
+        t = self.emb_table
+        if type(t) is VanillaEmbedding and t._mode is None and not t.sparse_grad and users.dim() == 1 and self.num_layers > 0:
+            both, reg = _kernels.lightgcn_propagate_reg(self.sparse_dropout(matrix), t.get_weight(), None, self.num_layers,
+                                                        users, pos_items, neg_items, batch_rows_only=batch_rows_only,
+                                                        item_base=self._num_user)
+            user_emb, item_emb = torch.split(both, (self._num_user, self._num_item))
+            return user_emb, item_emb, reg
+        user_emb, item_emb = self(matrix)
+        return user_emb, item_emb, self.get_reg_loss(users, pos_items, neg_items)
+
     def get_embs(self):
         return [("user-item", self.emb_table)]
 

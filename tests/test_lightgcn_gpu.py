@@ -308,3 +308,32 @@ def test_fused_step_paths_with_sparse_dropout_reuse_the_plan_across_draws():
         assert_close(b[3], a[3], 1e-5, 1e-7, f"draw {d}: item table gradient")
     for p in _kernels._plans.values():
         assert not bool(p.hub_need.any()), "hub flags are cleared by the launch that consumed them"
+
+
+@pytest.mark.parametrize("rows_only", [False, True])
+def test_single_table_model_fused_step_equals_the_two_calls(rows_only):
+    """SingleLightGCN.forward_with_reg_loss (one table, items after the users) == (model(adj), model.get_reg_loss(...)):
+    the rows the losses read bit for bit, the table gradient within float-atomic ordering."""
+    from recsys_benchmark_amd.losses import bpr_loss_rows
+
+    U, I, D, L, B = 700, 300, 32, 2, 64
+    adj = _random_graph(U, I, 9000, seed=41).to(DEV)
+    gen = torch.Generator().manual_seed(6)
+    users = torch.randint(0, U, (B,), generator=gen).to(DEV)
+    pos = torch.randint(0, I, (B,), generator=gen).to(DEV)
+    neg = torch.randint(0, 25, (B,), generator=gen).to(DEV)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = SingleLightGCN(U, I, num_layers=L, hidden_size=D).to(DEV)
+        if fused:
+            au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg, batch_rows_only=rows_only)
+        else:
+            au, ai = model(adj)
+            reg = model.get_reg_loss(users, pos, neg)
+        (bpr_loss_rows(au, ai, users, pos, neg) + 0.05 * reg).backward()
+        outs.append((au.detach()[users], ai.detach()[pos], ai.detach()[neg], reg.detach(), model.emb_table.get_weight().grad.clone()))
+    for a, b, what in zip(outs[0][:3], outs[1][:3], ("user rows", "positive rows", "negative rows")):
+        assert torch.equal(a, b), what
+    assert_close(outs[1][3], outs[0][3], 1e-5, 1e-7, "reg loss (norm^2 vs sum of squares)")
+    assert_close(outs[1][4], outs[0][4], 1e-5, 1e-7, "table gradient")
