@@ -616,6 +616,9 @@ MI_API int mi_scatter_axpy_rows(const int64_t *idx, const float *g, float alpha,
 MI_API int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                         const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                         int64_t nN, int32_t *err, float *workspace, float *out, void *stream);
+MI_API int mi_rowsq_fwd_armed(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                              const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                              int64_t nN, int32_t *err, float *workspace, float *out, void *stream);
 MI_API int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                         const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                         int64_t nN, const float *g, float *dU, float *dP, float *dN, void *stream);
@@ -623,6 +626,11 @@ MI_API int64_t mi_bpr_workspace_elems(int64_t B);
 MI_API int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                       const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                       int64_t nN, int32_t *err, float *sig, float *workspace, float *loss, void *stream);
+/* _armed: the same launch without the memset node that zeroes the arrival ticket — the caller promises the last word
+ * of `workspace` is zero on entry; the kernel leaves it zero, so a workspace zeroed once serves every later call. */
+MI_API int mi_bpr_fwd_armed(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
+                            const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
+                            int64_t nN, int32_t *err, float *sig, float *workspace, float *loss, void *stream);
 MI_API int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                       const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                       int64_t nN, const float *sig, const float *g, float *dU, float *dP, float *dN,

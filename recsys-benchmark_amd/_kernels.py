@@ -778,9 +778,11 @@ class LightGCNPropagateReg(torch.autograd.Function):
             item_tab, pr, nr, item_base = Xbc, pi, ni, Xac.shape[0]
         last_rows = (ui, pi, ni, item_base) if batch_rows_only else None
         res = _propagate(plan, False, valc, Xac, Xbc, num_layers, last_rows=last_rows)
-        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        from .losses import _ticket_workspace
+
+        ws, armed = _ticket_workspace("rowsq", dev, lib.mi_bpr_workspace_elems(B))
         reg = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_rowsq_fwd(Xac.data_ptr(), ui.data_ptr(), item_tab.data_ptr(), pr.data_ptr(), item_tab.data_ptr(),
+        _lib.check((lib.mi_rowsq_fwd_armed if armed else lib.mi_rowsq_fwd)(Xac.data_ptr(), ui.data_ptr(), item_tab.data_ptr(), pr.data_ptr(), item_tab.data_ptr(),
                                     nr.data_ptr(), B, D, Xac.shape[0], item_tab.shape[0], item_tab.shape[0],
                                     _lib.err_word(dev).data_ptr(), ws.data_ptr(), reg.data_ptr(), _lib.stream_ptr(dev)),
                    "mi_rowsq_fwd")

@@ -239,10 +239,26 @@ __global__ __launch_bounds__(1024) void k_bce_logits_fwd(const float *__restrict
   __shared__ float part[16];
   float s = 0.f;
   const float sc = 1.f / (float)n;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const float xv = x[i], yv = y[i];
-    s += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
-    if (dx_unit) dx_unit[i] = sc * (1.f / (1.f + expf(-xv)) - yv);
+  // four elements per thread and trip with every load issued before the first store: dx_unit may alias x or y as far as
+  // the compiler knows, so a load after a store waits for it — one element per trip was four dependent round trips at
+  // B = 4096 (7.2 us for a kernel that reads 32 KB)
+  constexpr int U = 4;
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)U * blockDim.x) {
+    float xv[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      xv[u] = i < n ? x[i] : 0.f;
+      yv[u] = i < n ? y[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < n) {
+        s += fmaxf(xv[u], 0.f) - xv[u] * yv[u] + log1pf(expf(-fabsf(xv[u])));
+        if (dx_unit) dx_unit[i] = sc * (1.f / (1.f + expf(-xv[u])) - yv[u]);
+      }
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;

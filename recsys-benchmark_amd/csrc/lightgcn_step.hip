@@ -331,7 +331,7 @@ int64_t mi_bpr_workspace_elems(int64_t B) {
   return grid_for_waves(B) + 1;   // per-block partial sums + the ticket word
 }
 
-int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+static int bpr_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
                const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
                float *sig, float *workspace, float *loss, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
@@ -340,11 +340,25 @@ int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t 
   if (!U || !P || !Nn || !sig || !workspace || !loss) return MI_ERR_INVALID_ARG;
   const int grid = grid_for_waves(B);
   // workspace[grid] is the ticket: zeroed here once per call (captured as a memset node in a graph)
-  if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+  if (zero_ticket && hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
   MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace,
             reinterpret_cast<unsigned *>(workspace + grid), loss);
   return launch_status();
+}
+
+int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+               const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+               float *sig, float *workspace, float *loss, void *stream) {
+  return bpr_fwd_impl(true, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, sig, workspace, loss, stream);
+}
+
+// the same without the memset node: the caller promises that the ticket word (workspace[mi_bpr_workspace_elems(B) - 1])
+// is zero on entry — the kernel leaves it zero, so a workspace zeroed ONCE and kept serves every later call
+int mi_bpr_fwd_armed(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+               const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+               float *sig, float *workspace, float *loss, void *stream) {
+  return bpr_fwd_impl(false, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, sig, workspace, loss, stream);
 }
 
 int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
@@ -359,18 +373,30 @@ int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t 
   return launch_status();
 }
 
-int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+static int rowsq_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
                  const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
                  float *workspace, float *out, void *stream) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
   const RowBounds nb{nU, nP, nN, err};
   if (!U || !P || !Nn || !ui || !pi || !ni || !workspace || !out) return MI_ERR_INVALID_ARG;
   const int grid = grid_for_waves(B);
-  if (hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
+  if (zero_ticket && hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
   MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, workspace,
             reinterpret_cast<unsigned *>(workspace + grid), out);
   return launch_status();
+}
+
+int mi_rowsq_fwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                 const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+                 float *workspace, float *out, void *stream) {
+  return rowsq_fwd_impl(true, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, workspace, out, stream);
+}
+
+int mi_rowsq_fwd_armed(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                 const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+                 float *workspace, float *out, void *stream) {      // see mi_bpr_fwd_armed
+  return rowsq_fwd_impl(false, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, workspace, out, stream);
 }
 
 int mi_rowsq_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,

@@ -58,6 +58,31 @@ class BCEWithLogitsLoss(nn.Module):
         return _BCEFn.apply(logits, target.float())
 
 
+_workspaces = {}
+
+
+def _armed_workspace(kind: str, dev, elems: int) -> torch.Tensor:
+    """A per-(kernel, device, size) workspace whose arrival ticket (the last word) is zero: zeroed here once; the kernels
+    that use it leave the ticket zero, so the launch needs no memset node (mi_*_fwd_armed).  Launches that share one sit
+    on one stream, one after the other."""
+    key = (kind, str(dev), int(elems))
+    ws = _workspaces.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None          # memory allocated inside a capture belongs to that graph's pool: not a thing to keep
+        ws = _workspaces[key] = torch.zeros(int(elems), dtype=torch.float32, device=dev)
+    return ws
+
+
+def _ticket_workspace(kind: str, dev, elems: int):
+    """(workspace, armed): the kept, pre-zeroed workspace and True, or a fresh one and False (the launch then zeroes the
+    ticket with a memset node of its own)."""
+    ws = _armed_workspace(kind, dev, elems)
+    if ws is not None:
+        return ws, True
+    return torch.empty(int(elems), dtype=torch.float32, device=dev), False
+
+
 class _BPRFn(torch.autograd.Function):
     """-logsigmoid(u.p - u.n).mean() with u = U[ui], p = P[pi], n = Nn[ni] (None index = row b)."""
 
@@ -75,9 +100,9 @@ class _BPRFn(torch.autograd.Function):
         if B == 0:
             raise ValueError("bpr_loss of an empty batch")
         sig = torch.empty(B, dtype=torch.float32, device=dev)
-        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        ws, armed = _ticket_workspace("bpr", dev, lib.mi_bpr_workspace_elems(B))
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_bpr_fwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
+        _lib.check((lib.mi_bpr_fwd_armed if armed else lib.mi_bpr_fwd)(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
                                   _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
                                   _lib.err_word(dev).data_ptr(), sig.data_ptr(), ws.data_ptr(), loss.data_ptr(),
                                   _lib.stream_ptr(dev)), "mi_bpr_fwd")
@@ -138,9 +163,9 @@ class _RowSqFn(torch.autograd.Function):
         B, D = ui.numel(), U.shape[1]
         if pi.numel() != B or ni.numel() != B or P.shape[1] != D or Nn.shape[1] != D or B == 0:
             raise ValueError("reg loss: users / positives / negatives must be [B] indices into [*, D] tables")
-        ws = torch.empty(int(lib.mi_bpr_workspace_elems(B)), dtype=torch.float32, device=dev)
+        ws, armed = _ticket_workspace("rowsq", dev, lib.mi_bpr_workspace_elems(B))
         out = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_rowsq_fwd(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(), ni.data_ptr(),
+        _lib.check((lib.mi_rowsq_fwd_armed if armed else lib.mi_rowsq_fwd)(U.data_ptr(), ui.data_ptr(), P.data_ptr(), pi.data_ptr(), Nn.data_ptr(), ni.data_ptr(),
                                     B, D, U.shape[0], P.shape[0], Nn.shape[0], _lib.err_word(dev).data_ptr(),
                                     ws.data_ptr(), out.data_ptr(), _lib.stream_ptr(dev)), "mi_rowsq_fwd")
         ctx.save_for_backward(U, P, Nn, ui, pi, ni)
