@@ -239,9 +239,8 @@ __global__ __launch_bounds__(1024) void k_bce_logits_fwd(const float *__restrict
   __shared__ float part[16];
   float s = 0.f;
   const float sc = 1.f / (float)n;
-  // four elements per thread and trip with every load issued before the first store: dx_unit may alias x or y as far as
-  // the compiler knows, so a load after a store waits for it — one element per trip was four dependent round trips at
-  // B = 4096 (7.2 us for a kernel that reads 32 KB)
+  // four elements per thread and trip, all eight loads issued before the first use: hipcc does not pipeline the
+  // one-element loop, which at B = 4096 was four dependent round trips (7.2 us for a kernel that reads 32 KB)
   constexpr int U = 4;
   for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)U * blockDim.x) {
     float xv[U], yv[U];
