@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""QR backward (mi_dual_gather_bwd) at the C3 shape: ids from the Avazu field sizes vs ids uniform over the whole table.
+Nine of Avazu's 22 fields have <= 31 values: 4096 lookups each land on <= 16 rows of the quotient table."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recsys_benchmark_amd import _kernels
+
+AVAZU = [241, 8, 8, 3697, 4614, 25, 5481, 329, 31, 381763, 1611748, 6793, 6, 5, 2509, 9, 10, 432, 5, 68, 169, 61]
+dev, B, D = "cuda", 4096, 16
+N = sum(AVAZU)
+gen = torch.Generator().manual_seed(0)
+off = torch.tensor([0] + AVAZU[:-1]).cumsum(0)
+ids_f = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in AVAZU], 1) + off
+ids_u = torch.randint(0, N, (B, len(AVAZU)), generator=gen)
+big = [d for d in AVAZU if d > 64]
+cases = {"avazu fields": ids_f, "uniform over the table": ids_u,
+         "avazu, the 9 small fields replaced by uniform ids": torch.where(torch.tensor([d <= 32 for d in AVAZU])[None, :], ids_u, ids_f)}
+T1 = torch.randn(2, D, device=dev, requires_grad=True)
+T2 = torch.randn((N + 1) // 2, D, device=dev, requires_grad=True)
+G = torch.randn(B, len(AVAZU), D, device=dev)
+for name, ids in cases.items():
+    ids = ids.to(dev)
+    def run():
+        out = _kernels.dual_gather(ids, T1, T2, mod1=2, div2=2, op="mult")
+        out.backward(G)
+        T1.grad = None; T2.grad = None
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    from recsys_benchmark_amd.profiling import KernelTimer
+    with KernelTimer(4096) as kt:
+        for _ in range(30):
+            run()
+        torch.cuda.synchronize()
+    s = kt.summary()
+    print(f"{name:55s}", {k: round(v["avg_us"], 2) for k, v in s.items() if "dual" in k})
