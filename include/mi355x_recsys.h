@@ -160,6 +160,17 @@ MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const floa
                               float *gS1, float *gS2, int64_t n, int32_t F, int32_t De,
                               int64_t n1, int64_t n2, int64_t mod1, int64_t div2,
                               int32_t op, int32_t xform, void *stream);
+/* The same, told which FIELDS of idx[B, F] have a handful of values (n = B * F; xform 0 only, else the hint is ignored):
+ * small_fields int32[n_small] = their column indices, is_small uint8[F] the same as flags, field_row0 int64[F] = the first
+ * row of table 2 a field's ids reach (all device arrays).  A small field's B lookups land on <= 16 rows of table 2 from
+ * field_row0[f]; their gradient is summed per field in registers by extra workgroups and added once per (row, column) and
+ * workgroup instead of B same-address atomics (an id outside that span is still added, atomically).  n_small = 0: plain. */
+MI_API int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const float *T1, const float *T2,
+                                     const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *gT1,
+                                     float *gT2, float *gS1, float *gS2, int64_t n, int32_t F, int32_t De, int64_t n1,
+                                     int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform,
+                                     const int32_t *small_fields, int32_t n_small, const int64_t *field_row0,
+                                     const uint8_t *is_small, void *stream);
 
 
 /* ---- §8f rank 4 (first flavour): single-table gather with a per-element transform -------------

@@ -365,7 +365,7 @@ class DualGather(torch.autograd.Function):
     """out = T1'[idx % mod1] (op) T2'[idx // div2]  (mi_dual_gather_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int):
+    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int, fields=None):
         dev = _lib.require_gpu(idx, T1, T2)
         idxc = _i64c(idx)
         T1c, T2c = _f32c(T1), _f32c(T2)
@@ -397,6 +397,7 @@ class DualGather(torch.autograd.Function):
         )
         ctx.save_for_backward(idxc, T1c, T2c, S1c, S2c, M1c, M2c)
         ctx.meta = (n, F, De, mod1, div2, op, xform)
+        ctx.fields = fields if (fields is not None and idx.dim() == 2 and fields[3] == F) else None
         return out
 
     @staticmethod
@@ -408,19 +409,47 @@ class DualGather(torch.autograd.Function):
         gT1, gT2 = torch.zeros_like(T1c), torch.zeros_like(T2c)
         gS1 = torch.zeros_like(S1c) if xform == XF_SOFT else None
         gS2 = torch.zeros_like(S2c) if xform == XF_SOFT else None
+        small, row0, flags = (ctx.fields[0], ctx.fields[1], ctx.fields[2]) if ctx.fields is not None else (None, None, None)
         _lib.check(
-            _lib.load().mi_dual_gather_bwd(
+            _lib.load().mi_dual_gather_bwd_fields(
                 idxc.data_ptr(), g.data_ptr(), T1c.data_ptr(), T2c.data_ptr(), _lib.ptr(S1c), _lib.ptr(S2c),
                 _lib.ptr(M1c), _lib.ptr(M2c), gT1.data_ptr(), gT2.data_ptr(), _lib.ptr(gS1), _lib.ptr(gS2),
-                n, F, De, T1c.shape[0], T2c.shape[0], mod1, div2, op, xform, _lib.stream_ptr(dev)),
-            "mi_dual_gather_bwd",
+                n, F, De, T1c.shape[0], T2c.shape[0], mod1, div2, op, xform, _lib.ptr(small),
+                small.numel() if small is not None else 0, _lib.ptr(row0), _lib.ptr(flags), _lib.stream_ptr(dev)),
+            "mi_dual_gather_bwd_fields",
         )
-        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None
+        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None
 
 
-def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None):
+SMALL_FIELD_ROWS = 16     # kSmallRows of csrc/embed.hip
+
+
+def small_field_hint(field_dims, div2: int, device):
+    """The `fields` hint of dual_gather for ids that are per-field ids + cumulative offsets (how the CTR models address one
+    shared table): (small field indices int32, first table-2 row of every field int64, flags uint8, F), or None when no
+    field is small.  A field is small when its ids reach at most 16 rows of table 2 (idx // div2)."""
+    if isinstance(field_dims, int) or len(field_dims) == 0:
+        return None
+    off, row0, small = 0, [], []
+    for f, card in enumerate(field_dims):
+        lo, hi = off // div2, (off + card - 1) // div2
+        row0.append(lo)
+        if hi - lo + 1 <= SMALL_FIELD_ROWS:
+            small.append(f)
+        off += card
+    if not small:
+        return None
+    flags = torch.zeros(len(field_dims), dtype=torch.uint8)
+    flags[small] = 1
+    return (torch.tensor(small, dtype=torch.int32, device=device), torch.tensor(row0, dtype=torch.int64, device=device),
+            flags.to(device), len(field_dims))
+
+
+def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None, fields=None):
+    """fields (optional): small_field_hint(...) — lets the backward sum the gradient of low-cardinality fields per field
+    instead of with thousands of same-address atomics; same result up to the order of float additions."""
     xform = XF_SOFT if S1 is not None else (XF_MASK if M1 is not None else XF_NONE)
-    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform)
+    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform, fields)
 
 
 def csr_rows(values, crow, col, ids, D: int, N: int) -> torch.Tensor:

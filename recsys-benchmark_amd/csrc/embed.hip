@@ -153,10 +153,65 @@ struct DualGrads {
 
 constexpr int kLdsAccFloats = 8192;  // 32 KiB
 
+// Small fields (optional; xf == XF_NONE, idx is [B, F]).  A field with a handful of values sends all B lookups of its column
+// to a handful of rows of table 2: same-address float atomics run one after the other (~13 ns each) — Avazu has nine such
+// fields of 22, 12.5 us of the 34.5 us this kernel took at the C3 shape (tools/probe_dual_bwd.py).  Their table-2
+// contributions are summed per field instead: kSmallParts extra workgroups per small field walk that field's column,
+// every thread keeps one register per row of the field's span (<= kSmallRows rows from field_row0[f]), the workgroup
+// joins its lookup slots through LDS and adds each (row, d) once — kSmallParts same-address atomics instead of B.
+// The main workgroups skip table 2 for those fields (is_small[f]); an id outside its field's span still goes the
+// atomic way, so any id is handled.
+constexpr int kSmallRows = 16, kSmallParts = 32;
+struct SmallFields {
+  const int32_t *fields;     // [n] field indices
+  const int64_t *row0;       // [F] first table-2 row of every field
+  const uint8_t *is_small;   // [F]
+  int n, nmain;              // small fields; workgroups of the main part (the extra ones follow)
+  int64_t B;
+};
+
 __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__ idx, DualTables t,
                                                      const float *__restrict__ g, DualGrads gr, int64_t n,
-                                                     int F, int De, int op, int xf, int lds1, int lds2) {
+                                                     int F, int De, int op, int xf, int lds1, int lds2, SmallFields sm) {
   __shared__ float acc[kLdsAccFloats];
+  if (sm.n > 0 && (int)blockIdx.x >= sm.nmain) {
+    // ---- a small field's column: thread (lookup slot lk, column d), registers r[row of the field's span]
+    const int sb = blockIdx.x - sm.nmain, f = sm.fields[sb / kSmallParts], part = sb % kSmallParts;
+    const int LK = kBlock / De, lk = threadIdx.x / De, d = threadIdx.x % De;
+    const int64_t base_row = sm.row0[f];
+    float r[kSmallRows];
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) r[k] = 0.f;
+    for (int64_t b = (int64_t)part * LK + lk; b < sm.B; b += (int64_t)kSmallParts * LK) {
+      const int64_t i = b * F + f;
+      const int64_t id = idx[i];
+      const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+      if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) continue;
+      int64_t o1, o2;
+      out_offsets(op, i, F, De, o1, o2);
+      float g2;
+      if (op == OP_CAT) g2 = g[o2 + d];
+      else if (op == OP_MULT) g2 = g[o1 + d] * t.T1[i1 * De + d];
+      else g2 = g[o1 + d];
+      const int64_t rel = i2 - base_row;
+      if ((uint64_t)rel < (uint64_t)kSmallRows) {
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) r[k] += (rel == k) ? g2 : 0.f;
+      } else {
+        atomicAdd(gr.gT2 + i2 * De + d, g2);          // an id outside its field's span
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) acc[(lk * kSmallRows + k) * De + d] = r[k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < kSmallRows * De; o += kBlock) {
+      const int k = o / De, dd = o % De;
+      float v = 0.f;
+      for (int l = 0; l < LK; ++l) v += acc[(l * kSmallRows + k) * De + dd];
+      if (v != 0.f && base_row + k < t.n2) atomicAdd(gr.gT2 + (base_row + k) * De + dd, v);
+    }
+    return;
+  }
   // acc layout: [table-1 grads | table-2 grads] for whichever table is LDS-accumulated
   const int n1e = lds1 ? (int)(t.n1 * De) : 0;
   const int n2e = lds2 ? (int)(t.n2 * De) : 0;
@@ -164,8 +219,9 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
   if (n1e + n2e) __syncthreads();
 
   const int64_t total = n * De;
+  const int64_t nblk = sm.n > 0 ? sm.nmain : gridDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
+       e += nblk * blockDim.x) {
     const int64_t i = e / De;
     const int d = (int)(e % De);
     const int64_t id = idx[i];
@@ -199,7 +255,9 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
       g2 = t.M2[a2] ? g2 : 0.f;
     }
     if (lds1) atomicAdd(&acc[a1], g1); else atomicAdd(gr.gT1 + a1, g1);
-    if (lds2) atomicAdd(&acc[n1e + a2], g2); else atomicAdd(gr.gT2 + a2, g2);
+    if (sm.n > 0 && sm.is_small[i % F]) {}          // table 2 of a small field: the extra workgroups' job
+    else if (lds2) atomicAdd(&acc[n1e + a2], g2);
+    else atomicAdd(gr.gT2 + a2, g2);
     if (xf == XF_SOFT) {
       atomicAdd(gr.gS1 + a1, s1);
       atomicAdd(gr.gS2 + a2, s2);
@@ -508,6 +566,16 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
                        const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *gT1,
                        float *gT2, float *gS1, float *gS2, int64_t n, int32_t F, int32_t De, int64_t n1,
                        int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform, void *stream) {
+  return mi_dual_gather_bwd_fields(idx, g_out, T1, T2, S1, S2, M1, M2, gT1, gT2, gS1, gS2, n, F, De, n1, n2, mod1, div2, op, xform,
+                                   nullptr, 0, nullptr, nullptr, stream);
+}
+
+int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const float *T1, const float *T2,
+                              const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *gT1,
+                              float *gT2, float *gS1, float *gS2, int64_t n, int32_t F, int32_t De, int64_t n1,
+                              int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform,
+                              const int32_t *small_fields, int32_t n_small, const int64_t *field_row0,
+                              const uint8_t *is_small, void *stream) {
   if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
   if (op < OP_MULT || op > OP_CAT || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
@@ -520,8 +588,15 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
   int lds1 = (n1 * De <= kLdsAccFloats / 2), lds2 = (n2 * De <= kLdsAccFloats / 2);
   int grid = grid_for_elems(n * De);
   if ((lds1 || lds2) && grid > 512) grid = 512;
+  SmallFields sm{nullptr, nullptr, nullptr, 0, grid, 0};
+  if (n_small < 0 || (n_small > 0 && (!small_fields || !field_row0 || !is_small))) return MI_ERR_INVALID_ARG;
+  // the per-field sums need the [B, F] shape, plain tables, a thread layout of whole rows, table 2 on the atomic path
+  if (n_small > 0 && xform == XF_NONE && n % F == 0 && kBlock % De == 0 && kSmallRows * De * (kBlock / De) <= kLdsAccFloats && !lds2) {
+    sm = SmallFields{small_fields, field_row0, is_small, n_small, grid, n / F};
+    grid += n_small * kSmallParts;
+  }
   MI_LAUNCH("dual_gather_bwd", k_dual_bwd, grid, kBlock, stream, idx, t, g_out, gr, n, F, De, op, xform, lds1,
-            lds2);
+            lds2, sm);
   return launch_status();
 }
 

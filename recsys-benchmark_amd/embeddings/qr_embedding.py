@@ -42,6 +42,8 @@ class QRHashingEmbedding(IEmbedding):
         assert operation != "cat" or hidden_size % 2 == 0
         self._operation, self._mode, self._hidden_size = operation, mode, hidden_size
         self._num_item = field_dims if isinstance(field_dims, int) else sum(field_dims)
+        self._field_dims = None if isinstance(field_dims, int) else [int(v) for v in field_dims]
+        self._hint = None                  # (device, small-field hint) for the backward, built on first use
         self._divider, rows1, rows2 = table_rows(self._num_item, divider)
 
         width = hidden_size // 2 if operation == "cat" else hidden_size
@@ -70,7 +72,14 @@ class QRHashingEmbedding(IEmbedding):
         w1, w2 = self._tables()
         d = self._divider
         if self._mode is None:
-            return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation)
+            fields = None
+            if self._field_dims is not None and tensor.dim() == 2 and tensor.shape[1] == len(self._field_dims):
+                # ids arrive as per-field ids + cumulative offsets (the CTR models' shared table): tell the backward which
+                # fields have a handful of values
+                if self._hint is None or self._hint[0] != tensor.device:
+                    self._hint = (tensor.device, _kernels.small_field_hint(self._field_dims, d, tensor.device))
+                fields = self._hint[1]
+            return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation, fields=fields)
         # EmbeddingBag modes reduce each table's rows BEFORE the combine (two bags in the reference)
         bag1 = _kernels.bag_reduce(_kernels.gather_rows(tensor % d, w1), self._mode)
         bag2 = _kernels.bag_reduce(_kernels.gather_rows(tensor // d, w2), self._mode)

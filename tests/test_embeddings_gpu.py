@@ -621,3 +621,31 @@ def test_dual_gather_gradients_with_small_and_huge_ids(op, div2, De):
     g1 = torch.zeros(n1, De).index_add_(0, i1, G * (T2[i2] if op == "mult" else 1.0))
     g2 = torch.zeros(n2, De).index_add_(0, i2, G * (T1[i1] if op == "mult" else 1.0))
     assert torch.equal(a.grad.cpu(), g1) and torch.equal(b.grad.cpu(), g2)
+
+
+@pytest.mark.parametrize("op", ["mult", "add", "cat"])
+def test_dual_gather_backward_with_the_small_field_hint_is_the_same_gradient(op):
+    """Fields with a handful of values (here 3, 5, 9, 31 and 32 of them among larger ones, odd offsets so that spans straddle
+    quotient rows, plus ids OUTSIDE their field's range in one column) get their table-2 gradient summed per field in
+    registers (mi_dual_gather_bwd_fields) instead of by same-address atomics: integer-valued data, so both are exact."""
+    dims = [3, 700, 5, 9, 1201, 31, 32, 64, 2, 4000]
+    gen = torch.Generator().manual_seed(5)
+    B, D, div = 513, 16, 2
+    off = torch.tensor([0] + dims[:-1]).cumsum(0)
+    ids = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1) + off
+    ids[:7, 0] = torch.randint(0, sum(dims), (7,), generator=gen)          # ids that are not in field 0's range
+    N = sum(dims)
+    De = D // 2 if op == "cat" else D
+    T1v = torch.randint(-3, 4, (div, De), generator=gen).float()
+    T2v = torch.randint(-3, 4, ((N + div - 1) // div, De), generator=gen).float()
+    G = torch.randint(-2, 3, (B, 2 * len(dims), De) if op == "cat" else (B, len(dims), De), generator=gen).float().to(DEV)
+    hint = _kernels.small_field_hint(dims, div, DEV)
+    assert hint is not None and hint[0].tolist() == [0, 2, 3, 5, 8]        # (32 values at an odd offset span 17 rows: not small)
+    grads = []
+    for fields in (None, hint):
+        T1 = T1v.clone().to(DEV).requires_grad_(True)
+        T2 = T2v.clone().to(DEV).requires_grad_(True)
+        out = _kernels.dual_gather(ids.to(DEV), T1, T2, mod1=div, div2=div, op=op, fields=fields)
+        out.backward(G)
+        grads.append((T1.grad.clone(), T2.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
