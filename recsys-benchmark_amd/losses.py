@@ -59,12 +59,18 @@ class BCEWithLogitsLoss(nn.Module):
 
 
 _workspaces = {}
+ARMED_WORKSPACES = True
 
 
 def _armed_workspace(kind: str, dev, elems: int) -> torch.Tensor:
     """A per-(kernel, device, size) workspace whose arrival ticket (the last word) is zero: zeroed here once; the kernels
-    that use it leave the ticket zero, so the launch needs no memset node (mi_*_fwd_armed).  Launches that share one sit
-    on one stream, one after the other."""
+    that use it leave the ticket zero, so the launch needs no memset node (mi_*_fwd_armed).  Launches that share one must
+    run one after the other: fine for everything on one stream (eager steps, one captured graph, its replays — a capture
+    runs on torch's capture stream, the warm-up that created the workspace on another, so the key cannot hold the
+    stream); a program that runs two such losses of one kind CONCURRENTLY on two streams should call the plain entry
+    points (set losses.ARMED_WORKSPACES = False)."""
+    if not ARMED_WORKSPACES:
+        return None
     key = (kind, str(dev), int(elems))
     ws = _workspaces.get(key)
     if ws is None:
