@@ -152,8 +152,6 @@ def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=25.0):
     weight.grad, and dense Adam(weight_decay=1e-6) over every parameter; both at the survey's F=39 / N~1M shape where 13
     iterations fit the time budget, and the dense-gradient step at the full C2 table with as many iterations as the
     budget allows (its 2.16 GB gradient makes one step take seconds)."""
-    import torch.nn.functional as F_
-
     from oracle import reference_ops as ro
 
     phys, logical = physical_cores()
@@ -166,16 +164,8 @@ def cpu_baseline(dims, D, hidden, B, p_dropout, budget_s=25.0):
         x, y = synth_batch(dims_, B, 2023, "cpu")
         opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=1e-3, weight_decay=1e-6) if adam else None
 
-        def fwd():
-            if not sparse:
-                return ro.deepfm_forward(x, p, len(hidden), True, True, p_dropout=p_dropout)
-            # the same op sequence with nn.Embedding(sparse=True) / EmbeddingBag(sparse=True) gradients
-            rows = x + p["offsets"]
-            emb = F_.embedding(rows, p["embedding._emb_module.weight"], sparse=True)
-            y_fm = F_.embedding_bag(rows, p["fc.weight"], mode="sum", sparse=True) + p["_bias"] + ro.fm_second_order(emb)
-            b = emb.shape[0]
-            return (y_fm + ro.mlp_tail(emb.reshape(b, -1), p, "_deep_branch", len(hidden), True, True,
-                                       p_dropout=p_dropout)).squeeze(-1)
+        def fwd():      # sparse: nn.Embedding(sparse=True) / EmbeddingBag(sparse=True) gradients, same op sequence
+            return ro.deepfm_forward(x, p, len(hidden), True, True, p_dropout=p_dropout, sparse=sparse, fc_sparse=sparse)
 
         def step():
             for v in p.values():

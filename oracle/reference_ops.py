@@ -36,9 +36,9 @@ def fm_second_order(emb: torch.Tensor) -> torch.Tensor:
     return 0.5 * (square_of_sum - sum_of_square).sum(1, keepdim=True)
 
 
-def first_order(rows: torch.Tensor, fc_weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+def first_order(rows: torch.Tensor, fc_weight: torch.Tensor, bias: torch.Tensor, sparse: bool = False) -> torch.Tensor:
     """EmbeddingBag(N,1,'sum') over each row of the 2-D input + bias (src/models/deepfm.py:49,95)."""
-    return F.embedding_bag(rows, fc_weight, mode="sum") + bias
+    return F.embedding_bag(rows, fc_weight, mode="sum", sparse=sparse) + bias
 
 
 def mlp_tail(x: torch.Tensor, p: Params, prefix: str, hidden: int, use_bn: bool, training: bool,
@@ -63,19 +63,22 @@ def mlp_tail(x: torch.Tensor, p: Params, prefix: str, hidden: int, use_bn: bool,
     return F.linear(x, p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"])
 
 
-def deepfm_embed_fm(x: torch.Tensor, p: Params) -> Tuple[torch.Tensor, torch.Tensor]:
+def deepfm_embed_fm(x: torch.Tensor, p: Params, sparse: bool = False, fc_sparse: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """The gather + FM + first-order part of DeepFM.forward with a vanilla table
-    (src/models/deepfm.py:88-98; src/models/embeddings/base.py:74-75) -> (emb[B,F,D], y_fm[B,1])."""
+    (src/models/deepfm.py:88-98; src/models/embeddings/base.py:74-75) -> (emb[B,F,D], y_fm[B,1]).
+    sparse: nn.Embedding(sparse=True), the `sparse: True` embedding config of configs/deepfm/base_config_sparse.yaml:8-10
+    (src/models/embeddings/base.py:60-64) — same values, the table's gradient in row (COO) form; fc_sparse: the same for
+    the first-order EmbeddingBag (this build's extension, DeepFM(fc_sparse=True))."""
     rows = x + p["offsets"]
-    emb = F.embedding(rows, p["embedding._emb_module.weight"])
-    y_fm = first_order(rows, p["fc.weight"], p["_bias"]) + fm_second_order(emb)
+    emb = F.embedding(rows, p["embedding._emb_module.weight"], sparse=sparse)
+    y_fm = first_order(rows, p["fc.weight"], p["_bias"], sparse=fc_sparse) + fm_second_order(emb)
     return emb, y_fm
 
 
 def deepfm_forward(x: torch.Tensor, p: Params, n_hidden: int, use_bn: bool, training: bool,
-                   p_dropout: float = 0.0) -> torch.Tensor:
+                   p_dropout: float = 0.0, sparse: bool = False, fc_sparse: bool = False) -> torch.Tensor:
     """DeepFM.forward, vanilla embedding (src/models/deepfm.py:79-105); dropout off unless asked."""
-    emb, y_fm = deepfm_embed_fm(x, p)
+    emb, y_fm = deepfm_embed_fm(x, p, sparse, fc_sparse)
     b, nf, d = emb.shape
     scores = y_fm + mlp_tail(emb.reshape(b, nf * d), p, "_deep_branch", n_hidden, use_bn, training,
                              p_dropout=p_dropout)

@@ -197,6 +197,14 @@ class GatherFM(torch.autograd.Function):
 DETERMINISTIC = False
 
 
+def _no_atomics_promised(what: str) -> None:
+    """use_deterministic_algorithms(True) promises gradients without float atomics; a backward that only exists in the
+    atomic form says so instead of handing out gradients that merely look reproducible."""
+    if DETERMINISTIC:
+        raise NotImplementedError(f"{what} accumulates duplicate rows with float atomics; it has no deterministic form "
+                                  "(recsys_benchmark_amd.use_deterministic_algorithms(True) is on)")
+
+
 def coalesce_dense(rows: torch.Tensor, vals: torch.Tensor, N: int, D: int) -> torch.Tensor:
     """Dense [N, D] gradient of a table out of row-form (rows[n], vals[n, D]) contributions, added in a fixed order."""
     dev = vals.device
@@ -405,6 +413,7 @@ class DualGather(torch.autograd.Function):
         idxc, T1c, T2c, S1c, S2c, M1c, M2c = ctx.saved_tensors
         n, F, De, mod1, div2, op, xform = ctx.meta
         dev = g.device
+        _no_atomics_promised("the two-table (QR / CERP) gather backward")
         g = _f32c(g)
         gT1, gT2 = torch.zeros_like(T1c), torch.zeros_like(T2c)
         gS1 = torch.zeros_like(S1c) if xform == XF_SOFT else None
@@ -1342,6 +1351,7 @@ class XformGather(torch.autograd.Function):
     def backward(ctx, g):
         idxc, Wc, Sc, Mc = ctx.saved_tensors
         srs, scs, xform, Wshape, Sshape = ctx.meta
+        _no_atomics_promised("the transformed (PEP / masked) gather backward")
         g = _f32c(g)
         N, D = Wc.shape
         gW = torch.zeros_like(Wc)

@@ -501,10 +501,13 @@ constexpr int TN_S = 2, TN_TILE = BK * 64;
 __device__ __forceinline__ void tn_dma(const float *src, float *lds_dst) {
   // (inline asm, not __builtin_amdgcn_global_load_lds: after the builtin hipcc treats every later LDS read as possibly
   //  out of order with it and waits lgkmcnt(0) in front of each MFMA.  The asm writes M0, which hipcc does not let an asm
-  //  declare as clobbered ("reserved register"): nothing else in k_gemm_tn_multi uses M0 — checked in the ISA, and to be
-  //  re-checked when this kernel gains LDS-direct or indexed-register code.)
+  //  declare as clobbered ("reserved register"), so the block SAVES and RESTORES it itself: M0 is read when the DMA
+  //  issues, the restore right behind the issue is safe, and code the compiler may one day place around this — LDS-direct
+  //  loads, indexed registers — finds M0 as it left it.  Two scalar moves per DMA; the loop is not SALU-bound.)
   const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(off) : "memory");
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(off) : "memory");
 }
 
 __global__ __launch_bounds__(256) void k_gemm_tn_multi(MultiArgs m) {

@@ -64,29 +64,31 @@ __device__ __forceinline__ float4 row_dot(const int *__restrict__ col, const flo
   return a;
 }
 
-// mask[w] bit b = row 32 w + b of X has a non-zero element; a wave builds one word (64 / LPR rows per pass)
+// mask[w] bit b = row 32 w + b of X has a non-zero element; a wave builds one word, RPP = min(32, 64 / LPR) rows per pass
+// (D = 4: a wave could cover 64 rows, i.e. two words — its upper 32 lanes sit the single pass out instead)
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void k_row_mask(Seg2 X, int n_rows, uint32_t *__restrict__ mask, int n_words) {
   constexpr int NPW = kWave / LPR;
+  constexpr int RPP = NPW > 32 ? 32 : NPW;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63, q = lane % LPR, k = lane / LPR;
   const int word = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (word >= n_words) return;
   uint32_t bits = 0;
 #pragma unroll
-  for (int p = 0; p < 32 / NPW; ++p) {
-    const int row = word * 32 + p * NPW + k;
+  for (int p = 0; p < 32 / RPP; ++p) {
+    const int row = word * 32 + p * RPP + k;
     bool nz = false;
-    if (row < n_rows) {
+    if (k < RPP && row < n_rows) {
       const float4 x = ld4(seg_row(X, row, D) + q * 4);
       nz = x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f;
     }
     const unsigned long long b = __ballot(nz);
     // lanes of row slot k are k * LPR .. k * LPR + LPR - 1
 #pragma unroll
-    for (int kk = 0; kk < NPW; ++kk) {
+    for (int kk = 0; kk < RPP; ++kk) {
       const unsigned long long grp = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << (kk * LPR));
-      if (b & grp) bits |= 1u << (p * NPW + kk);
+      if (b & grp) bits |= 1u << (p * RPP + kk);
     }
   }
   if (lane == 0) mask[word] = bits;

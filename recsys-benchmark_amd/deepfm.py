@@ -102,13 +102,15 @@ class DeepFM(nn.Module):
         W.data = packed[:, :D]
         w1.data = packed[:, D:D + 1]
         if not getattr(self, "_packed_hook", False):
-            # checkpoints keep the reference's format: two contiguous tensors, not two views that drag the packed buffer along
+            # checkpoints keep the reference's format: contiguous tensors, not views that drag the packed buffer along —
+            # whichever module's state_dict() is asked (the model's, `model.embedding`'s as factory.save_ctr_checkpoint
+            # does, or `fc`'s)
             def _contiguous_tables(module, state_dict, prefix, local_metadata):
-                for key in (prefix + "embedding._emb_module.weight", prefix + "fc.weight"):
-                    t = state_dict.get(key)
-                    if t is not None and not t.is_contiguous():
+                for key, t in list(state_dict.items()):
+                    if key.startswith(prefix) and torch.is_tensor(t) and not t.is_contiguous():
                         state_dict[key] = t.detach().contiguous()
-            self._register_state_dict_hook(_contiguous_tables)
+            for mod in (self, emb, emb._emb_module, self.fc):
+                mod._register_state_dict_hook(_contiguous_tables)
             self._packed_hook = True
         return self
 

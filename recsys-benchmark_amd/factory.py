@@ -83,7 +83,11 @@ def load_graph_model(checkpoint_path: str, strict=True):
 def _save_embedding(emb, checkpoint_dir: str, field_name: str, name: str) -> None:
     field_dir = os.path.join(checkpoint_dir, field_name)
     os.makedirs(field_dir, exist_ok=True)
-    torch.save(emb.state_dict(), os.path.join(field_dir, f"{name}.pth"))
+    # a table may be a column-slice view of a packed buffer (DeepFM.pack_tables()): torch.save would serialise the whole
+    # packed storage behind every view — the file keeps the reference's layout, one contiguous tensor per key
+    state = {k: (v.detach().contiguous().clone() if torch.is_tensor(v) and not v.is_contiguous() else v)
+             for k, v in emb.state_dict().items()}
+    torch.save(state, os.path.join(field_dir, f"{name}.pth"))
 
 
 def save_cf_emb_checkpoint(model, checkpoint_dir: str, name: str = "target"):

@@ -62,6 +62,43 @@ def bucket_capacity(n: int, world: int, slack: float) -> int:
     return min(n, int(mean * slack + 6.0 * (mean ** 0.5)) + 64)
 
 
+_captures = 0          # global-mode captures this process has under way (noted by note_capture())
+
+
+def note_capture(delta: int) -> None:
+    """Callers that capture a hipGraph while a DirectComm may exist bracket the capture with note_capture(+1) / (-1)."""
+    global _captures
+    _captures = max(0, _captures + delta)
+
+
+def _capture_under_way() -> bool:
+    return _captures > 0
+
+
+class _relaxed_capture_mode:
+    """Thread-local relaxed capture mode for the calling thread (cudaThreadExchangeStreamCaptureMode): its event queries
+    neither join nor invalidate a capture another thread holds.  A no-op where torch does not expose the call."""
+
+    def __enter__(self):
+        self._rt = self._old = None
+        try:
+            rt = torch.cuda.cudart()
+            self._old = rt.cudaThreadExchangeStreamCaptureMode(rt.cudaStreamCaptureMode.Relaxed) if hasattr(
+                rt, "cudaThreadExchangeStreamCaptureMode") else None
+            self._rt = rt
+        except Exception:  # noqa: BLE001
+            self._rt = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._rt is not None and self._old is not None:
+            try:
+                self._rt.cudaThreadExchangeStreamCaptureMode(self._old)
+            except Exception:  # noqa: BLE001
+                pass
+        return False
+
+
 class DirectComm:
     """The library's own RCCL communicator (csrc/comm.hip): all-to-all / all-reduce enqueued on the CURRENT stream, i.e.
     the one the kernels run on — no process-group stream, no event hand-offs around the collectives (≈60 us of the
@@ -74,6 +111,8 @@ class DirectComm:
         self._pending = []          # (host time, event) markers behind collectives, oldest first
         self._last_mark = 0.0
         self._watchdog = None
+        import threading
+        self._lock = threading.Lock()      # _pending and handle are touched by the watchdog thread too
 
     # A collective of a library-owned communicator has no ProcessGroupNCCL watchdog behind it: when a peer dies (or
     # raises and leaves), the surviving ranks would sit in the next all-to-all forever.  Every second or so a collective
@@ -89,9 +128,12 @@ class DirectComm:
         if now - self._last_mark < 1.0:
             return
         self._last_mark = now
+        if torch.cuda.is_current_stream_capturing():
+            return                      # an event recorded into a capture cannot be queried from outside it
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
-        self._pending.append((now, ev))
+        with self._lock:
+            self._pending.append((now, ev))
         if self._watchdog is None:
             deadline = float(os.environ.get("MI_COMM_DEADLINE_S", "180"))
 
@@ -101,13 +143,27 @@ class DirectComm:
                 from . import _lib
                 while self.handle is not None:
                     time.sleep(1.0)
-                    while self._pending and self._pending[0][1].query():
-                        self._pending.pop(0)
-                    if self._pending and time.monotonic() - self._pending[0][0] > deadline:
+                    # A cross-thread event query while ANOTHER thread holds a global-mode stream capture (trainer's
+                    # GraphedTrainStep, bench's per-batch graphs) would invalidate that capture: this thread's own
+                    # calls are made capture-"relaxed" (what ProcessGroupNCCL's watchdog does), and a tick that finds a
+                    # capture under way on this device is skipped besides — captures last milliseconds, the deadline is
+                    # minutes.
+                    late = False
+                    with self._lock:
+                        if self.handle is None:
+                            return
+                        if _capture_under_way():
+                            continue
+                        with _relaxed_capture_mode():
+                            while self._pending and self._pending[0][1].query():
+                                self._pending.pop(0)
+                        late = bool(self._pending) and time.monotonic() - self._pending[0][0] > deadline
+                        handle = self.handle
+                    if late:
                         print(f"mi355x_recsys: a collective of the direct RCCL communicator has not finished within "
                               f"{deadline:.0f} s (a peer is gone?); aborting the communicator and exiting", file=sys.stderr, flush=True)
                         try:
-                            _lib.load().mi_comm_abort(self.handle)
+                            _lib.load().mi_comm_abort(handle)
                         finally:
                             os._exit(86)
 
@@ -213,9 +269,10 @@ class DirectComm:
     def close(self):
         from . import _lib
 
-        if self.handle is not None:
-            _lib.load().mi_comm_destroy(self.handle)
-            self.handle = None
+        with self._lock:                 # (not while the watchdog is between reading the handle and aborting it)
+            handle, self.handle = self.handle, None
+        if handle is not None:
+            _lib.load().mi_comm_destroy(handle)
 
 
 def _all_to_all(model, out, inp):

@@ -35,6 +35,29 @@ def _check_errors(model) -> None:
         _lib.check_index_errors()
 
 
+class _capture(torch.cuda.graph):
+    """torch.cuda.graph that also tells a direct RCCL communicator's watchdog thread (sharded.DirectComm) that a
+    global-mode capture is under way, so it leaves its event queries alone until the capture has ended."""
+
+    def __enter__(self):
+        from . import sharded
+
+        sharded.note_capture(+1)
+        try:
+            return super().__enter__()
+        except BaseException:
+            sharded.note_capture(-1)
+            raise
+
+    def __exit__(self, *exc):
+        from . import sharded
+
+        try:
+            return super().__exit__(*exc)
+        finally:
+            sharded.note_capture(-1)
+
+
 def _capturable(optimizers) -> bool:
     """False when an optimizer keeps its step count on the host (torch's Adam family without `capturable=True`): its
     step() refuses to run under capture, and a capture abandoned half-way is not something to recover from — so this
@@ -101,7 +124,7 @@ class GraphedTrainStep:
         for opt in self.optimizers:
             opt.zero_grad(set_to_none=True)        # the captured backward allocates the gradients in the graph's pool
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with _capture(graph):
             static_loss = self._body(static_in, static_lab)
         self._graph, self._static = graph, (static_in, static_lab, static_loss)
 
@@ -242,7 +265,7 @@ class GraphedForward:
             try:
                 static_in = x.clone()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with _capture(graph):
                     static_out = self.model(static_in)
                 entry = self._graphs[key] = (graph, static_in, static_out)
             except Exception as exc:
@@ -340,7 +363,7 @@ class GraphedCFTrainStep:
                 static = (users.clone(), pos_items.clone(), neg_items.clone())
                 self.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with _capture(graph):
                     parts = self._body(*static)
                 self._graph, self._static = graph, static + (parts,)
             except Exception as exc:

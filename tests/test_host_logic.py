@@ -67,6 +67,32 @@ def test_deepfm_offsets_and_load(tmp_path):
     assert (tmp_path / "deepfm" / "target.pth").exists()
 
 
+def test_packed_tables_save_the_references_checkpoint_layout(tmp_path):
+    """DeepFM.pack_tables() turns the two lookup tables into column views of one [N, 32] buffer; every way of asking for a
+    state_dict (the model's, and `model.embedding`'s as save_ctr_checkpoint does) must still give the reference's two
+    contiguous tensors, not views that serialise the whole packed storage behind them."""
+    import os
+
+    dims = [50, 70, 130]
+    m = pkg.get_ctr_model(dims, {"name": "deepfm", "num_factor": 16, "hidden_sizes": [8]})
+    W0, w0 = m.embedding._emb_module.weight.detach().clone(), m.fc.weight.detach().clone()
+    m.pack_tables()
+    assert m.tables_packed and not m.embedding._emb_module.weight.is_contiguous()
+    N = sum(dims)
+    for sd in (m.state_dict(), m.embedding.state_dict(), m.embedding._emb_module.state_dict(), m.fc.state_dict()):
+        for k, t in sd.items():
+            assert t.is_contiguous(), k
+            assert t.untyped_storage().nbytes() == t.numel() * t.element_size(), f"{k} drags a larger storage along"
+    pkg.save_ctr_checkpoint(m, str(tmp_path))
+    path = tmp_path / "deepfm" / "target.pth"
+    assert os.path.getsize(path) < N * 16 * 4 + 4096, "the file holds the [N, 16] table, not the [N, 32] packed buffer"
+    sd = torch.load(path)
+    assert list(sd) == ["_emb_module.weight"] and sd["_emb_module.weight"].is_contiguous()
+    assert torch.equal(sd["_emb_module.weight"], W0)
+    full = m.state_dict()
+    assert torch.equal(full["fc.weight"], w0) and torch.equal(full["embedding._emb_module.weight"], W0)
+
+
 def test_graph_model_factory_and_checkpoint_helpers(tmp_path):
     cfg = {"name": "lightgcn", "num_layers": 3, "hidden_size": 8}
     m = pkg.get_graph_model(10, 12, cfg)

@@ -167,7 +167,8 @@ def test_consecutive_dropout_draws_use_their_own_transposed_values():
         del drawn, d
 
 
-@pytest.mark.parametrize("U,I,nnz,D,L", [(1500, 500, 20000, 64, 3), (50, 70, 300, 16, 2), (300, 200, 4000, 8, 1)])
+@pytest.mark.parametrize("U,I,nnz,D,L", [(1500, 500, 20000, 64, 3), (50, 70, 300, 16, 2), (300, 200, 4000, 8, 1),
+                                         (90, 110, 900, 4, 2)])      # D = 4: a wave of the mask kernel spans two words
 @pytest.mark.parametrize("masked", [True, False])
 def test_backward_with_a_gradient_on_few_rows_skips_the_zero_rows_exactly(U, I, nnz, D, L, masked, monkeypatch):
     """The gradient entering a backward propagation is non-zero only on the batch's rows (BPR, L2 reg): the first layer

@@ -24,8 +24,8 @@ DEV = "cuda"
 
 @pytest.fixture(autouse=True, params=[True, False], ids=["joins-in-prologue", "finalize-launches"])
 def _fused_tail_on(request, monkeypatch):
-    """Every test runs with the BatchNorm joins in the consuming kernels' prologues (the default since round 3) and with
-    the finalize launches of round 2 (MI_TAIL_MERGE_JOINS=0)."""
+    """Every test runs with the BatchNorm joins in the consuming kernels' prologues (opt-in, MI_TAIL_MERGE_JOINS=1: built in
+    round 3, measured slower, see tail.py) and with the finalize launches (the default)."""
     from recsys_benchmark_amd import tail as _tail_mod
 
     monkeypatch.setattr(_mlp, "FUSED_TAIL", True)
