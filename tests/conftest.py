@@ -43,9 +43,18 @@ class Golden(dict):
 
 
 def load_golden(name: str) -> Golden:
+    """A fixture may name another one in `params_from`: that file's `param/*` arrays are the parameters it ran with (its own
+    arrays win) — how the C1 eval fixture avoids a second copy of the 2.3 MB base-config parameters."""
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     with np.load(path) as z:
-        return Golden({k: z[k] for k in z.files})
+        out = {k: z[k] for k in z.files}
+    base = out.pop("params_from", None)
+    if base is not None:
+        with np.load(os.path.join(GOLDEN_DIR, str(base) + ".npz")) as z:
+            for k in z.files:
+                if k.startswith("param/"):
+                    out.setdefault(k, z[k])
+    return Golden(out)
 
 
 def golden_names(prefix: str):

@@ -110,6 +110,53 @@ def gen_deepfm():
              **before, **grads_of(model))
 
 
+# ------------------------------------------------------------------ G1 / C1: the reference's base config on its own sample
+def gen_deepfm_c1():
+    """BASELINE config 1: the reference's OWN dataset class maps tests/assets/train_criteo_sample.txt
+    (100 rows, min_threshold 10) to the 39 per-field ids and field sizes, and the `model` block of
+    configs/deepfm/base_config.yaml:1-10 (D = 16, 400x3, BatchNorm; p_dropout 0 for parity) runs on B = 256 of its rows
+    (the 100 rows repeated), training mode (forward + BCE backward) and eval mode.  The eval file keeps only what differs
+    from the training file (`params_from`): the inputs, the BatchNorm running statistics it ran with, outputs, and the
+    gradients of the small parameters."""
+    import tempfile
+
+    import yaml
+    from src.dataset.criteo import CriteoDataset
+
+    with tempfile.TemporaryDirectory() as tmp:
+        ds = CriteoDataset(os.path.join(REF, "tests/assets/train_criteo_sample.txt"), os.path.join(tmp, "cache.bin"))
+        dims = [int(d) for d in ds.field_dims]
+        feats = torch.stack([ds[i][0] for i in range(len(ds))]).to(torch.int64)
+        labels = torch.tensor([float(ds[i][1]) for i in range(len(ds))])
+    assert len(dims) == 39 and feats.shape == (100, 39)
+    with open(os.path.join(REF, "configs/deepfm/base_config.yaml")) as fin:
+        block = yaml.safe_load(fin)["model"]
+    assert block["num_factor"] == 16 and block["hidden_sizes"] == [400, 400, 400] and block["use_batchnorm"] is True
+    B = 256
+    pick = torch.arange(B) % feats.shape[0]
+    x, y = feats[pick].contiguous(), labels[pick].contiguous()
+    gen = torch.Generator().manual_seed(2024)
+    for training in (True, False):
+        set_seed(2023)
+        cfg = dict(block, name="deepfm", p_dropout=0.0)
+        model = get_ctr_model(dims, cfg)
+        with torch.no_grad():
+            model._bias.copy_(torch.randn(1, generator=torch.Generator().manual_seed(5)) * 0.1)
+        randomize_bn(model, torch.Generator().manual_seed(6))
+        model.train(training)
+        before = params_of(model)
+        logits = model(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+        loss.backward()
+        common = dict(field_dims=np.array(dims), x=x, y=y, logits=logits, loss=loss, use_bn=np.array(True),
+                      training=np.array(training), n_hidden=np.array(3))
+        if training:
+            save("deepfm_c1_base_config_train", **common, **before, **grads_of(model))
+        else:
+            small = {k: v for k, v in grads_of(model).items() if v.numel() <= 4096}
+            save("deepfm_c1_base_config_eval", params_from=np.array("deepfm_c1_base_config_train"), **common, **small)
+
+
 # ------------------------------------------------------------------ G2: QR
 def gen_qr():
     gen = torch.Generator().manual_seed(7)
@@ -570,7 +617,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["deepfm", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "tt_init", "dcn", "lightgcn", "csr_pruned", "losses", "metrics"]
+    which = sys.argv[1:] or ["deepfm", "deepfm_c1", "qr", "cerp", "pep", "ptq", "qat", "optembed", "dhe", "tt", "tt_init", "dcn", "lightgcn", "csr_pruned", "losses", "metrics"]
     for w in which:
         print(f"[{w}]")
         globals()[f"gen_{w}"]()
