@@ -238,6 +238,59 @@ class GatherBench:
                                                L.stream_ptr(self.dev)), "bwd")
 
 
+class DgradBench:
+    """The tail's FIRST input-gradient product (dz[B, H] . W1[H, F*D]) launched through the C-ABI in its two forms: plain
+    (OUT = da, what round 3 ran in front of mi_gather_fm_bwd_rows) and with the lookup's backward in its epilogue
+    (mi_tail_dgrad_gemm_fm: reads the saved rows + their per-sample sums, writes the table's row-form gradient).  The
+    difference of their in-graph wall times is what the fused epilogue costs a step.  Saved rows and outputs rotate through
+    `sets` buffer sets larger than the Infinity Cache (the epilogue then reads the rows from HBM: a step's own rows are
+    ~250 us old and may still be cache-resident, so this is the pessimistic side)."""
+
+    def __init__(self, B, F, D, H, dev, sets=None):
+        from recsys_benchmark_amd import _lib as L
+
+        self.L, self.lib, self.B, self.F, self.D, self.H, self.dev = L, L.load(), B, F, D, H, dev
+        K = F * D
+        set_bytes = 2 * B * K * 4
+        self.sets = sets or max(2, min(24, -(-(320 << 20) // set_bytes)))
+        g = torch.Generator().manual_seed(11)
+        self.emb = [torch.randn(B, K, generator=g).to(dev) for _ in range(self.sets)]
+        self.out = [torch.empty(B, K, device=dev) for _ in range(self.sets)]
+        self.esum = torch.randn(B, D, generator=g).to(dev)
+        self.gy, self.g1 = torch.randn(B, generator=g).to(dev), torch.empty(B, F, device=dev)
+        self.DY = [torch.randn(B, H, generator=g).to(dev) for _ in range(2)]
+        self.Z = [torch.randn(B, H, generator=g).to(dev) for _ in range(2)]
+        self.W = (torch.randn(H, K, generator=g) * 0.05).to(dev)
+        self.c = [torch.randn(H, generator=g).to(dev) * 0.1 for _ in range(4)]      # mu, al, bz, de
+
+    def run(self, i, fm):
+        L, B, H, K = self.L, self.B, self.H, self.F * self.D
+        k, j = i % self.sets, i % 2
+        mu, al, bz, de = self.c
+        if fm:
+            L.check(self.lib.mi_tail_dgrad_gemm_fm(self.DY[j].data_ptr(), self.Z[j].data_ptr(), H, mu.data_ptr(), al.data_ptr(),
+                                                   bz.data_ptr(), de.data_ptr(), self.W.data_ptr(), K, self.out[k].data_ptr(), None,
+                                                   B, H, K, None, self.emb[k].data_ptr(), self.esum.data_ptr(), self.gy.data_ptr(),
+                                                   self.g1.data_ptr(), self.D, L.stream_ptr(self.dev)), "dgrad_fm")
+        else:
+            L.check(self.lib.mi_tail_dgrad_gemm_s(self.DY[j].data_ptr(), self.Z[j].data_ptr(), H, mu.data_ptr(), al.data_ptr(),
+                                                  bz.data_ptr(), de.data_ptr(), self.W.data_ptr(), K, None, K, None, None, None,
+                                                  0.0, None, self.out[k].data_ptr(), K, None, 0, None, B, H, K, None,
+                                                  L.stream_ptr(self.dev)), "dgrad")
+
+
+def dgrad_epilogue_us(B, F, D, H, dev, copies=32, reps=20):
+    """(plain, with the lookup backward in the epilogue) in-graph wall microseconds of the first input-gradient product."""
+    db = DgradBench(B, F, D, H, dev)
+    plain = graph_wall_us(lambda i: db.run(i, False), copies, reps, dev)
+    fm = graph_wall_us(lambda i: db.run(i, True), copies, reps, dev)
+    # interleaved once more: the two forms alternate inside ONE graph (same clocks, same cache state), halves attributed
+    both = graph_wall_us(lambda i: (db.run(2 * i, False), db.run(2 * i + 1, True)), copies // 2, reps, dev)
+    del db
+    torch.cuda.empty_cache()
+    return {"plain": plain, "fm": fm, "alternating_pair": both}
+
+
 def graph_wall_us(enqueue, copies, reps, dev):
     """WALL microseconds per enqueue(i) inside a replayed hipGraph holding `copies` of them back to back (HIP events on the
     stream the graph is launched on, around `reps` replays)."""
@@ -1016,6 +1069,7 @@ def main():
         xs_ring = [blob[:nx].view(torch.int64).view(B, F) for blob in ring]
         xs_ring += [synth_batch(dims, B, 31337 + i, dev, args.ids)[0] for i in range(max(0, 64 - len(xs_ring)))]
         ingraph = gather_in_graph_us(model, xs_ring, B, F, D, dev, copies=64)
+        ingraph["dgrad"] = dgrad_epilogue_us(B, F, D, hidden[0], dev)
         if not args.no_sweep and rank == 0:
             sweep = batch_sweep(model, dims, F, D, dev, args.ids)
     sharded_phases = None
@@ -1047,12 +1101,29 @@ def main():
         roofline = None
         if ingraph is not None:
             fwd_us, bwd_us, pair_us = ingraph["fwd"], ingraph["bwd"], ingraph["pair"]
-            dom, dom_us, dom_bytes = (("gather_fm_fwd", fwd_us, fb * B) if fwd_us >= bwd_us else
-                                      ("gather_fm_bwd_rows", bwd_us, bb * B))
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(dom_bytes / dom_us / 1e3, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(dom_bytes / dom_us / 1e3 / HBM_PEAK_GBS, 4),
-                        "traffic": traffic_all.get(dom), "avg_us": round(dom_us, 3),
-                        "clock": "WALL per kernel inside a replayed hipGraph of 64 launches of that kernel, HIP events on the launching "
+            dg = ingraph["dgrad"]
+            epi_us = max(dg["fm"] - dg["plain"], 0.0)
+            from recsys_benchmark_amd import tail as _tailmod
+            fused = bool(_tailmod.FM_EPILOGUE and _mlp.FUSED_TAIL and sparse)
+            step_pair_us = fwd_us + epi_us if fused else pair_us
+            pair_bytes = (fb + bb) * B
+            roofline = {"bound": "hbm",
+                        "kernel": ("gather+FM fwd+bwd PAIR as the step runs it: k_gather_fm_fwd + the lookup backward in the epilogue of "
+                                   "the tail's first input-gradient product (k_tail_dgrad<..., FM>: its time with the epilogue minus "
+                                   "its time without)" if fused else "gather+FM fwd+bwd pair: k_gather_fm_fwd + k_gather_fm_bwd_rows"),
+                        "achieved": round(pair_bytes / step_pair_us / 1e3, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(pair_bytes / step_pair_us / 1e3 / HBM_PEAK_GBS, 4),
+                        "traffic": traffic_all.get("gather_fm_pair_fused" if fused else "gather_fm_fwd"), "avg_us": round(step_pair_us, 3),
+                        "alg_bytes": pair_bytes,
+                        "attribution": {"gather_fm_fwd_us": round(fwd_us, 3),
+                                        "tail_dgrad_gemm_plain_us": round(dg["plain"], 3), "tail_dgrad_gemm_fm_us": round(dg["fm"], 3),
+                                        "epilogue_us": round(epi_us, 3),
+                                        "alternating_plain_then_fm_us_per_pair": round(dg["alternating_pair"], 3),
+                                        "note": "algorithmic bytes are SURVEY.md §8d's 24F + 20FD + 8 per sample for the PAIR (the fused "
+                                                "form moves fewer: dL/demb is neither written nor read back); time = forward kernel + "
+                                                "(first input-gradient product with the lookup backward in its epilogue - the same "
+                                                "product without), each an in-graph wall per launch over cold buffers"},
+                        "clock": "WALL per kernel inside a replayed hipGraph of 32-64 launches of that kernel, HIP events on the launching "
                                  "stream around 20 replays; ids, table rows and activations rotate through more data than the "
                                  "256 MiB Infinity Cache holds, so every launch reads from HBM as inside a training step",
                         "cache_assisted_back_to_back": {"note": "the same graphs over ONE activation buffer set and 16 id batches (their "
@@ -1061,9 +1132,9 @@ def main():
                                                         "gather_fm_bwd_rows": rl(ingraph["warm"]["bwd"], bb * B)},
                         "alg_bytes_per_sample": {"fwd": fb, "bwd": bb},
                         "gather_fm_fwd": rl(fwd_us, fb * B), "gather_fm_bwd_rows": rl(bwd_us, bb * B),
-                        "fwd_bwd_pair": dict(rl(pair_us, (fb + bb) * B), what="wall per fwd+bwd pair in a graph of 64 pairs (the backward reads a forward's output from 8 pairs earlier)",
-                                             sum_of_the_two_kernels_us=round(fwd_us + bwd_us, 3),
-                                             target_us_for_half_of_peak=round((fb + bb) * B / (0.5 * HBM_PEAK_GBS) / 1e3, 2)),
+                        "two_kernel_pair": dict(rl(pair_us, (fb + bb) * B), what="the round-3 form (MI_FUSED_FM_EPILOGUE=0): wall per fwd + bwd_rows pair in a graph of 64 pairs",
+                                                sum_of_the_two_kernels_us=round(fwd_us + bwd_us, 3)),
+                        "target_us_for_half_of_peak": round((fb + bb) * B / (0.5 * HBM_PEAK_GBS) / 1e3, 2),
                         "table_layout": args.layout if not sharded else "sharded packed rows"}
             if kernels:
                 roofline["eager_dispatch_clock"] = {

@@ -39,7 +39,8 @@ extern "C" {
 
 /* 2: round 3 — mi_sort_field_rows / mi_bpr_* / mi_rowsq_* had gained arguments under version 1 (callers built against
  * that header must rebuild); mi_gather_fm_fwd_ld, mi_sparse_adam_sorted's row stride and the later additions are new. */
-#define MI_ABI_VERSION 2
+/* 3: round 4 — mi_tail_bn_fwd gained `shift` and `nrep` (a caller built against version 2 passes a shorter struct). */
+#define MI_ABI_VERSION 3
 
 #define MI_OK 0
 #define MI_ERR_INVALID_ARG (-1)  /* null pointer, negative size, bad enum */
@@ -84,6 +85,15 @@ MI_API int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets,
                                float *emb_out, float *yfm_out, int64_t *rows_out,
                                int64_t B, int32_t F, int32_t D, int64_t N,
                                int32_t *err, void *stream);
+
+/* The same forward, additionally storing sum_out[b, :] = sum_f emb[b, f, :] (fp32[B, D], nullable) — the one quantity of the
+ * FM backward (src/models/deepfm.py:91-92 through autograd: dE_bf = g_b (S_b - e_bf)) that a kernel seeing only SOME fields
+ * of a sample cannot re-derive; mi_tail_dgrad_gemm_fm (below) consumes it. */
+MI_API int mi_gather_fm_fwd_sum(const int64_t *idx, const int64_t *offsets,
+                                const float *W, int64_t ldw, const float *w1, int64_t ldw1, const float *bias,
+                                float *emb_out, float *yfm_out, int64_t *rows_out, float *sum_out,
+                                int64_t B, int32_t F, int32_t D, int64_t N,
+                                int32_t *err, void *stream);
 
 /* Backward of the above, row-sparse form (the MI355X-native default):
  *   gvals[b,f,:] = g_emb[b,f,:] + g_y[b] * (S_b - emb[b,f,:]),  S_b = sum_f emb
@@ -733,6 +743,8 @@ typedef struct mi_tail_bn_fwd {
   int64_t *num_batches_tracked, *seed_bump;
   float *mu, *sc, *be, *rstd;
   float momentum, eps;
+  const float *shift;     /* nrep > 0: the shift the sums were taken around, [N] (mi_tail_fwd_gemm_s's shift_out) */
+  int32_t nrep;           /* 0: `part` = tile statistics [MT, N, 2]; > 0: `part` = shifted sums [nrep, 2, N] (mi_tail_fwd_gemm_s) */
 } mi_tail_bn_fwd;
 typedef struct mi_tail_bn_bwd {
   const float *part;
@@ -746,6 +758,28 @@ MI_API int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, co
                               float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
                               float *part, float *a_out, int32_t M, int32_t N, int32_t K,
                               const mi_tail_bn_fwd *x_stats, void *stream);
+/* BatchNorm statistics WITHOUT finalize launches (round 4).  The producing product adds, per column c and 64-row tile,
+ *   t1 = sum (z - s_c),  t2 = sum (z - s_c)^2,   s_c = shift_running_mean[c] - shift_mean_offset[c]  (each nullable: 0)
+ * into part[r, 0, c] / part[r, 1, c] (fp32[sum_reps, 2, N], ZEROED by the caller, r = row tile % sum_reps) with float atomics
+ * and stores s into shift_out[N]; the consuming kernel (mi_tail_fwd_gemm_* / mi_tail_head_fwd_m with a mi_tail_bn_fwd whose
+ * nrep = sum_reps, part and shift point at these buffers) derives mean = s + t1/M, M2 = t2 - t1^2/M and the constants in
+ * its prologue from (2 nrep + 3) N floats and its first workgroup writes mu / sc / be / rstd and the running statistics
+ * (F.batch_norm(training=True) semantics, src/models/deepfm.py:57-58).  sum_reps = 0 is mi_tail_fwd_gemm_m.
+ * mi_tail_dgrad_gemm_s: the backward mirror — part_reps > 0: part is fp32[part_reps, K, 2] (zeroed by the caller), every row
+ * tile ADDS its column sums (sum dy, sum dy (z - mu)) into row (tile % part_reps); a mi_tail_bn_bwd with nblk = part_reps
+ * over the same buffer then joins them in the next product's prologue (or mi_tail_bn_finalize_bwd does).
+ * Float-atomic order: results vary in the last bits between runs; deterministic callers use the tile-statistics forms. */
+MI_API int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
+                              float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
+                              float *part, float *a_out, int32_t M, int32_t N, int32_t K,
+                              const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
+                              const float *shift_running_mean, const float *shift_mean_offset, void *stream);
+MI_API int mi_tail_dgrad_gemm_s(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
+                                const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
+                                int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,
+                                const uint8_t *p_keep, float *OUT, int32_t ldo, float *part, int32_t part_reps,
+                                float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                                void *stream);
 MI_API int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                               const uint8_t *keep, const float *w, const float *b, const float *add, float *out,
                               int32_t M, int32_t N, const mi_tail_bn_fwd *stats, void *stream);
@@ -754,6 +788,19 @@ MI_API int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, co
                                 int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,
                                 const uint8_t *p_keep, float *OUT, int32_t ldo, float *part, float *dz_out, int32_t M,
                                 int32_t N, int32_t K, const mi_tail_bn_bwd *sums, void *stream);
+/* DeepFM: the FIRST layer's input-gradient product with the whole of mi_gather_fm_bwd_rows in its epilogue
+ * (src/models/deepfm.py:88-102 through autograd).  The tail's input is the embedding block emb[M, K = F*D]; instead of
+ * storing da = dz . W and launching the gather backward on it, the epilogue writes the lookup table's row-form gradient
+ *   gvals[m, f, :] = da[m, f*D : (f+1)*D] + g_y[m] * (emb_sum[m, :] - emb[m, f, :])       (fp32[M*F, D], == [M, K])
+ *   g1vals[m, f]   = g_y[m]                                                               (fp32[M, F], nullable)
+ * emb_sum = mi_gather_fm_fwd_sum's sum_out.  The scalar bias's gradient sum_m g_y[m] equals the head bias's (both are
+ * added to every logit): callers take it from mi_tail_bn_finalize_bwd's db.  One launch and 2 * 4 * M * K bytes (da written,
+ * da read back) less than the two-kernel form.  Other arguments as mi_tail_dgrad_gemm_m with no layer below. */
+MI_API int mi_tail_dgrad_gemm_fm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
+                                 const float *bz, const float *de, const float *W, int32_t ldw, float *gvals,
+                                 float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                                 const float *emb, const float *emb_sum, const float *g_y, float *g1vals, int32_t D,
+                                 void *stream);
 MI_API int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
                                  const int32_t *lds, uint8_t *const *bits, int32_t M, void *stream);
 /* the same launch also zero-fills zero_buf[0 .. zero_floats) (a multiple of 4 floats, 16-byte aligned): the backward pass's

@@ -20,11 +20,14 @@ _i32 = ctypes.c_int32
 
 # name -> argtypes; every entry point returns int unless listed in _RESTYPES.
 # tests/test_abi.py cross-checks this table against include/mi355x_recsys.h.
+ABI_VERSION = 3          # MI_ABI_VERSION of include/mi355x_recsys.h these bindings were written against
+
 SIGNATURES = {
     "mi_abi_version": [],
     "mi_strerror": [ctypes.c_int],
     "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_fwd_ld": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
+    "mi_gather_fm_fwd_sum": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
     "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
     "mi_gather_rows_fwd": [_p, _p, _p, _i64, _i32, _i64, _p, _p],
@@ -112,9 +115,13 @@ SIGNATURES = {
     "mi_tail_dropout_masks_z": [_p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p],
     "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_fwd_gemm_m": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p],
+    "mi_tail_fwd_gemm_s": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p],
+    "mi_tail_dgrad_gemm_s": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
+                             _i32, _p, _i32, _p, _i32, _i32, _i32, _p, _p],
     "mi_tail_head_fwd_m": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _i32, _i32, _p, _p],
     "mi_tail_dgrad_gemm_m": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
                              _i32, _p, _p, _i32, _i32, _i32, _p, _p],
+    "mi_tail_dgrad_gemm_fm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p],
     "mi_tail_part_elems": [_i32, _i32],
     "mi_tail_bn_finalize_fwd": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
                                 _p, _p],
@@ -177,7 +184,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
-        if lib.mi_abi_version() != 2:
+        if lib.mi_abi_version() != ABI_VERSION:
             raise MI355XLibraryError("libmi355x_recsys.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

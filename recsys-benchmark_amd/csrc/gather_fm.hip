@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
     const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
-    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err) {
+    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63;
@@ -108,6 +108,10 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
       }
     }
     S = slot_sum<LPR>(S);
+    // sum_f e[b, f, :] — what the FM backward needs besides the rows themselves (dE_bf = g_b (S_b - e_bf)): kept when the
+    // backward runs in the epilogue of the MLP's first input-gradient product (tail.hip), which sees a tile of 6-7 fields
+    // of a sample and cannot re-derive the sum over all F
+    if (sum_out && r == 0) st4(sum_out + b * D + q * 4, S);
     float t = (r == 0 ? dot4(S, S) : 0.f) - ss;
     t = wave_sum(0.5f * t + lin);
     if (lane == 0) yfm[b] = t + bv;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
     const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
-    int64_t B, int F, int D, int64_t N, int *err) {
+    int64_t B, int F, int D, int64_t N, int *err, float *__restrict__ sum_out) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_anyD(
           ss += v * v;
         }
       }
+      if (sum_out && d < D) sum_out[b * D + d] = S;
       t += 0.5f * (S * S - ss);
     }
     t = wave_sum(t);
@@ -562,9 +567,9 @@ inline int nit_for(int F, int LPR) {
 
 extern "C" {
 
-int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
-                        int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
-                        int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+int mi_gather_fm_fwd_sum(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                         int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out, float *sum_out,
+                         int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
   if (B < 0 || F < 0 || D <= 0 || N < 0 || ldw < D || ldw1 < 1) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!idx || !offsets || !W || !w1 || !emb_out || !yfm_out) return MI_ERR_INVALID_ARG;
@@ -574,22 +579,28 @@ int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets, const float 
     if (nit > 0 && F <= kWave) {
 #define CALL(LPR, NIT)                                                                                \
   MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT, true>), grid, kBlock, stream, idx, offsets,   \
-            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err)
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err, sum_out)
       MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
     } else {
 #define CALL(LPR, NIT)                                                                               \
   MI_LAUNCH("gather_fm_fwd", (k_gather_fm_fwd<LPR, NIT, false>), grid, kBlock, stream, idx, offsets, \
-            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err)
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err, sum_out)
       MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
     }
   } else {
     if (ldw != D || ldw1 != 1) return MI_ERR_UNSUPPORTED;      // the scalar fallback reads the reference's two tensors only
     MI_LAUNCH("gather_fm_fwd", k_gather_fm_fwd_anyD, grid, kBlock, stream, idx, offsets, W, w1,
-              bias, emb_out, yfm_out, rows_out, B, F, D, N, err);
+              bias, emb_out, yfm_out, rows_out, B, F, D, N, err, sum_out);
   }
   return launch_status();
+}
+
+int mi_gather_fm_fwd_ld(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                        int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
+                        int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, void *stream) {
+  return mi_gather_fm_fwd_sum(idx, offsets, W, ldw, w1, ldw1, bias, emb_out, yfm_out, rows_out, nullptr, B, F, D, N, err, stream);
 }
 
 int mi_gather_fm_fwd(const int64_t *idx, const int64_t *offsets, const float *W, const float *w1,
@@ -694,14 +705,14 @@ int mi_slot_fm_fwd(const int64_t *slot, const float *buf, int64_t nrows, const f
 #define CALL(LPR, NIT)                                                                                 \
   MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT, true>), grid, kBlock, stream, slot,              \
             (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr,        \
-            B, F, nrows, ld, ld, err)
+            B, F, nrows, ld, ld, err, (float *)nullptr)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   } else {
 #define CALL(LPR, NIT)                                                                               \
   MI_LAUNCH("slot_fm_fwd", (k_gather_fm_fwd<LPR, NIT, false>), grid, kBlock, stream, slot,           \
             (const int64_t *)nullptr, buf, buf + D, bias, emb_out, yfm_out, (int64_t *)nullptr,      \
-            B, F, nrows, ld, ld, err)
+            B, F, nrows, ld, ld, err, (float *)nullptr)
     MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL
   }

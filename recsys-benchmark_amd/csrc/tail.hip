@@ -126,7 +126,70 @@ struct BnFwd {           // device view of mi_tail_bn_fwd
   int64_t *nbt, *seed_bump;
   float *mu, *sc, *be, *rstd;
   float momentum, eps;
+  int nrep;              // > 0: `part` holds SHIFTED SUMS [nrep][2][N] accumulated by float atomics (below), not tile statistics
+  const float *shift;    // [N] the shift they were taken around
 };
+// ---- statistics as shifted sums (round 4) ----------------------------------------------------------------------------
+// A product's epilogue adds, per column c, t1 = sum_m (z - s_c) and t2 = sum_m (z - s_c)^2 of its 64-row tile into
+// sums[r][0][c] / sums[r][1][c] with float atomics (r = row tile % nrep: replicas spread the same-address traffic; each
+// atomic wave-instruction covers 64 consecutive floats), s_c = the layer's running mean minus the Linear bias the product
+// left out — a value near the batch mean after a few steps, and any value is algebraically exact:
+//   mean = s + t1 / M,   M2 = t2 - t1^2 / M
+// (the cancellation in M2 is of relative size (mean - s)^2 / var, which is O(1) for a BatchNorm pre-activation).  The
+// CONSUMING kernel derives mu / gamma rstd / beta from (2 nrep + 3) N floats in its prologue — 8 to 20 KB, one round trip,
+// against the 205 KB of tile statistics round 3's joined form pulled through every CU — and no finalize launch exists.
+// Float-atomic order makes the statistics vary in the last bits between runs: deterministic mode keeps the tile
+// statistics and the finalize launches.
+template <int NT>
+__device__ __forceinline__ void bn_derive_fwd(const BnFwd &b, int M, int N, float *cst, bool writer, int tid) {
+  const float inv_m = 1.f / (float)M;
+  for (int n = tid * 2; n < N; n += NT * 2) {
+    float2 t1 = make_float2(0.f, 0.f), t2 = t1;
+    for (int r = 0; r < b.nrep; ++r) {
+      const float2 a = *reinterpret_cast<const float2 *>(b.part + (int64_t)(2 * r) * N + n);
+      const float2 q = *reinterpret_cast<const float2 *>(b.part + (int64_t)(2 * r + 1) * N + n);
+      t1.x += a.x; t1.y += a.y; t2.x += q.x; t2.y += q.y;
+    }
+    const float2 sh = *reinterpret_cast<const float2 *>(b.shift + n);
+    const float2 gm2 = b.gamma ? *reinterpret_cast<const float2 *>(b.gamma + n) : make_float2(1.f, 1.f);
+    const float2 bt2 = b.beta ? *reinterpret_cast<const float2 *>(b.beta + n) : make_float2(0.f, 0.f);
+    float2 mo2 = make_float2(0.f, 0.f), rm2 = mo2, rv2 = mo2;
+    if (writer && b.running_mean) {
+      rm2 = *reinterpret_cast<const float2 *>(b.running_mean + n);
+      rv2 = *reinterpret_cast<const float2 *>(b.running_var + n);
+      if (b.mean_offset) mo2 = *reinterpret_cast<const float2 *>(b.mean_offset + n);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n + j;
+      const float s1 = j ? t1.y : t1.x, s2 = j ? t2.y : t2.x;
+      const float d = s1 * inv_m;
+      const float mean = (j ? sh.y : sh.x) + d;
+      const float m2 = fmaxf(s2 - s1 * d, 0.f);
+      const float var = m2 * inv_m;
+      const float rstd = rsqrtf(var + b.eps);
+      const float gm = j ? gm2.y : gm2.x, bt = j ? bt2.y : bt2.x;
+      cst[col] = mean;
+      cst[kCstPitch + col] = gm * rstd;
+      cst[2 * kCstPitch + col] = bt;
+      if (writer) {
+        b.mu[col] = mean;
+        b.sc[col] = gm * rstd;
+        b.be[col] = bt;
+        b.rstd[col] = rstd;
+        if (b.running_mean) {
+          b.running_mean[col] = (1.f - b.momentum) * (j ? rm2.y : rm2.x) + b.momentum * (mean + (j ? mo2.y : mo2.x));
+          const float unb = M > 1 ? m2 / (float)(M - 1) : var;
+          b.running_var[col] = (1.f - b.momentum) * (j ? rv2.y : rv2.x) + b.momentum * unb;
+        }
+      }
+    }
+  }
+  if (writer && tid == 0) {
+    if (b.nbt) b.nbt[0] += 1;
+    if (b.seed_bump) b.seed_bump[0] += 1;
+  }
+}
 // (mean, M2) of the 64-row tiles -> batch mean and variance in ONE pass with every load of a chunk in flight (a thread
 // that walks 64 tiles 8 at a time pays 8 dependent L2 round trips: measured +10 us per kernel).  The tile means are
 // shifted by tile 0's mean c before they are summed and squared (tile means differ from the grand mean by ~sigma / 8,
@@ -137,6 +200,10 @@ struct BnFwd {           // device view of mi_tail_bn_fwd
 constexpr int kMergeChunk = 32;
 template <int NT>
 __device__ __forceinline__ void bn_merge_fwd(const BnFwd &b, int M, int N, float *cst, bool writer, int tid) {
+  if (b.nrep > 0) {
+    bn_derive_fwd<NT>(b, M, N, cst, writer, tid);
+    return;
+  }
   const int MT = (M + BM - 1) / BM;
   const float inv_m = 1.f / (float)M;
   for (int n = tid * 2; n < N; n += NT * 2) {
@@ -209,20 +276,28 @@ struct BnBwd {           // device view of mi_tail_bn_bwd
 };
 // cst rows: 0 mu, 1 al, 2 bz, 3 de (the constants of LoadDz).  Two adjacent columns per thread, kMergeChunk partial rows in
 // flight.  The head's dw / db pieces are joined by ANOTHER workgroup (wwriter) so that no workgroup carries both joins.
+template <int NT, int CH>
+__device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, float *cst, bool writer, bool wwriter, int tid);
+// few partial rows (the replicas of an atomically accumulated sum, mi_tail_dgrad_gemm_s): 8 loads per trip instead of 32
 template <int NT>
 __device__ __forceinline__ void bn_merge_bwd(const BnBwd &b, int M, int N, float *cst, bool writer, bool wwriter, int tid) {
+  if (b.nblk <= 8 && (!b.wpart || b.nwblk <= 8)) bn_merge_bwd_impl<NT, 8>(b, M, N, cst, writer, wwriter, tid);
+  else bn_merge_bwd_impl<NT, kMergeChunk>(b, M, N, cst, writer, wwriter, tid);
+}
+template <int NT, int CH>
+__device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, float *cst, bool writer, bool wwriter, int tid) {
   const float inv_m = 1.f / (float)M;
   for (int n = tid * 2; n < N; n += NT * 2) {
     const float *p = b.part + (int64_t)n * 2;
     const float2 r2 = *reinterpret_cast<const float2 *>(b.rstd + n), mu2 = *reinterpret_cast<const float2 *>(b.mu + n);
     const float2 gm2 = b.gamma ? *reinterpret_cast<const float2 *>(b.gamma + n) : make_float2(1.f, 1.f);
     float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
-    for (int base = 0; base < b.nblk; base += kMergeChunk) {
-      float4 v[kMergeChunk];
+    for (int base = 0; base < b.nblk; base += CH) {
+      float4 v[CH];
 #pragma unroll
-      for (int u = 0; u < kMergeChunk; ++u) v[u] = ld4(p + (int64_t)min(base + u, b.nblk - 1) * N * 2);
+      for (int u = 0; u < CH; ++u) v[u] = ld4(p + (int64_t)min(base + u, b.nblk - 1) * N * 2);
 #pragma unroll
-      for (int u = 0; u < kMergeChunk; ++u)
+      for (int u = 0; u < CH; ++u)
         if (base + u < b.nblk) { s10 += v[u].x; s20 += v[u].y; s11 += v[u].z; s21 += v[u].w; }
     }
 #pragma unroll
@@ -246,12 +321,12 @@ __device__ __forceinline__ void bn_merge_bwd(const BnBwd &b, int M, int N, float
   if (wwriter && b.wpart) {
     for (int n = tid; n <= N; n += NT) {
       float sw = 0.f;
-      for (int base = 0; base < b.nwblk; base += kMergeChunk) {
-        float v[kMergeChunk];
+      for (int base = 0; base < b.nwblk; base += CH) {
+        float v[CH];
 #pragma unroll
-        for (int u = 0; u < kMergeChunk; ++u) v[u] = b.wpart[(int64_t)min(base + u, b.nwblk - 1) * (N + 4) + n];
+        for (int u = 0; u < CH; ++u) v[u] = b.wpart[(int64_t)min(base + u, b.nwblk - 1) * (N + 4) + n];
 #pragma unroll
-        for (int u = 0; u < kMergeChunk; ++u)
+        for (int u = 0; u < CH; ++u)
           if (base + u < b.nwblk) sw += v[u];
       }
       if (n < N) b.dw[n] = sw; else if (b.db) b.db[0] = sw;
@@ -274,6 +349,11 @@ struct FwdArgs {
   int ncols;          // columns per workgroup (multiple of 4, <= 112)
   int ntn;            // column tiles
   BnFwd bn;           // MERGE: the statistics behind x's constants, joined here (x.mu / sc / be are then not read)
+  // stat_rep > 0: `part` is the shifted-sum accumulator [stat_rep][2][N] (zeroed by the caller); the epilogue adds this
+  // tile's sums with float atomics around shift = stat_rm - stat_off (either nullable: 0) and row tile 0 stores the shift
+  int stat_rep;
+  float *stat_shift;
+  const float *stat_rm, *stat_off;
 };
 
 template <bool ACT, bool MERGE, bool DMA = false>
@@ -324,6 +404,11 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
       st4(a.Z + (int64_t)(m0 + row) * a.ldz + n0 + c, ld4(T + row * kTilePitch + c));
   }
   if (!a.part) return;
+  float stat_s = 0.f;
+  if (a.stat_rep > 0 && t < cols_valid) {
+    if (a.stat_rm) stat_s = a.stat_rm[n0 + t];
+    if (a.stat_off) stat_s -= a.stat_off[n0 + t];
+  }
   // column statistics: thread (rg = t / 128, col = t % 128) walks rows 16 rg .. 16 rg + 15 of its column with shifted
   // sums around the group's first row (a value of the column itself: no cancellation); one thread per column then
   // merges the 4 groups (Chan) — the same grouping and order for every launch: deterministic.
@@ -358,9 +443,17 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
       m2_a += m2_b + delta * delta * (n_a * n_b / n);
       n_a = n;
     }
-    float *o = a.part + ((int64_t)mt * a.N + n0 + t) * 2;
-    o[0] = mean_a;
-    o[1] = m2_a;
+    if (a.stat_rep > 0) {
+      const float d = mean_a - stat_s;
+      float *o = a.part + (int64_t)((mt % a.stat_rep) * 2) * a.N + n0 + t;
+      atomicAdd(o, n_a * d);
+      atomicAdd(o + a.N, fmaf(n_a * d, d, m2_a));
+      if (mt == 0) a.stat_shift[n0 + t] = stat_s;
+    } else {
+      float *o = a.part + ((int64_t)mt * a.N + n0 + t) * 2;
+      o[0] = mean_a;
+      o[1] = m2_a;
+    }
   }
 }
 
@@ -656,13 +749,22 @@ struct DgradArgs {
   float *OUT;         // [M, K] dy_prev or da_prev
   int ldo;
   float *part;        // [MT, K, 2] (sum dy, sum dy (z - mu)), nullable
+  int part_rep;       // > 0: part is [part_rep, K, 2], zeroed by the caller; row tile mt ADDS into row mt % part_rep (atomics)
   float *dz_out;      // [M, N] (pitch dz.ld), nullable: dz as the operand load computed it
   int M, N, K;
   int ncols, ntn;     // column tiles over K
   BnBwd bn;           // MERGE: the column sums behind dz's constants, joined here (dz.al / bz / de are then not read)
+  // FM: the tail's input is DeepFM's embedding block emb[M, F*D] and OUT is the row-form gradient of the lookup table
+  // (src/models/deepfm.py:88-98 through autograd): OUT[m, f*D + d] = da[m, f*D + d] + gy[m] * (S[m, d] - emb[m, f*D + d]),
+  // g1[m, f] = gy[m] — the whole of mi_gather_fm_bwd_rows in this epilogue, da never stored
+  const float *fm_emb;   // [M, K] saved rows (pitch K)
+  const float *fm_sum;   // [M, fm_D] sum over the fields (mi_gather_fm_fwd_sum)
+  const float *fm_gy;    // [M] dL/d y_fm
+  float *fm_g1;          // [M, K / fm_D] first-order gradient values (nullable)
+  int fm_D;
 };
 
-template <bool DZ, bool MID, bool MERGE>
+template <bool DZ, bool MID, bool MERGE, bool FM = false>
 __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + (MERGE ? kCstFloats : 0)];
   const int mt_total = (a.M + BM - 1) / BM;
@@ -697,7 +799,40 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   acc_to_lds(acc, T, wave, lane);
   __syncthreads();
   const int t = threadIdx.x;
-  if constexpr (!MID) {
+  if constexpr (FM) {
+    static_assert(!MID, "the FM epilogue belongs to the product whose output is the tail's input gradient");
+    // all loads of the thread's four chunks first (saved rows from HBM / Infinity Cache, sums and gy from L2), then the
+    // arithmetic: one round trip for the epilogue
+    float4 e[4], sm[4], da[4];
+    float gy[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
+      ok[k] = i < 64 * 28 && row < rows_valid && c < cols_valid;
+      const int m = m0 + (ok[k] ? row : 0), kc = k0 + (ok[k] ? c : 0);
+      e[k] = ld4(a.fm_emb + (int64_t)m * a.K + kc);
+      sm[k] = ld4(a.fm_sum + (int64_t)m * a.fm_D + kc % a.fm_D);
+      gy[k] = a.fm_gy[m];
+      da[k] = ld4(T + (ok[k] ? row : 0) * kTilePitch + (ok[k] ? c : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
+      if (ok[k]) {
+        float4 o;
+        o.x = da[k].x + gy[k] * (sm[k].x - e[k].x);
+        o.y = da[k].y + gy[k] * (sm[k].y - e[k].y);
+        o.z = da[k].z + gy[k] * (sm[k].z - e[k].z);
+        o.w = da[k].w + gy[k] * (sm[k].w - e[k].w);
+        st4(a.OUT + (int64_t)(m0 + row) * a.ldo + k0 + c, o);
+      }
+    }
+    if (a.fm_g1 && nt == 0) {      // the first-order table's gradient values of this row tile: gy[m] for every field
+      const int F = a.K / a.fm_D;
+      for (int i = t; i < rows_valid * F; i += kThreads) a.fm_g1[(int64_t)m0 * F + i] = a.fm_gy[m0 + i / F];
+    }
+  } else if constexpr (!MID) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
@@ -752,8 +887,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 18; ++q) { s1 += ws[(q * BNT + t) * 2]; s2 += ws[(q * BNT + t) * 2 + 1]; }
-      float *o = a.part + ((int64_t)mt * a.K + k0 + t) * 2;
-      o[0] = s1; o[1] = s2;
+      if (a.part_rep > 0) {
+        float *o = a.part + ((int64_t)(mt % a.part_rep) * a.K + k0 + t) * 2;
+        atomicAdd(o, s1);
+        atomicAdd(o + 1, s2);
+      } else {
+        float *o = a.part + ((int64_t)mt * a.K + k0 + t) * 2;
+        o[0] = s1; o[1] = s2;
+      }
     }
   }
 }
@@ -839,15 +980,25 @@ extern "C" {
 static bool bn_fwd_view(const mi_tail_bn_fwd *m, BnFwd *out) {
   if (!m->part || !aligned16(m->part) || !m->mu || !m->sc || !m->be || !m->rstd) return false;
   if ((m->running_mean == nullptr) != (m->running_var == nullptr)) return false;
+  if (m->nrep < 0 || m->nrep > 64 || (m->nrep > 0 && !m->shift)) return false;
   *out = BnFwd{m->part, m->gamma, m->beta, m->mean_offset, m->running_mean, m->running_var, m->num_batches_tracked,
-               m->seed_bump, m->mu, m->sc, m->be, m->rstd, m->momentum, m->eps};
+               m->seed_bump, m->mu, m->sc, m->be, m->rstd, m->momentum, m->eps, m->nrep, m->shift};
   return true;
 }
 
 int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
                        const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
                        int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, void *stream) {
+  return mi_tail_fwd_gemm_s(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, x_stats, 0, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                       const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                       int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
+                       const float *shift_running_mean, const float *shift_mean_offset, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
+  if (sum_reps < 0 || sum_reps > 64 || (sum_reps > 0 && (!part || !shift_out))) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !W || !Z) return MI_ERR_INVALID_ARG;
   if (!vec_ok(X, ldx) || !vec_ok(W, ldw) || !vec_ok(Z, ldz) || N % 4 || K % 4) return MI_ERR_UNSUPPORTED;
@@ -862,6 +1013,7 @@ int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const flo
   if (x_mu && x_p > 0.f && (!x_keep || ldx % 8)) return MI_ERR_INVALID_ARG;
   a.x = ActDesc{X, ldx, x_mu, x_sc, x_be, x_p, x_keep};
   a.W = W; a.ldw = ldw; a.Z = Z; a.ldz = ldz; a.part = part;
+  a.stat_rep = sum_reps; a.stat_shift = shift_out; a.stat_rm = shift_running_mean; a.stat_off = shift_mean_offset;
   if (a_out && (!x_mu || !aligned16(a_out))) return MI_ERR_INVALID_ARG;      // only a transformed operand has anything to keep
   a.a_out = a_out;
   a.M = M; a.N = N; a.K = K;
@@ -1021,15 +1173,54 @@ int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t 
   return launch_status();
 }
 
+static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                        const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
+                        const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
+                        float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                        const float *fm_emb, const float *fm_sum, const float *fm_gy, float *fm_g1, int32_t fm_D,
+                        int32_t part_reps, void *stream);
+
 int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
                          const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
                          const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
                          float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
                          void *stream) {
+  return dgrad_launch(DY, Zl, ld, mu, al, bz, de, W, ldw, pZ, pld, p_mu, p_sc, p_be, p_p, p_keep, OUT, ldo, part, dz_out, M, N,
+                      K, sums, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+int mi_tail_dgrad_gemm_s(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                         const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
+                         const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
+                         float *part, int32_t part_reps, float *dz_out, int32_t M, int32_t N, int32_t K,
+                         const mi_tail_bn_bwd *sums, void *stream) {
+  if (part_reps < 0 || part_reps > 64 || (part_reps > 0 && !part)) return MI_ERR_INVALID_ARG;
+  return dgrad_launch(DY, Zl, ld, mu, al, bz, de, W, ldw, pZ, pld, p_mu, p_sc, p_be, p_p, p_keep, OUT, ldo, part, dz_out, M, N,
+                      K, sums, nullptr, nullptr, nullptr, nullptr, 0, part_reps, stream);
+}
+
+int mi_tail_dgrad_gemm_fm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                          const float *de, const float *W, int32_t ldw, float *gvals, float *dz_out, int32_t M, int32_t N,
+                          int32_t K, const mi_tail_bn_bwd *sums, const float *emb, const float *emb_sum, const float *g_y,
+                          float *g1vals, int32_t D, void *stream) {
+  if (!emb || !emb_sum || !g_y || D <= 0 || D % 4 || K % D) return MI_ERR_INVALID_ARG;
+  if (!aligned16(emb) || !aligned16(emb_sum)) return MI_ERR_UNSUPPORTED;
+  return dgrad_launch(DY, Zl, ld, mu, al, bz, de, W, ldw, nullptr, K, nullptr, nullptr, nullptr, 0.f, nullptr, gvals, K,
+                      nullptr, dz_out, M, N, K, sums, emb, emb_sum, g_y, g1vals, D, 0, stream);
+}
+
+static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                        const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
+                        const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
+                        float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                        const float *fm_emb, const float *fm_sum, const float *fm_gy, float *fm_g1, int32_t fm_D,
+                        int32_t part_reps, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!DY || !W || !OUT) return MI_ERR_INVALID_ARG;
   DgradArgs a;
+  a.part_rep = part_reps;
+  a.fm_emb = fm_emb; a.fm_sum = fm_sum; a.fm_gy = fm_gy; a.fm_g1 = fm_g1; a.fm_D = fm_D;
   a.bn = BnBwd{};
   if (sums) {               // al / bz / de are joined from the column sums in the kernel's prologue and written to sums->al ...
     if (N > kCstPitch) return MI_ERR_UNSUPPORTED;
@@ -1054,6 +1245,13 @@ int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, const flo
   a.ncols = cols_per_tile(K, &a.ntn);
   const int tiles = ((M + BM - 1) / BM) * a.ntn;
   const bool dz = al != nullptr, mid = p_mu != nullptr;
+  if (fm_emb) {
+    if (mid) return MI_ERR_INVALID_ARG;
+    if (sums) MI_LAUNCH("tail_dgrad_gemm_fm", (k_tail_dgrad<true, false, true, true>), grid8(tiles), kThreads, stream, a);
+    else if (dz) MI_LAUNCH("tail_dgrad_gemm_fm", (k_tail_dgrad<true, false, false, true>), grid8(tiles), kThreads, stream, a);
+    else MI_LAUNCH("tail_dgrad_gemm_fm", (k_tail_dgrad<false, false, false, true>), grid8(tiles), kThreads, stream, a);
+    return launch_status();
+  }
   if (sums && mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, true, true>), grid8(tiles), kThreads, stream, a);
   else if (sums) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, false, true>), grid8(tiles), kThreads, stream, a);
   else if (dz && mid) MI_LAUNCH("tail_dgrad_gemm", (k_tail_dgrad<true, true, false>), grid8(tiles), kThreads, stream, a);

@@ -134,8 +134,37 @@ class DeepFM(nn.Module):
         return _kernels.fm_first_order(emb, rows, self.fc.weight, self._bias,
                                        sparse_w1=bool(self.fc.sparse))
 
+    def _fused_step(self, x):
+        """The whole forward as one autograd node (tail.DeepFMFusedFn) when the pieces fit: the full table with row-form
+        gradients (or deterministic mode, which builds its dense gradients from row-form values too) in front of a tail the
+        fused kernels take.  The lookup's backward then runs in the epilogue of the tail's first input-gradient product.
+        None: the two-node path below."""
+        from . import mlp as _mlp, tail as _tail
+
+        emb_mod = getattr(self, "embedding", None)
+        if not (_mlp.FUSED_TAIL and _tail.FM_EPILOGUE and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
+                and type(emb_mod) is VanillaEmbedding and emb_mod._mode is None):
+            return None
+        W, w1 = emb_mod.get_weight(), self.fc.weight
+        sparse_W, sparse_w1 = bool(emb_mod.sparse_grad), bool(self.fc.sparse)
+        if (not _kernels._float4_rows(W.shape[1]) or W.dtype != torch.float32 or W.device != x.device
+                or x.shape[1] != self.offsets.numel()):
+            return None
+        wants = W.requires_grad or w1.requires_grad
+        if not ((sparse_W and W.requires_grad) or (sparse_w1 and w1.requires_grad) or (_kernels.DETERMINISTIC and wants)):
+            return None              # dense weight.grad by float atomics: the scatter kernel of the two-node path
+        groups = _mlp._groups(self._deep_branch)
+        plan = _tail.fused_tail_plan(self._deep_branch, _tail._InputSpec(x.shape[0], x.shape[1] * W.shape[1], W.device), groups)
+        if plan is None:
+            return None
+        return _tail.run_fused_deepfm(plan, groups[-1][1], _mlp._seed_word(W.device), x, self.offsets, W, w1, self._bias,
+                                      sparse_W, sparse_w1)
+
     def forward(self, x):
         """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
+        fused = self._fused_step(x)
+        if fused is not None:
+            return fused.squeeze(-1)
         emb, y_fm = self._fm_and_embedding(x)
         b = emb.shape[0]
         scores = run_tail(self._deep_branch, emb.reshape(b, -1), last_add=y_fm)   # y_fm + deep(emb)

@@ -41,12 +41,19 @@ MERGE_JOINS = os.environ.get("MI_TAIL_MERGE_JOINS", "0") == "1"
 # The step's dropout keep bits + the zero fill of the backward pass's accumulation buffer as extra workgroups of the first
 # layer's finalize launch instead of a launch of their own (MI_TAIL_RIDE_MASKS=0: the separate launch).
 RIDE_MASKS = os.environ.get("MI_TAIL_RIDE_MASKS", "1") == "1"
+# Round 4: BatchNorm statistics (forward) and the dgamma / dbeta column sums (backward) as SUMS the producing product's
+# epilogue adds with float atomics into a few replicas of 2 N floats, derived into constants by the consuming product's
+# prologue from 8-20 KB (csrc/tail.hip, bn_derive_fwd) — no finalize launch between two products.  Two finalize launches
+# per step remain: the first forward layer's (it carries the dropout-bit / zero-fill workgroups) and the head's backward
+# (it joins the head's dw / db).  Off in deterministic mode (atomic order), off with MI_TAIL_STAT_SUMS=0 (the round-3 form).
+STAT_SUMS = os.environ.get("MI_TAIL_STAT_SUMS", "1") == "1"
+STAT_REPS = max(1, min(64, int(os.environ.get("MI_TAIL_STAT_REPS", "4"))))
 
 
 class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys.h)
     _fields_ = [(n, ctypes.c_void_p) for n in ("part", "gamma", "beta", "mean_offset", "running_mean", "running_var",
                                                "num_batches_tracked", "seed_bump", "mu", "sc", "be", "rstd")] + \
-               [("momentum", ctypes.c_float), ("eps", ctypes.c_float)]
+               [("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("shift", ctypes.c_void_p), ("nrep", ctypes.c_int32)]
 
 
 class _BnBwd(ctypes.Structure):          # mi_tail_bn_bwd
@@ -60,11 +67,11 @@ class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
                 ("zero_floats", ctypes.c_int64)]
 
 
-def _bn_fwd_struct(part, L, c, seed_bump) -> "_BnFwd":
+def _bn_fwd_struct(part, L, c, seed_bump, shift=None, nrep=0) -> "_BnFwd":
     bn = L.bn
     return _BnFwd(part.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), seed_bump, c[0].data_ptr(), c[1].data_ptr(),
-                  c[2].data_ptr(), c[3].data_ptr(), float(bn.momentum), float(bn.eps))
+                  c[2].data_ptr(), c[3].data_ptr(), float(bn.momentum), float(bn.eps), _lib.ptr(shift), int(nrep))
 
 
 class _Layer:
@@ -74,8 +81,19 @@ class _Layer:
         self.lin, self.bn, self.p = lin, bn, p
 
 
-def fused_tail_plan(seq: nn.Sequential, x: torch.Tensor, groups) -> Optional[List[_Layer]]:
-    """groups: mlp._groups(seq).  The plan (hidden layers; the head is groups[-1]) or None when the pattern does not fit."""
+class _InputSpec:
+    """Stands in for the tail's input tensor when the plan is made before that tensor exists (DeepFM's fused step)."""
+
+    def __init__(self, rows: int, width: int, device):
+        self.shape, self.device, self.dtype, self.is_cuda = (rows, width), device, torch.float32, device.type == "cuda"
+
+    def dim(self):
+        return 2
+
+
+def fused_tail_plan(seq: nn.Sequential, x, groups) -> Optional[List[_Layer]]:
+    """groups: mlp._groups(seq); x: the input tensor or an _InputSpec.  The plan (hidden layers; the head is groups[-1]) or
+    None when the pattern does not fit."""
     if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
         return None
     if len(groups) < 2 or groups[-1][0] != "plain" or len(groups) - 1 > 8:      # (the mask kernel takes <= 8 layers)
@@ -114,7 +132,7 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Option
     lib = _lib.load()
     n = len(plan)
     bits = [torch.empty(M * L.lin.out_features // 8, dtype=torch.uint8, device=dev) if L.p > 0 else None for L in plan]
-    if not any(b is not None for b in bits):
+    if not any(b is not None for b in bits) and (zero_buf is None or not ride):
         return (bits, None) if ride else bits
     salts = (ctypes.c_int64 * n)(*[SALT * (i + 1) for i in range(n)])
     ps = (ctypes.c_float * n)(*[L.p for L in plan])
@@ -131,6 +149,241 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Option
     return bits
 
 
+class _State:
+    """What the forward leaves for the backward: tensors (flattened for ctx.save_for_backward) + plain metadata."""
+    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat", "zsize", "boff")
+
+
+def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
+    """The forward kernels of the tail; returns (out[M, 1], tensors to save, state)."""
+    lib = _lib.load()
+    dev = _lib.require_gpu(x)
+    s = _lib.stream_ptr(dev)
+    M = x.shape[0]
+    k = len(plan)
+    # the backward pass's accumulation buffer (split-K weight gradients + the exactly-zero Linear bias gradients) is
+    # zero-filled by the mask launch of THIS forward when there is one: no fill launch in the backward
+    zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
+    zsize = (zsize + 3) // 4 * 4
+    merge = MERGE_JOINS
+    R = STAT_REPS
+    stat = STAT_SUMS and not merge and not _kernels.DETERMINISTIC and k >= 2
+    foff, boff = {}, {}                 # float offsets of the forward sums of layer i >= 1 / the backward sums of layer i <= k-2
+    if stat:
+        for i in range(1, k):
+            foff[i] = zsize
+            zsize += R * 2 * plan[i].lin.out_features
+        for i in range(k - 1):
+            boff[i] = zsize
+            zsize += R * 2 * plan[i].lin.out_features
+    zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if (stat or any(L.p > 0 for L in plan)) else None
+    # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that
+    # launch exists and a LATER kernel can advance the seed
+    ride = RIDE_MASKS and not merge and k >= 2
+    bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
+    if stat and job is None:            # (MI_TAIL_RIDE_MASKS=0: the mask launch filled it only if there are bits to draw)
+        if not any(b is not None for b in bits):
+            zeros.zero_()
+    keep_inputs = not _kernels.DETERMINISTIC
+    Zs, consts, acts = [], [], []
+    prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
+    any_bits = any(b is not None for b in bits)
+    bump_at = 1 if job is not None else 0
+    pending = None            # (part, layer, constants[, shift]) of the layer whose statistics the next kernel joins
+    bumped = False
+
+    def pending_struct():
+        nonlocal bumped
+        bump = seed.data_ptr() if (any_bits and not bumped) else None
+        bumped = bumped or bump is not None
+        if len(pending) == 4:
+            return _bn_fwd_struct(pending[0], pending[1], pending[2], bump, shift=pending[3], nrep=R)
+        return _bn_fwd_struct(pending[0], pending[1], pending[2], bump)
+
+    for i, L in enumerate(plan):
+        N, K = L.lin.out_features, L.lin.in_features
+        Z = torch.empty((M, N), dtype=torch.float32, device=dev)
+        sums_here = stat and i >= 1       # this product adds shifted sums; the NEXT kernel derives the constants
+        if sums_here:
+            part = zeros[foff[i]: foff[i] + R * 2 * N]
+            shift = torch.empty((N,), dtype=torch.float32, device=dev)
+        else:
+            part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
+            shift = None
+        c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
+        # the layer's input activation as its operand load computes it, kept for the weight gradient (not in
+        # deterministic mode, whose weight-gradient kernel recomputes it)
+        a_in = torch.empty((M, K), dtype=torch.float32, device=dev) if (keep_inputs and prev_c is not None) else None
+        stats = pending_struct() if pending is not None else None
+        bn = L.bn
+        _lib.check(lib.mi_tail_fwd_gemm_s(
+            prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
+            _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
+            float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), _lib.ptr(a_in),
+            M, N, K, ctypes.byref(stats) if stats is not None else None, R if sums_here else 0, _lib.ptr(shift),
+            bn.running_mean.data_ptr() if sums_here else None, _lib.ptr(L.lin.bias) if sums_here else None, s),
+            "mi_tail_fwd_gemm_s")
+        acts.append(a_in if a_in is not None else x.new_empty(0))
+        if sums_here:
+            pending = (part, L, c, shift)
+        elif merge:
+            pending = (part, L, c)
+        else:
+            pending = None
+            late_bump = stat or i != bump_at       # (stat: the first deriving kernel advances the seed)
+            _lib.check(lib.mi_tail_bn_finalize_fwd_r(
+                part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (any_bits and not late_bump) else None,
+                c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
+                ctypes.byref(job[0]) if (i == 0 and job is not None) else None, s), "mi_tail_bn_finalize_fwd_r")
+            bumped = bumped or (any_bits and not late_bump)
+        Zs.append(Z)
+        consts.append(c)
+        prev, prev_c, prev_p, prev_bits = Z, c, L.p, bits[i]
+    out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    add = None if last_add is None else _kernels._f32c(last_add).view(-1)
+    N = plan[-1].lin.out_features
+    stats = pending_struct() if pending is not None else None
+    _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
+                                      float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
+                                      out.data_ptr(), M, N, ctypes.byref(stats) if stats is not None else None, s),
+               "mi_tail_head_fwd_m")
+    st = _State()
+    st.k, st.plan, st.zeros = k, plan, zeros
+    st.stat, st.zsize, st.boff = stat, zsize, boff
+    st.ps = [L.p for L in plan]
+    st.has_head_bias = b_head is not None
+    st.add_shape = None if last_add is None else tuple(last_add.shape)
+    saved = [x, w_head, *Ws, *Zs, *consts, *[b if b is not None else x.new_empty(0) for b in bits],
+             *[L.bn.weight for L in plan], *acts]
+    st.n_saved = len(saved)
+    return out, saved, st
+
+
+def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=None):
+    """The backward kernels of the tail.  need_params[j]: whether parameter j of (W, b, gamma, beta) x k + (w, b)_head wants
+    a gradient.  fm (DeepFM, the tail's input is the embedding block): (emb_sum[M, D], g1vals[M, F] or None, D) — the first
+    layer's input-gradient product then writes the lookup table's row-form gradient instead of dx (mi_tail_dgrad_gemm_fm)
+    and the returned dx IS that [M, F*D] buffer.  Returns (dx, dadd, grads, db_head)."""
+    lib = _lib.load()
+    k, plan = st.k, st.plan
+    x, w_head = saved[0], saved[1]
+    Ws, Zs, consts = saved[2:2 + k], saved[2 + k:2 + 2 * k], saved[2 + 2 * k:2 + 3 * k]
+    bits = [b if b.numel() else None for b in saved[2 + 3 * k:2 + 4 * k]]
+    gammas = saved[2 + 4 * k:2 + 5 * k]
+    acts = [a if a.numel() else None for a in saved[2 + 5 * k:2 + 6 * k]]
+    dev = x.device
+    s = _lib.stream_ptr(dev)
+    M = x.shape[0]
+    gvec = _kernels._f32c(g).view(M)
+    later = []           # weight-gradient products for ONE launch at the end
+    # one zero-filled buffer for everything that must start at zero: the split-K weight gradients and the (exactly zero)
+    # gradients of the hidden Linear biases — one fill launch instead of 2k
+    sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
+    zeros = st.zeros                       # filled by the forward's mask launch; a second backward needs a fresh one
+    st.zeros = None
+    if zeros is None:
+        zeros = torch.zeros((max(st.zsize, sum(a + b for a, b in sizes)),), dtype=torch.float32, device=dev)
+    stat, R = st.stat, STAT_REPS
+    zoff = [0]
+    for a, b in sizes:
+        zoff.append(zoff[-1] + a + b)
+    grads: List[Optional[torch.Tensor]] = [None] * (4 * k + 2)
+
+    # ---- head: dy of the last hidden layer, its column sums, dw / db of the head
+    N = Zs[-1].shape[1]
+    c = consts[-1]
+    nblk = int(lib.mi_tail_head_blocks(M))
+    DY = torch.empty((M, N), dtype=torch.float32, device=dev)
+    part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
+    wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
+    _lib.check(lib.mi_tail_head_bwd(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(st.ps[-1]),
+                                    _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
+                                    wpart.data_ptr(), M, N, s), "mi_tail_head_bwd")
+    dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
+    db_head = torch.empty((1,), dtype=torch.float32, device=dev)
+    part_rows, wp, nw = nblk, wpart, nblk
+    dx = None
+    for i in range(k - 1, -1, -1):
+        N, K = Zs[i].shape[1], Ws[i].shape[1]
+        c = consts[i]
+        dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
+        dzc = torch.empty((3, N), dtype=torch.float32, device=dev)         # al, bz, de
+        below = Zs[i - 1] if i > 0 else x
+        bc = consts[i - 1] if i > 0 else None
+        bp = st.ps[i - 1] if i > 0 else 0.0
+        bb = bits[i - 1] if i > 0 else None
+        runs_dgrad = i > 0 or need_x
+        # the column sums behind dz's constants: joined in the input-gradient product's prologue, or (no such product
+        # for this layer, or MERGE_JOINS off) by the finalize launch
+        sums = None
+        if (MERGE_JOINS or stat) and runs_dgrad and part_rows <= 128:     # (the head's 256 partial rows keep their finalize launch)
+            sums = _BnBwd(part.data_ptr(), gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                          dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp),
+                          dw_head.data_ptr() if wp is not None else None, db_head.data_ptr() if wp is not None else None,
+                          part_rows, nw)
+        else:
+            _lib.check(lib.mi_tail_bn_finalize_bwd(
+                part.data_ptr(), part_rows, M, N, gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp), nw, dw_head.data_ptr() if wp is not None else None,
+                db_head.data_ptr() if wp is not None else None, s), "mi_tail_bn_finalize_bwd")
+        wp = None
+        grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
+        if need_params[4 * i + 1] and plan[i].lin.bias is not None:
+            grads[4 * i + 1] = zeros[zoff[i] + N * K: zoff[i + 1]]     # exact: the batch mean is removed
+        a_in = x if i == 0 else acts[i]
+        defer = need_params[4 * i] and runs_dgrad and a_in is not None and not _kernels.DETERMINISTIC
+        dz_keep = torch.empty((M, N), dtype=torch.float32, device=dev) if defer else None
+        layer_DY = DY
+        if runs_dgrad:
+            OUT = torch.empty((M, K), dtype=torch.float32, device=dev)
+            if i > 0 and stat:             # the layer below's column sums: added into R zeroed rows (float atomics)
+                npart = zeros[st.boff[i - 1]: st.boff[i - 1] + R * 2 * K]
+            else:
+                npart = torch.empty(int(lib.mi_tail_part_elems(M, K)), dtype=torch.float32, device=dev) if i > 0 else None
+            if i == 0 and fm is not None:
+                emb_sum, g1vals, D = fm
+                _lib.check(lib.mi_tail_dgrad_gemm_fm(
+                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                    Ws[i].data_ptr(), K, OUT.data_ptr(), _lib.ptr(dz_keep), M, N, K,
+                    ctypes.byref(sums) if sums is not None else None, x.data_ptr(), emb_sum.data_ptr(), gvec.data_ptr(),
+                    _lib.ptr(g1vals), D, s), "mi_tail_dgrad_gemm_fm")
+            else:
+                _lib.check(lib.mi_tail_dgrad_gemm_s(
+                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                    Ws[i].data_ptr(), K, below.data_ptr() if i > 0 else None, K, _lib.ptr(bc[0]) if bc is not None else None,
+                    _lib.ptr(bc[1]) if bc is not None else None, _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb),
+                    OUT.data_ptr(), K, _lib.ptr(npart), R if (stat and i > 0) else 0, _lib.ptr(dz_keep), M, N, K,
+                    ctypes.byref(sums) if sums is not None else None, s), "mi_tail_dgrad_gemm_s")
+        # the weight gradient comes AFTER the input-gradient product: in the joined form that product's workgroup 0 is
+        # what writes al / bz / de
+        if defer:
+            dW = zeros[zoff[i]: zoff[i] + N * K].view(N, K)               # split-K slices meet in atomics
+            later.append(dict(A=dz_keep, B=a_in, C=dW, M=N, N=K, K=M, lda=N, ldb=K, ldc=K))   # dW = dz^T a_in
+            grads[4 * i] = dW
+        elif need_params[4 * i]:
+            splits = int(lib.mi_tail_wgrad_splits(M, N, K))
+            slab = torch.empty((splits, N, K), dtype=torch.float32, device=dev)
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            _lib.check(lib.mi_tail_wgrad_gemm(
+                layer_DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                below.data_ptr(), K, _lib.ptr(bc[0]) if bc is not None else None, _lib.ptr(bc[1]) if bc is not None else None,
+                _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb), slab.data_ptr(), dW.data_ptr(), M, N, K, s),
+                "mi_tail_wgrad_gemm")
+            grads[4 * i] = dW
+        if runs_dgrad:
+            if i > 0:
+                DY, part, part_rows = OUT, npart, (R if stat else (M + 63) // 64)
+            else:
+                dx = OUT
+    _kernels.gemm_multi(later, transA=True)
+    grads[4 * k] = dw_head
+    grads[4 * k + 1] = db_head if st.has_head_bias else None
+    dadd = gvec.view(st.add_shape) if (st.add_shape is not None and need_add) else None
+    return dx, dadd, grads, db_head
+
+
 class FusedTailFn(torch.autograd.Function):
     """out[M, 1] = head(a_k) + last_add, a_l = dropout(relu(bn(a_{l-1} W_l^T + b_l))).
 
@@ -141,188 +394,84 @@ class FusedTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, head, seed, x, last_add, *params):
-        lib = _lib.load()
-        dev = _lib.require_gpu(x)
-        s = _lib.stream_ptr(dev)
-        x = _kernels._f32c(x)
-        M = x.shape[0]
         k = len(plan)
+        x = _kernels._f32c(x)
         Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
         w_head = _kernels._f32c(params[4 * k]).view(-1)
-        b_head = params[4 * k + 1]
-        # the backward pass's accumulation buffer (split-K weight gradients + the exactly-zero Linear bias gradients) is
-        # zero-filled by the mask launch of THIS forward when there is one: no fill launch in the backward
-        zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
-        zsize = (zsize + 3) // 4 * 4
-        zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if any(L.p > 0 for L in plan) else None
-        # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that
-        # launch exists and a LATER finalize launch can advance the seed
-        merge = MERGE_JOINS
-        ride = RIDE_MASKS and not merge and k >= 2
-        bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
-        ctx.zeros = zeros
-        keep_inputs = not _kernels.DETERMINISTIC
-        Zs, consts, acts = [], [], []
-        prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
-        any_bits = any(b is not None for b in bits)
-        bump_at = 1 if job is not None else 0
-        pending = None            # (part, layer, constants) of the layer whose statistics the next kernel joins
-        for i, L in enumerate(plan):
-            N, K = L.lin.out_features, L.lin.in_features
-            Z = torch.empty((M, N), dtype=torch.float32, device=dev)
-            part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
-            c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
-            # the layer's input activation as its operand load computes it, kept for the weight gradient (not in
-            # deterministic mode, whose weight-gradient kernel recomputes it)
-            a_in = torch.empty((M, K), dtype=torch.float32, device=dev) if (keep_inputs and prev_c is not None) else None
-            stats = None
-            if pending is not None:
-                stats = _bn_fwd_struct(pending[0], pending[1], pending[2], seed.data_ptr() if (i == 1 and any_bits) else None)
-            _lib.check(lib.mi_tail_fwd_gemm_m(
-                prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
-                _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
-                float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), _lib.ptr(a_in),
-                M, N, K, ctypes.byref(stats) if stats is not None else None, s), "mi_tail_fwd_gemm_m")
-            acts.append(a_in if a_in is not None else x.new_empty(0))
-            if merge:
-                pending = (part, L, c)
-            else:
-                bn = L.bn
-                _lib.check(lib.mi_tail_bn_finalize_fwd_r(
-                    part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
-                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                    bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (i == bump_at and any_bits) else None,
-                    c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
-                    ctypes.byref(job[0]) if (i == 0 and job is not None) else None, s), "mi_tail_bn_finalize_fwd_r")
-            Zs.append(Z)
-            consts.append(c)
-            prev, prev_c, prev_p, prev_bits = Z, c, L.p, bits[i]
-        out = torch.empty((M, 1), dtype=torch.float32, device=dev)
-        add = None if last_add is None else _kernels._f32c(last_add).view(-1)
-        N = plan[-1].lin.out_features
-        stats = None
-        if pending is not None:
-            stats = _bn_fwd_struct(pending[0], pending[1], pending[2], seed.data_ptr() if (k == 1 and any_bits) else None)
-        _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
-                                          float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
-                                          out.data_ptr(), M, N, ctypes.byref(stats) if stats is not None else None, s),
-                   "mi_tail_head_fwd_m")
-        ctx.plan, ctx.k = plan, k
-        ctx.ps = [L.p for L in plan]
-        ctx.has_head_bias = b_head is not None
-        ctx.add_shape = None if last_add is None else tuple(last_add.shape)
-        ctx.save_for_backward(x, w_head, *Ws, *Zs, *consts, *[b if b is not None else x.new_empty(0) for b in bits],
-                              *[L.bn.weight for L in plan], *acts)
+        out, saved, st = _tail_forward(plan, seed, x, last_add, Ws, w_head, params[4 * k + 1])
+        ctx.st = st
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
-        k, plan = ctx.k, ctx.plan
-        saved = ctx.saved_tensors
-        x, w_head = saved[0], saved[1]
-        Ws, Zs, consts = saved[2:2 + k], saved[2 + k:2 + 2 * k], saved[2 + 2 * k:2 + 3 * k]
-        bits = [b if b.numel() else None for b in saved[2 + 3 * k:2 + 4 * k]]
-        gammas = saved[2 + 4 * k:2 + 5 * k]
-        acts = [a if a.numel() else None for a in saved[2 + 5 * k:2 + 6 * k]]
-        dev = x.device
-        s = _lib.stream_ptr(dev)
-        M = x.shape[0]
-        gvec = _kernels._f32c(g).view(M)
-        later = []           # weight-gradient products for ONE launch at the end
-        # one zero-filled buffer for everything that must start at zero: the split-K weight gradients and the (exactly zero)
-        # gradients of the hidden Linear biases — one fill launch instead of 2k
-        sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
-        zeros = ctx.zeros                      # filled by the forward's mask launch; a second backward needs a fresh one
-        ctx.zeros = None
-        if zeros is None:
-            zeros = torch.zeros((sum(a + b for a, b in sizes),), dtype=torch.float32, device=dev)
-        zoff = [0]
-        for a, b in sizes:
-            zoff.append(zoff[-1] + a + b)
         need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, *params)
-        grads: List[Optional[torch.Tensor]] = [None] * (4 * k + 2)
-
-        # ---- head: dy of the last hidden layer, its column sums, dw / db of the head
-        N = Zs[-1].shape[1]
-        c = consts[-1]
-        nblk = int(lib.mi_tail_head_blocks(M))
-        DY = torch.empty((M, N), dtype=torch.float32, device=dev)
-        part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
-        wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_tail_head_bwd(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(ctx.ps[-1]),
-                                        _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
-                                        wpart.data_ptr(), M, N, s), "mi_tail_head_bwd")
-        dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
-        db_head = torch.empty((1,), dtype=torch.float32, device=dev)
-        part_rows, wp, nw = nblk, wpart, nblk
-        dx = None
-        for i in range(k - 1, -1, -1):
-            N, K = Zs[i].shape[1], Ws[i].shape[1]
-            c = consts[i]
-            dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
-            dzc = torch.empty((3, N), dtype=torch.float32, device=dev)         # al, bz, de
-            below = Zs[i - 1] if i > 0 else x
-            bc = consts[i - 1] if i > 0 else None
-            bp = ctx.ps[i - 1] if i > 0 else 0.0
-            bb = bits[i - 1] if i > 0 else None
-            runs_dgrad = i > 0 or need[3]
-            # the column sums behind dz's constants: joined in the input-gradient product's prologue, or (no such product
-            # for this layer, or MERGE_JOINS off) by the finalize launch
-            sums = None
-            if MERGE_JOINS and runs_dgrad and part_rows <= 128:     # (the head's 256 partial rows keep their finalize launch)
-                sums = _BnBwd(part.data_ptr(), gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                              dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp),
-                              dw_head.data_ptr() if wp is not None else None, db_head.data_ptr() if wp is not None else None,
-                              part_rows, nw)
-            else:
-                _lib.check(lib.mi_tail_bn_finalize_bwd(
-                    part.data_ptr(), part_rows, M, N, gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                    dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp), nw, dw_head.data_ptr() if wp is not None else None,
-                    db_head.data_ptr() if wp is not None else None, s), "mi_tail_bn_finalize_bwd")
-            wp = None
-            grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
-            if need[5 + 4 * i + 1] and plan[i].lin.bias is not None:
-                grads[4 * i + 1] = zeros[zoff[i] + N * K: zoff[i + 1]]     # exact: the batch mean is removed
-            a_in = x if i == 0 else acts[i]
-            defer = need[5 + 4 * i] and runs_dgrad and a_in is not None and not _kernels.DETERMINISTIC
-            dz_keep = torch.empty((M, N), dtype=torch.float32, device=dev) if defer else None
-            layer_DY = DY
-            if runs_dgrad:
-                OUT = torch.empty((M, K), dtype=torch.float32, device=dev)
-                npart = torch.empty(int(lib.mi_tail_part_elems(M, K)), dtype=torch.float32, device=dev) if i > 0 else None
-                _lib.check(lib.mi_tail_dgrad_gemm_m(
-                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
-                    Ws[i].data_ptr(), K, below.data_ptr() if i > 0 else None, K, _lib.ptr(bc[0]) if bc is not None else None,
-                    _lib.ptr(bc[1]) if bc is not None else None, _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb),
-                    OUT.data_ptr(), K, _lib.ptr(npart), _lib.ptr(dz_keep), M, N, K,
-                    ctypes.byref(sums) if sums is not None else None, s), "mi_tail_dgrad_gemm_m")
-            # the weight gradient comes AFTER the input-gradient product: in the joined form that product's workgroup 0 is
-            # what writes al / bz / de
-            if defer:
-                dW = zeros[zoff[i]: zoff[i] + N * K].view(N, K)               # split-K slices meet in atomics
-                later.append(dict(A=dz_keep, B=a_in, C=dW, M=N, N=K, K=M, lda=N, ldb=K, ldc=K))   # dW = dz^T a_in
-                grads[4 * i] = dW
-            elif need[5 + 4 * i]:
-                splits = int(lib.mi_tail_wgrad_splits(M, N, K))
-                slab = torch.empty((splits, N, K), dtype=torch.float32, device=dev)
-                dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-                _lib.check(lib.mi_tail_wgrad_gemm(
-                    layer_DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
-                    below.data_ptr(), K, _lib.ptr(bc[0]) if bc is not None else None, _lib.ptr(bc[1]) if bc is not None else None,
-                    _lib.ptr(bc[2]) if bc is not None else None, float(bp), _lib.ptr(bb), slab.data_ptr(), dW.data_ptr(), M, N, K, s),
-                    "mi_tail_wgrad_gemm")
-                grads[4 * i] = dW
-            if runs_dgrad:
-                if i > 0:
-                    DY, part, part_rows = OUT, npart, (M + 63) // 64
-                else:
-                    dx = OUT
-        _kernels.gemm_multi(later, transA=True)
-        grads[4 * k] = dw_head
-        grads[4 * k + 1] = db_head if ctx.has_head_bias else None
-        dadd = gvec.view(ctx.add_shape) if (ctx.add_shape is not None and need[4]) else None
+        dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[5:], need[4])
         return (None, None, None, dx, dadd, *grads)
+
+
+class DeepFMFusedFn(torch.autograd.Function):
+    """DeepFM's whole forward as ONE autograd node (src/models/deepfm.py:79-105): gather + FM + first-order term
+    (mi_gather_fm_fwd_sum) feeding the fused tail, so that the backward of the lookup runs in the EPILOGUE of the first
+    layer's input-gradient product (mi_tail_dgrad_gemm_fm) instead of as a kernel of its own behind it: the gradient of the
+    embedding block is never written to memory and read back, one launch less per step.
+
+    Inputs: idx [B, F] raw ids, offsets [F], W / w1 (the two tables, strided views of a packed table allowed), bias, then
+    the tail's parameters as FusedTailFn takes them.  Table gradients come in row (COO) form for the tables that asked for
+    it (sparse_W / sparse_w1) and are scatter-added into a dense gradient for one that did not — exactly what
+    _kernels.GatherFM.backward does with the same values."""
+
+    @staticmethod
+    def forward(ctx, plan, head, seed, idx, offsets, W, w1, bias, sparse_W: bool, sparse_w1: bool, *params):
+        dev = _lib.require_gpu(idx, offsets, W, w1, bias)
+        lib = _lib.load()
+        idx = _kernels._i64c(idx)
+        offsets = _kernels._i64c(offsets.reshape(-1))
+        Wc, ldw = _kernels._row_strided(W)
+        w1c, ldw1 = _kernels._row_strided(w1.reshape(w1.shape[0], -1) if w1.dim() != 2 else w1, align=1)
+        B, F = idx.shape
+        N, D = Wc.shape
+        emb = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+        yfm = torch.empty((B,), dtype=torch.float32, device=dev)
+        rows = torch.empty((B, F), dtype=torch.int64, device=dev)
+        esum = torch.empty((B, D), dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_gather_fm_fwd_sum(idx.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1,
+                                            _lib.ptr(bias), emb.data_ptr(), yfm.data_ptr(), rows.data_ptr(), esum.data_ptr(),
+                                            B, F, D, N, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+                   "mi_gather_fm_fwd_sum")
+        _kernels.note_field_layout(rows, offsets, N)
+        k = len(plan)
+        Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
+        w_head = _kernels._f32c(params[4 * k]).view(-1)
+        out, saved, st = _tail_forward(plan, seed, emb, yfm, Ws, w_head, params[4 * k + 1])
+        ctx.st = st
+        ctx.meta = (B, F, D, N, tuple(W.shape), tuple(w1.shape), bool(sparse_W), bool(sparse_w1), bias is not None)
+        ctx.save_for_backward(*saved, rows, esum)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, F, D, N, Wshape, w1shape, sparse_W, sparse_w1, has_bias = ctx.meta
+        saved = ctx.saved_tensors
+        rows, esum = saved[-2], saved[-1]
+        need = ctx.needs_input_grad           # (plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *params)
+        need_W, need_w1, need_b = need[5], need[6], need[7]
+        dev = rows.device
+        g1vals = torch.empty((B * F,), dtype=torch.float32, device=dev) if need_w1 else None
+        gvals, _, grads, db_head = _tail_backward(ctx.st, saved[:ctx.st.n_saved], g, True, need[10:], False,
+                                                  fm=(esum, g1vals, D))
+        gvals = gvals.view(B * F, D)
+        stream = _lib.stream_ptr(dev)
+        gW = gw1 = None
+        if need_W:
+            gW = (_kernels._coo(rows, gvals, Wshape) if sparse_W
+                  else _kernels._scatter_rows(rows, gvals, N, D, stream).view(Wshape))
+        if need_w1:
+            gw1 = (_kernels._coo(rows, g1vals.view((-1,) + (1,) * (len(w1shape) - 1)), w1shape) if sparse_w1
+                   else _kernels._scatter_rows(rows, g1vals, N, 1, stream).view(w1shape))
+        # the scalar bias is added to every logit, like the head's bias: the same gradient, sum_m g[m]
+        gb = db_head.clone() if (has_bias and need_b) else None
+        return (None, None, None, None, None, gW, gw1, gb, None, None, *grads)
 
 
 def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
@@ -332,3 +481,17 @@ def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: t
         params += [L.lin.weight, L.lin.bias, L.bn.weight, L.bn.bias]
     params += [head.weight, head.bias]
     return FusedTailFn.apply(plan, head, seed, x, last_add, *params)
+
+
+# DeepFM's lookup backward in the epilogue of the tail's first input-gradient product (MI_FUSED_FM_EPILOGUE=0: two nodes,
+# mi_gather_fm_bwd_rows as a kernel of its own behind the tail's backward — the round-3 form)
+FM_EPILOGUE = os.environ.get("MI_FUSED_FM_EPILOGUE", "1") == "1"
+
+
+def run_fused_deepfm(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, idx, offsets, W, w1, bias,
+                     sparse_W: bool, sparse_w1: bool) -> torch.Tensor:
+    params = []
+    for L in plan:
+        params += [L.lin.weight, L.lin.bias, L.bn.weight, L.bn.bias]
+    params += [head.weight, head.bias]
+    return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *params)

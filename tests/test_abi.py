@@ -79,7 +79,7 @@ def test_binding_table_matches_header():
 
 def test_load_and_version():
     lib = _lib.load()
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == _lib.ABI_VERSION == 3
     assert lib.mi_strerror(0) == b"ok"
     assert b"invalid" in lib.mi_strerror(-1)
 

@@ -166,6 +166,73 @@ def test_gather_fm_kernels_vs_oracle(B, dims, D, zipf, layout):
     _lib.check_index_errors()
 
 
+@pytest.mark.parametrize("B,dims,D", [c for c in CASES if c[0] >= 2 and c[2] % 4 == 0 and (c[2] // 4) & (c[2] // 4 - 1) == 0])
+@pytest.mark.parametrize("layout", ["split", "packed128"])
+@pytest.mark.parametrize("fc_sparse", [True, False])
+def test_lookup_backward_in_the_dgrad_epilogue_vs_oracle_and_vs_the_two_node_path(B, dims, D, layout, fc_sparse, monkeypatch):
+    """The gather + FM backward folded into the epilogue of the tail's first input-gradient product (tail.DeepFMFusedFn,
+    mi_tail_dgrad_gemm_fm): logits and EVERY gradient of a whole DeepFM step against the oracle
+    (oracle/reference_ops.deepfm_forward = src/models/deepfm.py:79-105 through autograd) at the gather kernels' CASES,
+    and against this build's two-node path (mi_gather_fm_bwd_rows behind the tail) on the same inputs.  fc_sparse False =
+    the reference's sparse config (configs/deepfm/base_config_sparse.yaml: row-form embedding gradient, dense first-order)."""
+    from recsys_benchmark_amd import mlp as _mlp_mod, tail as _tail_mod
+
+    if layout == "packed128" and D > 16:
+        pytest.skip("packed128 holds D <= 16")
+    F = len(dims)
+    torch.manual_seed(B + D)
+    hidden = [32, 16]
+    base = pkg.DeepFM(dims, D, hidden, p_dropout=0.0, use_batchnorm=True, embedding_config={"name": "vanilla", "sparse": True},
+                      fc_sparse=fc_sparse)
+    with torch.no_grad():
+        base._bias.fill_(0.3)
+        for m in base._deep_branch:
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    gen = torch.Generator().manual_seed(B * 7 + D)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+    y = (torch.rand(B, generator=gen) < 0.3).float()
+    p = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    fits = _mlp_mod.FUSED_TAIL and (F * D) % 8 == 0 and B >= 2
+    if B >= 2:
+        ref = ro.deepfm_forward(x, p, len(hidden), True, True)
+        torch.nn.BCEWithLogitsLoss()(ref, y).backward()
+
+    import copy
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(_tail_mod, "FM_EPILOGUE", fused)
+        m = copy.deepcopy(base).to(DEV).train()
+        if layout == "packed128":
+            m.pack_tables()
+        logits = m(x.to(DEV))
+        assert (type(logits.grad_fn.next_functions[0][0]).__name__ == "DeepFMFusedFnBackward") == (fused and fits)
+        torch.nn.BCEWithLogitsLoss()(logits, y.to(DEV)).backward()
+        _lib.check_index_errors()
+        grads = {k: (v.grad.to_dense() if v.grad.is_sparse else v.grad).cpu() for k, v in m.named_parameters() if v.grad is not None}
+        assert m.embedding.get_weight().grad.is_sparse and m.fc.weight.grad.is_sparse == fc_sparse
+        got[fused] = (logits.detach().cpu(), grads)
+    if B < 2:
+        return          # (BatchNorm needs two samples; the reference raises there)
+    atol = 1e-5 + 2e-7 * B
+    for fused in (True, False):
+        logits, grads = got[fused]
+        assert_close(logits, ref.detach(), 1e-4, 1e-5, f"logits fused={fused}")
+        for k, gr in grads.items():
+            if k.startswith("linear_layer") or (k.endswith(".bias") and k.startswith("_deep_branch") and p[k].grad.abs().max() < 1e-6):
+                continue
+            assert_close(gr, p[k].grad, 2e-4, atol, f"grad {k} fused={fused}")
+    # the two paths share every kernel but the last: same logits bit for bit, table gradients equal up to the order in
+    # which a row's duplicates are summed when densified
+    assert torch.equal(got[True][0], got[False][0])
+    for k in ("embedding._emb_module.weight", "fc.weight", "_bias"):
+        assert_close(got[True][1][k], got[False][1][k], 1e-5, atol, f"{k}: fused epilogue vs two-node path")
+
+
 def test_empty_batch():
     p, x, g_emb, g_y = _random_case(0, [5, 6], 16, seed=1)
     emb, yfm = _kernels.gather_fm(x.to(DEV), p["offsets"].to(DEV), p["embedding._emb_module.weight"].to(DEV),

@@ -22,14 +22,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=[True, False], ids=["joins-in-prologue", "finalize-launches"])
+@pytest.fixture(autouse=True, params=["sums", "joins", "finalize"],
+                ids=["atomic-sums-derived-in-prologue", "joins-in-prologue", "finalize-launches"])
 def _fused_tail_on(request, monkeypatch):
-    """Every test runs with the BatchNorm joins in the consuming kernels' prologues (opt-in, MI_TAIL_MERGE_JOINS=1: built in
-    round 3, measured slower, see tail.py) and with the finalize launches (the default)."""
+    """Every test runs in the three forms of the BatchNorm statistics: shifted sums added with float atomics by the
+    producing product and derived into constants by the consuming product's prologue (round 4, the default), the tile
+    statistics joined in the consumer's prologue (MI_TAIL_MERGE_JOINS=1: round 3, measured slower), and tile statistics
+    with finalize launches (MI_TAIL_STAT_SUMS=0; what deterministic mode runs)."""
     from recsys_benchmark_amd import tail as _tail_mod
 
     monkeypatch.setattr(_mlp, "FUSED_TAIL", True)
-    monkeypatch.setattr(_tail_mod, "MERGE_JOINS", request.param)
+    monkeypatch.setattr(_tail_mod, "STAT_SUMS", request.param == "sums")
+    monkeypatch.setattr(_tail_mod, "MERGE_JOINS", request.param == "joins")
 
 
 def _seq(inp, hidden, p):
