@@ -716,6 +716,194 @@ def cpu_baseline_c5(model, adj_cpu, users, pos, neg, U, nl, B):
                       "oracle/reference_ops.py lightgcn_propagate (torch CSR matmul, as src/models/lightgcn.py:79-87) + bpr_loss + l2_reg_loss on torch CPU"}
 
 
+def bench_infer(args, real_stdout):
+    """The reference's ONLY timing harnesses are inference: scripts/deepfm/infer_deepfm.py:36,318-352 — one
+    eval-mode forward under torch.no_grad() on a resident batch (default batch 64), wall clock after one warm-up, or
+    timeit.repeat(number=20) — and scripts/lightgcn/infer_lightgcn.py:56-114,459-467 — forward / matching / filter / top-k of
+    one request (user_id = [0], k = 20), each phase fenced by cuda.synchronize(), mean over 20 runs.  This leg runs both
+    protocols on the C2 / C5 shapes (eval mode: BatchNorm on running statistics, no dropout — every product on the library's
+    own kernels, csrc/tail.hip + mi_tail_affine_consts) and the CPU oracle by the survey's 3 + 10 protocol beside them."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import statistics
+
+    import recsys_benchmark_amd as pkg
+    from recsys_benchmark_amd import _lib as L
+    from recsys_benchmark_amd.lightgcn import LightGCN, score_topk, train_items_csr
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    out = {"metric": "inference latency by the reference's own timing harnesses (eval-mode forward; LightGCN request phases)",
+           "unit": "us", "n_gpus": 1, "dtype": "f32", "data": "synthetic", "higher_is_better": False, "infer": {}}
+
+    # ---------------------------------------------------------------- DeepFM (C2 shape), eval + no_grad
+    dims, D, hidden = list(CRITEO_KAGGLE_26), 16, [400, 400, 400]
+    F = len(dims)
+    torch.manual_seed(2023)
+    model = pkg.DeepFM(dims, D, hidden, p_dropout=0.5, use_batchnorm=True).to(dev)
+    model.pack_tables()
+    model.eval()
+    deep = []
+    for B in (64, 4096):
+        xs = [synth_batch(dims, B, 555 + i, dev)[0] for i in range(16)]
+        with torch.no_grad():
+            model(xs[0])                                   # the reference's single warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model(xs[1]).cpu()                             # "--- Inference ---": one forward + the copy of its output
+            single = time.perf_counter() - t0
+            reps = []
+            for r in range(5):                             # timeit.repeat(number=20): 5 repeats of 20 forwards
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(20):
+                    model(xs[(r * 20 + i) % len(xs)])
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - t0) / 20)
+            # the same forward replayed as a hipGraph per resident batch (what a serving loop would keep)
+            graphs = []
+            pool = None
+            for xb in xs[:8]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    yb = model(xb)
+                pool = g.pool()
+                graphs.append((g, yb))
+            for g, _ in graphs:
+                g.replay()
+            torch.cuda.synchronize()
+            lat = []
+            for i in range(200):
+                t0 = time.perf_counter()
+                graphs[i % len(graphs)][0].replay()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for i in range(200):
+                graphs[i % len(graphs)][0].replay()
+            torch.cuda.synchronize()
+            thr = (time.perf_counter() - t0) / 200
+            with KernelTimer(capacity=256) as kt:
+                model(xs[2])
+                torch.cuda.synchronize()
+        lat.sort()
+        deep.append({"B": B, "single_forward_plus_output_copy_us": round(single * 1e6, 1),
+                     "eager_forward_us_timeit20": {"p50": round(statistics.median(reps) * 1e6, 1), "min": round(min(reps) * 1e6, 1)},
+                     "graph_replay_latency_us": {"p50": round(lat[len(lat) // 2] * 1e6, 1), "p99": round(lat[int(len(lat) * 0.99)] * 1e6, 1)},
+                     "graph_replay_back_to_back_us": round(thr * 1e6, 2),
+                     "p50_us": round(lat[len(lat) // 2] * 1e6, 1),
+                     "samples_per_s": round(B / thr, 1),
+                     "kernels_per_forward": {k: v["count"] for k, v in kt.summary().items()}})
+        del graphs
+    pkg.check_index_errors()
+    out["infer"]["deepfm"] = {"shape": f"C2: F={F}, D={D}, N={sum(dims)} rows (packed [N,32] table), MLP 400x3 + BatchNorm (eval) + Linear(400,1)",
+                              "lines": deep,
+                              "note": "every kernel of the forward is the library's own (gather_fm_fwd, tail_affine_consts, tail_fwd_gemm x3, "
+                                      "tail_head_fwd): kernels_per_forward lists what one eager forward launched"}
+    if not args.no_cpu_baseline:
+        from oracle import reference_ops as ro
+
+        phys, logical = physical_cores()
+        torch.set_num_threads(phys)
+        p = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+        cpu_lines = []
+        for B in (64, 4096):
+            x = synth_batch(dims, B, 555, "cpu")[0]
+            with torch.no_grad():
+                med, n = timed_cpu(lambda: ro.deepfm_forward(x, p, len(hidden), True, False), budget_s=8.0)
+            cpu_lines.append({"B": B, "p50_us": round(med * 1e6, 1), "samples_per_s": round(B / med, 1), "timed_iters": n})
+        out["infer"]["deepfm"]["cpu_baseline"] = {"kind": "port", "cores": phys, "lines": cpu_lines,
+                                                  "sample": "3 warm-up + 10 timed eval forwards (median), oracle/reference_ops.deepfm_forward under no_grad"}
+    del model
+    torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- LightGCN (C5 shape): request phases
+    U, I, Dg, nl, k = 31668, 38048, 64, 3, 20
+    adj_cpu = yelp_graph(U, I)
+    adj = adj_cpu.to(dev)
+    torch.manual_seed(2023)
+    gm = LightGCN(U, I, num_layers=nl, hidden_size=Dg).to(dev).eval()
+    # the users' train items (what the filter masks): the bipartite block of the adjacency's rows
+    crow = adj_cpu.crow_indices()
+    colv = adj_cpu.col_indices()
+    graph = {u: (colv[int(crow[u]):int(crow[u + 1])] - U).tolist() for u in range(2048)}
+    train_csr = train_items_csr(graph, 2048, dev)      # (crow, col) of the users a request may name
+    from recsys_benchmark_amd import _kernels as K_
+    lg = []
+    for users_n in (1, 2048):
+        users = torch.arange(users_n, device=dev)
+        acc = {"forward": 0.0, "matching": 0.0, "filter_topk": 0.0}
+        n_runs = 20
+        lib = L.load()
+        with torch.no_grad():
+            gm(adj)
+            score_topk(*gm(adj), users, k, train_csr)
+            torch.cuda.synchronize()
+            for _ in range(n_runs):
+                t0 = time.perf_counter()
+                ue, ie = gm(adj)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                # matching as the product runs it (lightgcn.score_topk): row gather + fp32 MFMA product
+                rows = K_.gather_rows(users, ue)
+                scores = torch.empty((users_n, I), dtype=torch.float32, device=dev)
+                K_.gemm(rows, ie.contiguous(), scores, users_n, I, Dg, Dg, Dg, I, transB=True)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                # filter + top-k: ONE launch, a workgroup per user masks the user's train items and selects the k best
+                topk = torch.empty((users_n, k), dtype=torch.int64, device=dev)
+                L.check(lib.mi_mask_topk_rows(scores.data_ptr(), scores.stride(0), users_n, I, users.data_ptr(), train_csr[0].data_ptr(),
+                                              train_csr[1].data_ptr(), k, topk.data_ptr(), None, L.stream_ptr(dev)), "mask_topk")
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                acc["forward"] += t1 - t0
+                acc["matching"] += t2 - t1
+                acc["filter_topk"] += t3 - t2
+        lg.append({"users": users_n, "k": k, "forward_us": round(acc["forward"] / n_runs * 1e6, 1),
+                   "matching_us": round(acc["matching"] / n_runs * 1e6, 1),
+                   "filter_plus_topk_us": round(acc["filter_topk"] / n_runs * 1e6, 1),
+                   "note": "filter and top-k are one launch here (a workgroup per user masks the user's train items and selects the "
+                           "k best): no host loop over users — the reference builds the filter's index lists in Python per request"})
+    out["infer"]["lightgcn"] = {"shape": f"C5: U={U}, I={I}, nnz(A)={int(adj_cpu.values().numel())}, D={Dg}, L={nl}", "lines": lg,
+                                "protocol": "scripts/lightgcn/infer_lightgcn.py: phases fenced by synchronize, mean of 20 runs; users = [0] "
+                                            "(the script's request) and the first 2048 users (a validation batch)"}
+    if not args.no_cpu_baseline:
+        from oracle import reference_ops as ro
+
+        Eu = gm.user_emb_table.get_weight().detach().cpu()
+        Ei = gm.item_emb_table.get_weight().detach().cpu()
+        cpu_lg = []
+        for users_n in (1, 2048):
+            uid = list(range(users_n))
+            ph = {"forward": [], "matching": [], "filter": [], "topk": []}
+            for it in range(3 + 5):
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    res = ro.lightgcn_propagate(adj_cpu, torch.cat([Eu, Ei]), nl)
+                    t1 = time.perf_counter()
+                    scores = res[:U][uid] @ res[U:].T
+                    t2 = time.perf_counter()
+                    ind0 = torch.tensor([], dtype=torch.long)
+                    ind1 = torch.tensor([], dtype=torch.long)
+                    for idx, user in enumerate(uid):                                  # the reference's own loop (:93-99)
+                        ind0 = torch.cat((ind0, torch.tensor([idx] * len(graph[user]), dtype=torch.long)))
+                        ind1 = torch.cat((ind1, torch.tensor(graph[user], dtype=torch.long)))
+                    scores[ind0, ind1] = float("-inf")
+                    t3 = time.perf_counter()
+                    torch.topk(scores, k, dim=1)
+                    t4 = time.perf_counter()
+                if it >= 3:
+                    for name, v in zip(ph, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                        ph[name].append(v)
+            cpu_lg.append({"users": users_n, **{f"{n}_us": round(statistics.median(v) * 1e6, 1) for n, v in ph.items()}})
+        phys, _ = physical_cores()
+        out["infer"]["lightgcn"]["cpu_baseline"] = {"kind": "port", "cores": phys, "lines": cpu_lg,
+                                                    "sample": "3 warm-up + 5 timed requests (median per phase), the reference's op sequence incl. its Python filter loop"}
+    d64 = deep[0]
+    out["value"] = d64["p50_us"]
+    out["config"] = {"workload": "inference: DeepFM C2 eval forward at B=64 (value = p50 graph-replay latency) and B=4096; LightGCN C5 request phases"}
+    emit(out, real_stdout)
+
+
 def self_launch(n):
     """Parent of an N-rank run: start `torch.distributed.run` as a CHILD process (never exec: see the GPU-box rules), one
     rank per device, rendezvous on 127.0.0.1; forward the ranks' stderr, print exactly rank 0's JSON line on stdout and
@@ -790,6 +978,8 @@ def main():
                     "nothing at those places (invalidates the measurement as a benchmark line)")
     ap.add_argument("--no-sweep", action="store_true", help="skip roofline.batch_sweep")
     ap.add_argument("--no-train-step", action="store_true", help="skip the train_step object (fwd+bwd+optimizers as one graph)")
+    ap.add_argument("--infer", action="store_true", help="the reference's own timing harnesses (scripts/deepfm/infer_deepfm.py, "
+                    "scripts/lightgcn/infer_lightgcn.py): eval-mode forward latency at B=64 / 4096, LightGCN request phases, CPU oracle beside")
     ap.add_argument("--windows", type=int, default=10, help="extra windows of --steps replays after the timed region, for "
                     "ms_per_step_windows {min, median, max}")
     ap.add_argument("--dry-launch", action="store_true", help="launch-contract check without a GPU: the ranks join a gloo "
@@ -810,6 +1000,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.infer and not args.dry_launch:
+        return bench_infer(args, real_stdout)
     if args.config == "c3" and not args.dry_launch:
         return bench_c3(args, real_stdout)
     if args.config == "c5" and not args.dry_launch:

@@ -39,7 +39,7 @@ extern "C" {
 
 /* 2: round 3 — mi_sort_field_rows / mi_bpr_* / mi_rowsq_* had gained arguments under version 1 (callers built against
  * that header must rebuild); mi_gather_fm_fwd_ld, mi_sparse_adam_sorted's row stride and the later additions are new. */
-/* 3: round 4 — mi_tail_bn_fwd gained `shift` and `nrep` (a caller built against version 2 passes a shorter struct). */
+/* 3: round 4 — mi_tail_bn_fwd gained `shift` and `nrep`, mi_tail_bn_bwd `dbias` and `affine` (a caller built against version 2 passes shorter structs). */
 #define MI_ABI_VERSION 3
 
 #define MI_OK 0
@@ -753,6 +753,8 @@ typedef struct mi_tail_bn_bwd {
   const float *wpart;
   float *dw, *db;
   int32_t nblk, nwblk;
+  float *dbias;           /* affine != 0, nullable: the Linear bias's gradient al * sum dy, [N] */
+  int32_t affine;         /* != 0: fixed statistics (eval-mode BatchNorm) or none: dz = al dy, bz = de = 0 (mi_tail_bn_finalize_bwd_a) */
 } mi_tail_bn_bwd;
 MI_API int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
                               float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz,
@@ -842,9 +844,34 @@ MI_API int32_t mi_tail_head_blocks(int32_t M);
 MI_API int mi_tail_head_bwd(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                             const uint8_t *keep, const float *g, const float *w, float *DY, float *part, float *wpart,
                             int32_t M, int32_t N, void *stream);
+/* sum_reps > 0: part is fp32[sum_reps, N, 2] and wpart fp32[sum_reps, N + 4], both ZEROED by the caller; workgroup b ADDS
+ * its sums into row b % sum_reps (float atomics) — a mi_tail_bn_bwd with nblk = nwblk = sum_reps then joins them in the next
+ * product's prologue and the head level needs no finalize launch.  sum_reps = 0 is mi_tail_head_bwd. */
+MI_API int mi_tail_head_bwd_s(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                              const uint8_t *keep, const float *g, const float *w, float *DY, float *part, float *wpart,
+                              int32_t sum_reps, int32_t M, int32_t N, void *stream);
 MI_API int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma,
                                    const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
                                    const float *wpart, int32_t nwblk, float *dw, float *db, void *stream);
+/* Layers that normalise with FIXED statistics or not at all — eval mode (model.eval(): BatchNorm1d on its running
+ * statistics, src/models/deepfm.py:57-58) and use_batchnorm=False (DeepFM's default, src/models/deepfm.py:20,56) — run on
+ * the same products: a = relu((z - mu) sc + be) with z = x W^T (the Linear bias stays out of the product) and
+ *   BatchNorm in eval mode: rstd = 1/sqrt(running_var + eps), mu = running_mean - bias, sc = gamma rstd, be = beta
+ *   no BatchNorm:           mu = 0, sc = 1, be = bias, rstd = 1
+ * mi_tail_affine_consts writes these for up to 8 layers in ONE launch (host arrays of device pointers; running_mean[l] ==
+ * NULL: layer l has no BatchNorm; gamma / beta / bias nullable per layer).
+ * mi_tail_bn_finalize_bwd_a: affine != 0 -> al = gamma rstd, bz = de = 0 (dz = al dy), dgamma = rstd sum dy (z - mu),
+ *   dbeta = sum dy, dbias (nullable) = al sum dy = the Linear bias's gradient; affine == 0 is mi_tail_bn_finalize_bwd.
+ * mi_tail_head_fwd_m with a mi_tail_bn_fwd whose `part` is NULL joins nothing and only advances *seed_bump (nullable): how
+ *   a step without any statistics to join moves its dropout seed on. */
+MI_API int mi_tail_affine_consts(int32_t nlayers, const int32_t *widths, const float *const *gamma,
+                                 const float *const *beta, const float *const *running_mean,
+                                 const float *const *running_var, const float *const *bias, const float *eps,
+                                 float *const *mu, float *const *sc, float *const *be, float *const *rstd, void *stream);
+MI_API int mi_tail_bn_finalize_bwd_a(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma,
+                                     const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
+                                     const float *wpart, int32_t nwblk, float *dw, float *db, int32_t affine,
+                                     float *dbias, void *stream);
 MI_API int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
                               const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
                               int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,

@@ -273,6 +273,11 @@ struct BnBwd {           // device view of mi_tail_bn_bwd
   const float *wpart;    // [nwblk, N + 4] head pieces, nullable
   int nwblk;
   float *dw, *db;
+  // affine != 0: the layer normalised with FIXED statistics (eval-mode BatchNorm: rstd of the running variance) or not at
+  // all (no BatchNorm: gamma null, rstd = 1): dz = al dy with al = gamma rstd, no batch terms (bz = de = 0); dbias
+  // (nullable) receives the Linear bias's gradient sum_m dz = al * sum_m dy (under a training-mode BatchNorm it is zero)
+  int affine;
+  float *dbias;
 };
 // cst rows: 0 mu, 1 al, 2 bz, 3 de (the constants of LoadDz).  Two adjacent columns per thread, kMergeChunk partial rows in
 // flight.  The head's dw / db pieces are joined by ANOTHER workgroup (wwriter) so that no workgroup carries both joins.
@@ -282,6 +287,7 @@ __device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, 
 template <int NT>
 __device__ __forceinline__ void bn_merge_bwd(const BnBwd &b, int M, int N, float *cst, bool writer, bool wwriter, int tid) {
   if (b.nblk <= 8 && (!b.wpart || b.nwblk <= 8)) bn_merge_bwd_impl<NT, 8>(b, M, N, cst, writer, wwriter, tid);
+  else if (b.nblk <= 16 && (!b.wpart || b.nwblk <= 16)) bn_merge_bwd_impl<NT, 16>(b, M, N, cst, writer, wwriter, tid);
   else bn_merge_bwd_impl<NT, kMergeChunk>(b, M, N, cst, writer, wwriter, tid);
 }
 template <int NT, int CH>
@@ -306,7 +312,7 @@ __device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, 
       const float s1 = j ? s11 : s10, s2 = j ? s21 : s20;
       const float r = j ? r2.y : r2.x, gm = j ? gm2.y : gm2.x;
       const float dg = s2 * r;
-      const float al = gm * r, bz = -gm * r * r * dg * inv_m, de = -gm * r * s1 * inv_m;
+      const float al = gm * r, bz = b.affine ? 0.f : -gm * r * r * dg * inv_m, de = b.affine ? 0.f : -gm * r * s1 * inv_m;
       cst[col] = j ? mu2.y : mu2.x;
       cst[kCstPitch + col] = al;
       cst[2 * kCstPitch + col] = bz;
@@ -314,6 +320,7 @@ __device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, 
       if (writer) {
         if (b.dgamma) b.dgamma[col] = dg;
         if (b.dbeta) b.dbeta[col] = s1;
+        if (b.affine && b.dbias) b.dbias[col] = al * s1;
         b.al[col] = al; b.bz[col] = bz; b.de[col] = de;
       }
     }
@@ -562,24 +569,36 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restr
 template <bool MERGE>
 __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float *__restrict__ w, const float *__restrict__ b,
                                                           const float *__restrict__ add, float *__restrict__ out, int M,
-                                                          int N, BnFwd bn) {
+                                                          int N, BnFwd bn, int64_t *bump) {
   __shared__ __attribute__((aligned(16))) float cst[MERGE ? 3 * kCstPitch : 4];
+  // (a step whose layers have no statistics to join — no BatchNorm, or eval mode — advances the dropout seed here: every
+  //  kernel that reads the step's keep bits was launched before this one)
+  if (bump && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nw = gridDim.x * kWavesPerBlock;
   const float bv = b ? b[0] : 0.f;
-  auto rows = [&](const auto &act) {
+  // `between`: work placed after the first trip's loads have been issued and before their values are used — the joined
+  // form derives the constants there (they are not needed to ISSUE a row load, only to turn z into the activation), so
+  // the join's own round trip runs under the rows' instead of in front of it (it cost +4 us in front)
+  auto rows = [&](const auto &act, const auto &between) {
     if (N <= 512) {                              // up to 4 rows of a wave in flight (a workgroup per CU walks 16 rows)
       const int c0 = lane * 4, c1 = lane * 4 + 256;
       const bool v0 = c0 < N, v1 = c1 < N;
       const float4 w0 = v0 ? ld4(w + c0) : make_float4(0.f, 0.f, 0.f, 0.f), w1 = v1 ? ld4(w + c1) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int m0 = wave0; m0 < M; m0 += 4 * nw) {
+      bool first = true;
+      for (int m0 = wave0; m0 < M || first; m0 += 4 * nw) {
         typename std::remove_reference<decltype(act)>::type::Raw r0[4], r1[4];
+        if (m0 < M) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int m = min(m0 + u * nw, M - 1);
-          if (v0) r0[u] = act.fetch(m, c0);
-          if (v1) r1[u] = act.fetch(m, c1);
+          for (int u = 0; u < 4; ++u) {
+            const int m = min(m0 + u * nw, M - 1);
+            if (v0) r0[u] = act.fetch(m, c0);
+            if (v1) r1[u] = act.fetch(m, c1);
+          }
         }
+        if (first) between();
+        first = false;
+        if (m0 >= M) break;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int m = m0 + u * nw;
@@ -593,6 +612,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float
       }
       return;
     }
+    between();
     for (int m = wave0; m < M; m += nw) {
       float s = 0.f;
       for (int c = lane * 4; c < N; c += 256) {
@@ -605,12 +625,13 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float
   };
   const LoadAct act = make_act(x);
   if constexpr (MERGE) {
-    bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
-    __syncthreads();
     const lds_cfp c = as_lds(cst);
-    rows(LoadActL{x.Z, x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop});
+    rows(LoadActL{x.Z, x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop}, [&]() {
+      bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
+      __syncthreads();
+    });
   } else {
-    rows(act);
+    rows(act, []() {});
   }
 }
 
@@ -621,9 +642,13 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_fwd(ActDesc x, const float
 // One workgroup = 16 rows x all features per trip; per-workgroup partials are joined by k_bn_finalize_bwd in block
 // order (deterministic).
 constexpr int kHeadRows = 8;
+// reps > 0: part / wpart have `reps` rows (zeroed by the caller) and workgroup b ADDS its sums into row b % reps with float
+// atomics — the next product's prologue then joins `reps` rows (bn_merge_bwd) and no finalize launch is needed.  Same-address
+// float atomics serialise at ~26 ns apiece (measured: 64 adders per address cost a kernel ~1.7 us), so reps is chosen to
+// leave <= 16 adders per address.
 __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float *__restrict__ g, const float *__restrict__ w,
                                                           float *__restrict__ DY, float *__restrict__ part,
-                                                          float *__restrict__ wpart, int M, int N) {
+                                                          float *__restrict__ wpart, int M, int N, int reps) {
   // thread t owns columns 4t .. 4t+3 (N <= 1024)
   const Drop drop = make_drop(x.keep, x.p, x.ld);
   const int c = threadIdx.x * 4;
@@ -669,6 +694,18 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
       s_ga.z += gm * fmaxf(pre.z, 0.f) * k.z; s_ga.w += gm * fmaxf(pre.w, 0.f) * k.w;
     }
   }
+  if (reps > 0) {
+    const int rr = blockIdx.x % reps;
+    if (cv) {
+      float *o = part + ((int64_t)rr * N + c) * 2;
+      atomicAdd(o + 0, s_dy.x); atomicAdd(o + 1, s_dyz.x); atomicAdd(o + 2, s_dy.y); atomicAdd(o + 3, s_dyz.y);
+      atomicAdd(o + 4, s_dy.z); atomicAdd(o + 5, s_dyz.z); atomicAdd(o + 6, s_dy.w); atomicAdd(o + 7, s_dyz.w);
+      float *q = wpart + (int64_t)rr * (N + 4) + c;
+      atomicAdd(q + 0, s_ga.x); atomicAdd(q + 1, s_ga.y); atomicAdd(q + 2, s_ga.z); atomicAdd(q + 3, s_ga.w);
+    }
+    if (threadIdx.x == 0) atomicAdd(wpart + (int64_t)rr * (N + 4) + N, s_g);
+    return;
+  }
   if (cv) {
     float *o = part + ((int64_t)blockIdx.x * N + c) * 2;
     st4(o, make_float4(s_dy.x, s_dyz.x, s_dy.y, s_dyz.y));
@@ -687,7 +724,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                             float *__restrict__ al, float *__restrict__ bz,
                                                             float *__restrict__ de, const float *__restrict__ wpart,
-                                                            int nwblk, float *__restrict__ dw, float *__restrict__ db) {
+                                                            int nwblk, float *__restrict__ dw, float *__restrict__ db,
+                                                            int affine, float *__restrict__ dbias) {
   // 16 columns x 16 row groups per workgroup (see k_bn_finalize_fwd): a group adds its run of partial rows in row order
   // with up to 16 loads in flight (64 partial rows: 4 per thread, one round trip; the head's 256: 16 per thread, one
   // trip), the 16 groups are added in group order through LDS.  Column N of the head's pieces is db.
@@ -734,8 +772,40 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
   if (dbeta) dbeta[n] = s1;
   const float inv_m = 1.f / (float)M;
   al[n] = gm * r;
-  bz[n] = -gm * r * r * dg * inv_m;
-  de[n] = -gm * r * s1 * inv_m;
+  bz[n] = affine ? 0.f : -gm * r * r * dg * inv_m;
+  de[n] = affine ? 0.f : -gm * r * s1 * inv_m;
+  if (affine && dbias) dbias[n] = gm * r * s1;
+}
+
+// Constants of layers that normalise with FIXED statistics or not at all (eval mode, use_batchnorm=False), all layers of a
+// tail in one launch:  a = relu((z - mu) * sc + be) with z = x W^T (the Linear bias b stays out of the product)
+//   eval-mode BatchNorm (src/models/deepfm.py:57-58 under model.eval()): rstd = 1/sqrt(running_var + eps),
+//       mu = running_mean - b,  sc = gamma rstd,  be = beta
+//   no BatchNorm (DeepFM's default use_batchnorm=False):  mu = 0, sc = 1, be = b, rstd = 1
+struct AffineJob {
+  const float *gamma[8], *beta[8], *rmean[8], *rvar[8], *bias[8];
+  float *mu[8], *sc[8], *be[8], *rstd[8];
+  float eps[8];
+  int n[8];
+  int nl;
+};
+__global__ __launch_bounds__(kBlock) void k_tail_affine_consts(AffineJob j) {
+  const int l = blockIdx.y;
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (l >= j.nl || c >= j.n[l]) return;
+  const float b = j.bias[l] ? j.bias[l][c] : 0.f;
+  if (j.rvar[l]) {
+    const float r = rsqrtf(j.rvar[l][c] + j.eps[l]);
+    j.mu[l][c] = j.rmean[l][c] - b;
+    j.sc[l][c] = (j.gamma[l] ? j.gamma[l][c] : 1.f) * r;
+    j.be[l][c] = j.beta[l] ? j.beta[l][c] : 0.f;
+    j.rstd[l][c] = r;
+  } else {
+    j.mu[l][c] = 0.f;
+    j.sc[l][c] = 1.f;
+    j.be[l][c] = b;
+    j.rstd[l][c] = 1.f;
+  }
 }
 
 // ============================================================================================== dgrad GEMM ====
@@ -1124,6 +1194,11 @@ int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float
   if (M < 0 || N <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   BnFwd bn{};
+  int64_t *bump = nullptr;
+  if (stats && !stats->part) {        // nothing to join: only the seed (if given) is advanced, by the plain kernel
+    bump = stats->seed_bump;
+    stats = nullptr;
+  }
   if (stats) {
     if (N > kCstPitch) return MI_ERR_UNSUPPORTED;
     if (!bn_fwd_view(stats, &bn)) return MI_ERR_INVALID_ARG;
@@ -1136,9 +1211,9 @@ int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float
   if (stats) {
     // every workgroup joins the statistics itself: one workgroup per CU, its waves walking the rows
     const int grid = (M + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (M + kWavesPerBlock - 1) / kWavesPerBlock : 256;
-    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<true>), grid, kBlock, stream, x, w, b, add, out, M, N, bn);
+    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<true>), grid, kBlock, stream, x, w, b, add, out, M, N, bn, (int64_t *)nullptr);
   } else {
-    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<false>), grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N, bn);
+    MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<false>), grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N, bn, bump);
   }
   return launch_status();
 }
@@ -1154,22 +1229,58 @@ int32_t mi_tail_head_blocks(int32_t M) { return M >= 64 * 256 ? 256 : (M + 15) /
 int mi_tail_head_bwd(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                      const uint8_t *keep, const float *g, const float *w, float *DY, float *part, float *wpart,
                      int32_t M, int32_t N, void *stream) {
-  if (M <= 0 || N <= 0) return MI_ERR_INVALID_ARG;
+  return mi_tail_head_bwd_s(Z, ldz, mu, sc, be, p, keep, g, w, DY, part, wpart, 0, M, N, stream);
+}
+
+int mi_tail_head_bwd_s(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                       const uint8_t *keep, const float *g, const float *w, float *DY, float *part, float *wpart,
+                       int32_t sum_reps, int32_t M, int32_t N, void *stream) {
+  if (M <= 0 || N <= 0 || sum_reps < 0 || sum_reps > 64) return MI_ERR_INVALID_ARG;
   if (!Z || !mu || !sc || !be || !g || !w || !DY || !part || !wpart) return MI_ERR_INVALID_ARG;
   if (!vec_ok(Z, ldz) || N % 4 || N > 4 * kBlock || !aligned16(w) || !aligned16(DY)) return MI_ERR_UNSUPPORTED;
   if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
   const ActDesc x{Z, ldz, mu, sc, be, p, keep};
-  MI_LAUNCH("tail_head_bwd", k_tail_head_bwd, mi_tail_head_blocks(M), kBlock, stream, x, g, w, DY, part, wpart, M, N);
+  MI_LAUNCH("tail_head_bwd", k_tail_head_bwd, mi_tail_head_blocks(M), kBlock, stream, x, g, w, DY, part, wpart, M, N, sum_reps);
   return launch_status();
 }
 
 int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma, const float *rstd,
                             float *dgamma, float *dbeta, float *al, float *bz, float *de, const float *wpart,
                             int32_t nwblk, float *dw, float *db, void *stream) {
+  return mi_tail_bn_finalize_bwd_a(part, nblk, M, N, gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db, 0, nullptr,
+                                   stream);
+}
+
+int mi_tail_bn_finalize_bwd_a(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma, const float *rstd,
+                              float *dgamma, float *dbeta, float *al, float *bz, float *de, const float *wpart,
+                              int32_t nwblk, float *dw, float *db, int32_t affine, float *dbias, void *stream) {
   if (M <= 0 || N <= 0 || nblk <= 0 || !part || !rstd || !al || !bz || !de) return MI_ERR_INVALID_ARG;
   if (wpart && !dw) return MI_ERR_INVALID_ARG;
   MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + kFinCols - 1) / kFinCols, kBlock, stream, part, nblk, M, N,
-            gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db);
+            gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db, affine, dbias);
+  return launch_status();
+}
+
+int mi_tail_affine_consts(int32_t nlayers, const int32_t *widths, const float *const *gamma, const float *const *beta,
+                          const float *const *running_mean, const float *const *running_var, const float *const *bias,
+                          const float *eps, float *const *mu, float *const *sc, float *const *be, float *const *rstd,
+                          void *stream) {
+  if (nlayers < 0 || nlayers > 8) return MI_ERR_INVALID_ARG;
+  if (nlayers == 0) return MI_OK;
+  if (!widths || !gamma || !beta || !running_mean || !running_var || !bias || !eps || !mu || !sc || !be || !rstd)
+    return MI_ERR_INVALID_ARG;
+  AffineJob j;
+  j.nl = nlayers;
+  int widest = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    if (widths[l] <= 0 || !mu[l] || !sc[l] || !be[l] || !rstd[l]) return MI_ERR_INVALID_ARG;
+    if ((running_mean[l] == nullptr) != (running_var[l] == nullptr)) return MI_ERR_INVALID_ARG;
+    j.gamma[l] = gamma[l]; j.beta[l] = beta[l]; j.rmean[l] = running_mean[l]; j.rvar[l] = running_var[l]; j.bias[l] = bias[l];
+    j.mu[l] = mu[l]; j.sc[l] = sc[l]; j.be[l] = be[l]; j.rstd[l] = rstd[l];
+    j.eps[l] = eps[l]; j.n[l] = widths[l];
+    widest = widths[l] > widest ? widths[l] : widest;
+  }
+  MI_LAUNCH("tail_affine_consts", k_tail_affine_consts, dim3((widest + kBlock - 1) / kBlock, nlayers), kBlock, stream, j);
   return launch_status();
 }
 
@@ -1227,7 +1338,7 @@ static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const floa
     if (!sums->part || !aligned16(sums->part) || sums->nblk <= 0 || !sums->rstd || !sums->al || !sums->bz || !sums->de || !mu || !Zl) return MI_ERR_INVALID_ARG;
     if (sums->wpart && (!sums->dw || sums->nwblk <= 0)) return MI_ERR_INVALID_ARG;
     a.bn = BnBwd{sums->part, sums->nblk, sums->gamma, sums->rstd, mu, sums->dgamma, sums->dbeta, sums->al, sums->bz, sums->de,
-                 sums->wpart, sums->nwblk, sums->dw, sums->db};
+                 sums->wpart, sums->nwblk, sums->dw, sums->db, sums->affine, sums->dbias};
     al = sums->al; bz = sums->bz; de = sums->de;
   }
   if (al && (!Zl || !mu || !bz || !de)) return MI_ERR_INVALID_ARG;

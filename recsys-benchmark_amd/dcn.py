@@ -1,7 +1,8 @@
 """DCN-Mix and DCNv2 — reference: src/models/dcn.py:11-222.  Same constructors, state_dict keys
 (`offsets, embedding.*, cross_head.*, _dnn.*` / `linear_model.weight, _last_fc.*`), forward
 signature and `load`.  Embedding lookup and cross network run as HIP kernels; the `_dnn` MLP
-(Linear/BatchNorm1d/ReLU/Dropout) stays on rocBLAS through PyTorch like DeepFM's tail."""
+(Linear/BatchNorm1d/ReLU/Dropout) + the final Linear(., 1) run on the fused tail kernels (tail.py) in training and eval mode
+(DCNv2's "Parallel" structure, whose MLP has no 1-output head of its own, keeps the general path of mlp.py)."""
 from typing import Any, Dict, List, Optional, Union
 
 import torch
@@ -104,10 +105,15 @@ class DCNv2(_FieldModel):
         _no_atomics_promised(self)
         rows, fields = self._lookup(x)
         crossed = self.cross_head(fields)
-        if self.structure == "Stacked":
-            features = run_tail(self._dnn, crossed)
-        else:
-            features = torch.concat([crossed, run_tail(self._dnn, fields)], dim=1)
         # first-order term: EmbeddingBag(N, 1, "sum") over the row ids = a D=1 row gather + bag sum
         first_order = _kernels.gather_rows(rows, self.linear_model.weight, bool(self.linear_model.sparse)).sum(1)
+        if self.structure == "Stacked":
+            # _dnn + _last_fc is the same (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail as DeepFM's: one node
+            # over the fused kernels, the first-order term added inside its last kernel (src/models/dcn.py:196-222)
+            tail = self.__dict__.get("_stacked_tail")
+            if tail is None or len(tail) != len(self._dnn) + 1 or tail[-1] is not self._last_fc:
+                tail = nn.Sequential(*self._dnn, self._last_fc)
+                self.__dict__["_stacked_tail"] = tail          # (not a registered submodule: state_dict keys unchanged)
+            return run_tail(tail, crossed, last_add=first_order).squeeze(-1)
+        features = torch.concat([crossed, run_tail(self._dnn, fields)], dim=1)
         return (self._last_fc(features) + first_order).squeeze(-1)

@@ -1,6 +1,7 @@
-"""The fused MLP tail: (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) of
-DeepFM._deep_branch / DCN._dnn (reference: src/models/deepfm.py:53-66,100-102, src/models/dcn.py:56-66) in TRAINING mode
-as ONE autograd node over the kernels of csrc/tail.hip:
+"""The fused MLP tail: (Linear, [BatchNorm1d], ReLU, [Dropout]) x k + Linear(., 1) of
+DeepFM._deep_branch / DCN._dnn (reference: src/models/deepfm.py:53-66,100-102, src/models/dcn.py:56-66) as ONE autograd
+node over the kernels of csrc/tail.hip — training mode (batch statistics), eval mode (running statistics folded into
+per-column constants: mi_tail_affine_consts), use_batchnorm=False, with or without grad (inference keeps nothing):
 
     forward   masks (one launch, only with dropout) ; per layer: MFMA product with the previous layer's
               BatchNorm+ReLU+Dropout applied in its operand load and the BatchNorm statistics in its epilogue, then a
@@ -48,6 +49,8 @@ RIDE_MASKS = os.environ.get("MI_TAIL_RIDE_MASKS", "1") == "1"
 # (it joins the head's dw / db).  Off in deterministic mode (atomic order), off with MI_TAIL_STAT_SUMS=0 (the round-3 form).
 STAT_SUMS = os.environ.get("MI_TAIL_STAT_SUMS", "1") == "1"
 STAT_REPS = max(1, min(64, int(os.environ.get("MI_TAIL_STAT_REPS", "4"))))
+# the head's backward runs 256 workgroups: 16 replicas leave 16 adders per address (same-address float atomics serialise)
+HEAD_REPS = max(1, min(64, int(os.environ.get("MI_TAIL_HEAD_REPS", "16"))))
 
 
 class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys.h)
@@ -58,7 +61,7 @@ class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys
 
 class _BnBwd(ctypes.Structure):          # mi_tail_bn_bwd
     _fields_ = [(n, ctypes.c_void_p) for n in ("part", "gamma", "rstd", "dgamma", "dbeta", "al", "bz", "de", "wpart", "dw", "db")] + \
-               [("nblk", ctypes.c_int32), ("nwblk", ctypes.c_int32)]
+               [("nblk", ctypes.c_int32), ("nwblk", ctypes.c_int32), ("dbias", ctypes.c_void_p), ("affine", ctypes.c_int32)]
 
 
 class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
@@ -75,10 +78,17 @@ def _bn_fwd_struct(part, L, c, seed_bump, shift=None, nrep=0) -> "_BnFwd":
 
 
 class _Layer:
-    __slots__ = ("lin", "bn", "p")
+    """One hidden group.  fixed: the layer normalises with FIXED statistics — an eval-mode BatchNorm1d (running statistics) —
+    or not at all (bn None: use_batchnorm=False); otherwise a training-mode BatchNorm1d (batch statistics)."""
+    __slots__ = ("lin", "bn", "p", "fixed")
 
-    def __init__(self, lin, bn, p):
-        self.lin, self.bn, self.p = lin, bn, p
+    def __init__(self, lin, bn, p, fixed):
+        self.lin, self.bn, self.p, self.fixed = lin, bn, p, fixed
+
+
+class _Plan(list):
+    """The hidden layers; grad: whether a backward may follow (grad mode at call time)."""
+    grad = True
 
 
 class _InputSpec:
@@ -91,33 +101,35 @@ class _InputSpec:
         return 2
 
 
-def fused_tail_plan(seq: nn.Sequential, x, groups) -> Optional[List[_Layer]]:
+def fused_tail_plan(seq: nn.Sequential, x, groups) -> Optional[_Plan]:
     """groups: mlp._groups(seq); x: the input tensor or an _InputSpec.  The plan (hidden layers; the head is groups[-1]) or
-    None when the pattern does not fit."""
-    if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+    None when the pattern does not fit: (Linear, [BatchNorm1d], ReLU, [Dropout]) x k + Linear(., 1), widths multiples of 8,
+    fp32, in training or eval mode, with or without grad."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
         return None
     if len(groups) < 2 or groups[-1][0] != "plain" or len(groups) - 1 > 8:      # (the mask kernel takes <= 8 layers)
         return None
     head = groups[-1][1]
     if not (isinstance(head, nn.Linear) and head.out_features == 1):
         return None
-    plan, width = [], x.shape[1]
+    plan, width = _Plan(), x.shape[1]
+    plan.grad = torch.is_grad_enabled()
     for g in groups[:-1]:
         if g[0] != "fused":
             return None
         _, lin, bn, dp = g
-        if bn is None or not bn.training or not bn.track_running_stats or bn.momentum is None or not bn.affine:
+        if bn is not None and (not bn.track_running_stats or bn.momentum is None or not bn.affine):
             return None
         if lin.in_features != width or lin.in_features % 8 or lin.out_features % 8 or lin.out_features > 1024:
             return None
         if dp is not None and dp.training and not 0.0 <= float(dp.p) < 1.0:      # p = 1 drops everything: general path
             return None
-        if any(t is not None and (t.dtype != torch.float32 or t.device != x.device)
-               for t in (lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        tensors = (lin.weight, lin.bias) + ((bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else ())
+        if any(t is not None and (t.dtype != torch.float32 or t.device != x.device) for t in tensors):
             return None
-        plan.append(_Layer(lin, bn, float(dp.p) if (dp is not None and dp.training) else 0.0))
+        plan.append(_Layer(lin, bn, float(dp.p) if (dp is not None and dp.training) else 0.0, bn is None or not bn.training))
         width = lin.out_features
-    if head.in_features != width or x.shape[0] < 2:
+    if head.in_features != width or x.shape[0] < (1 if all(L.fixed for L in plan) else 2):
         return None
     if any(t is not None and (t.dtype != torch.float32 or t.device != x.device) for t in (head.weight, head.bias)):
         return None
@@ -125,14 +137,14 @@ def fused_tail_plan(seq: nn.Sequential, x, groups) -> Optional[List[_Layer]]:
 
 
 def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Optional[torch.Tensor] = None, ride: bool = False):
-    """Keep bits of every layer with dropout, one launch; `zero_buf` (optional, fp32, a multiple of 4 elements) is
-    zero-filled by the same launch.  Without any dropout layer nothing is launched and zero_buf is NOT touched.
-    ride=True: nothing is launched here; returns (bits, job) with job the mi_tail_mask_ride (and the host arrays it points
-    at) for the first layer's mi_tail_bn_finalize_fwd_r, or None when there is nothing to do."""
+    """Keep bits of every layer with dropout; `zero_buf` (optional, fp32, a multiple of 4 elements) is zero-filled by the
+    same launch.  With neither nothing is launched.  ride=True: nothing is launched here; returns (bits, job) with job the
+    mi_tail_mask_ride (and the host arrays it points at) for the first layer's mi_tail_bn_finalize_fwd_r, or None when
+    there is nothing to do."""
     lib = _lib.load()
     n = len(plan)
     bits = [torch.empty(M * L.lin.out_features // 8, dtype=torch.uint8, device=dev) if L.p > 0 else None for L in plan]
-    if not any(b is not None for b in bits) and (zero_buf is None or not ride):
+    if not any(b is not None for b in bits) and zero_buf is None:
         return (bits, None) if ride else bits
     salts = (ctypes.c_int64 * n)(*[SALT * (i + 1) for i in range(n)])
     ps = (ctypes.c_float * n)(*[L.p for L in plan])
@@ -149,9 +161,39 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Option
     return bits
 
 
+def _fixed_constants(plan: List[_Layer], dev, stream):
+    """(mu, sc, be, rstd) [4, N] of every layer that normalises with fixed statistics or not at all, ONE launch for all of
+    them (mi_tail_affine_consts); {layer index: tensor}."""
+    idx = [i for i, L in enumerate(plan) if L.fixed]
+    if not idx:
+        return {}
+    n = len(idx)
+    out = {i: torch.empty((4, plan[i].lin.out_features), dtype=torch.float32, device=dev) for i in idx}
+    P = ctypes.c_void_p * n
+
+    def arr(f):
+        return P(*[f(plan[i]) or 0 for i in idx])
+
+    def bn_of(L, name):
+        return _lib.ptr(getattr(L.bn, name)) if L.bn is not None else None
+
+    # (every host array stays referenced until the call has returned: the library reads them at call time)
+    widths = (ctypes.c_int32 * n)(*[plan[i].lin.out_features for i in idx])
+    eps = (ctypes.c_float * n)(*[float(plan[i].bn.eps) if plan[i].bn is not None else 0.0 for i in idx])
+    gam, bet = arr(lambda L: bn_of(L, "weight")), arr(lambda L: bn_of(L, "bias"))
+    rme, rva = arr(lambda L: bn_of(L, "running_mean")), arr(lambda L: bn_of(L, "running_var"))
+    bia = arr(lambda L: _lib.ptr(L.lin.bias))
+    outs = [P(*[out[i][r].data_ptr() for i in idx]) for r in range(4)]
+    _lib.check(_lib.load().mi_tail_affine_consts(
+        n, ctypes.addressof(widths), ctypes.addressof(gam), ctypes.addressof(bet), ctypes.addressof(rme), ctypes.addressof(rva),
+        ctypes.addressof(bia), ctypes.addressof(eps), ctypes.addressof(outs[0]), ctypes.addressof(outs[1]),
+        ctypes.addressof(outs[2]), ctypes.addressof(outs[3]), stream), "mi_tail_affine_consts")
+    return out
+
+
 class _State:
     """What the forward leaves for the backward: tensors (flattened for ctx.save_for_backward) + plain metadata."""
-    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat", "zsize", "boff")
+    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat_b", "zsize", "boff", "hoff")
 
 
 def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
@@ -161,30 +203,38 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
     s = _lib.stream_ptr(dev)
     M = x.shape[0]
     k = len(plan)
-    # the backward pass's accumulation buffer (split-K weight gradients + the exactly-zero Linear bias gradients) is
-    # zero-filled by the mask launch of THIS forward when there is one: no fill launch in the backward
-    zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
-    zsize = (zsize + 3) // 4 * 4
+    grad = bool(getattr(plan, "grad", True))
     merge = MERGE_JOINS
-    R = STAT_REPS
-    stat = STAT_SUMS and not merge and not _kernels.DETERMINISTIC and k >= 2
-    foff, boff = {}, {}                 # float offsets of the forward sums of layer i >= 1 / the backward sums of layer i <= k-2
-    if stat:
-        for i in range(1, k):
+    R, Rh = STAT_REPS, HEAD_REPS
+    sums_ok = STAT_SUMS and not merge and not _kernels.DETERMINISTIC
+    stat_f = [sums_ok and i >= 1 and not L.fixed for i, L in enumerate(plan)]      # this product ADDS its statistics
+    stat_b = sums_ok and grad
+    # ONE zero-filled buffer per step for everything that accumulates: the split-K weight gradients and the (exactly zero)
+    # bias gradients under a training-mode BatchNorm (backward), the forward sums of the layers above the first, the
+    # backward column sums of every layer and of the head
+    zsize = 0
+    if grad:
+        zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
+        zsize = (zsize + 3) // 4 * 4
+    foff, boff, hoff = {}, {}, None
+    for i, L in enumerate(plan):
+        if stat_f[i]:
             foff[i] = zsize
-            zsize += R * 2 * plan[i].lin.out_features
+            zsize += R * 2 * L.lin.out_features
+    if stat_b:
         for i in range(k - 1):
             boff[i] = zsize
             zsize += R * 2 * plan[i].lin.out_features
-    zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if (stat or any(L.p > 0 for L in plan)) else None
-    # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that
-    # launch exists and a LATER kernel can advance the seed
-    ride = RIDE_MASKS and not merge and k >= 2
+        hoff = zsize
+        zsize += Rh * (3 * plan[-1].lin.out_features + 4)
+        zsize = (zsize + 3) // 4 * 4
+    zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if zsize else None
+    # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that launch
+    # exists (a training-mode BatchNorm on the first layer) and a LATER kernel can advance the seed
+    ride = RIDE_MASKS and not merge and k >= 2 and not plan[0].fixed
     bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
-    if stat and job is None:            # (MI_TAIL_RIDE_MASKS=0: the mask launch filled it only if there are bits to draw)
-        if not any(b is not None for b in bits):
-            zeros.zero_()
-    keep_inputs = not _kernels.DETERMINISTIC
+    keep_inputs = grad and not _kernels.DETERMINISTIC
+    fixed_c = _fixed_constants(plan, dev, s)
     Zs, consts, acts = [], [], []
     prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
     any_bits = any(b is not None for b in bits)
@@ -203,38 +253,42 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
     for i, L in enumerate(plan):
         N, K = L.lin.out_features, L.lin.in_features
         Z = torch.empty((M, N), dtype=torch.float32, device=dev)
-        sums_here = stat and i >= 1       # this product adds shifted sums; the NEXT kernel derives the constants
-        if sums_here:
-            part = zeros[foff[i]: foff[i] + R * 2 * N]
-            shift = torch.empty((N,), dtype=torch.float32, device=dev)
+        part = shift = None
+        if L.fixed:
+            c = fixed_c[i]
         else:
-            part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
-            shift = None
-        c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
+            c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
+            if stat_f[i]:
+                part = zeros[foff[i]: foff[i] + R * 2 * N]
+                shift = torch.empty((N,), dtype=torch.float32, device=dev)
+            else:
+                part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
         # the layer's input activation as its operand load computes it, kept for the weight gradient (not in
         # deterministic mode, whose weight-gradient kernel recomputes it)
         a_in = torch.empty((M, K), dtype=torch.float32, device=dev) if (keep_inputs and prev_c is not None) else None
         stats = pending_struct() if pending is not None else None
-        bn = L.bn
+        pending = None
         _lib.check(lib.mi_tail_fwd_gemm_s(
             prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
             _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
-            float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, part.data_ptr(), _lib.ptr(a_in),
-            M, N, K, ctypes.byref(stats) if stats is not None else None, R if sums_here else 0, _lib.ptr(shift),
-            bn.running_mean.data_ptr() if sums_here else None, _lib.ptr(L.lin.bias) if sums_here else None, s),
+            float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, Z.data_ptr(), N, _lib.ptr(part), _lib.ptr(a_in),
+            M, N, K, ctypes.byref(stats) if stats is not None else None, R if stat_f[i] else 0, _lib.ptr(shift),
+            L.bn.running_mean.data_ptr() if stat_f[i] else None, _lib.ptr(L.lin.bias) if stat_f[i] else None, s),
             "mi_tail_fwd_gemm_s")
         acts.append(a_in if a_in is not None else x.new_empty(0))
-        if sums_here:
+        if L.fixed:
+            pass
+        elif stat_f[i]:
             pending = (part, L, c, shift)
         elif merge:
             pending = (part, L, c)
         else:
-            pending = None
-            late_bump = stat or i != bump_at       # (stat: the first deriving kernel advances the seed)
+            bn = L.bn
+            late_bump = (sums_ok and k >= 2) or i != bump_at       # (sums: the first deriving kernel advances the seed)
             _lib.check(lib.mi_tail_bn_finalize_fwd_r(
                 part.data_ptr(), M, N, bn.weight.data_ptr(), bn.bias.data_ptr(), _lib.ptr(L.lin.bias),
                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (any_bits and not late_bump) else None,
+                bn.num_batches_tracked.data_ptr(), seed.data_ptr() if (any_bits and not late_bump and not bumped) else None,
                 c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(),
                 ctypes.byref(job[0]) if (i == 0 and job is not None) else None, s), "mi_tail_bn_finalize_fwd_r")
             bumped = bumped or (any_bits and not late_bump)
@@ -244,19 +298,25 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
     out = torch.empty((M, 1), dtype=torch.float32, device=dev)
     add = None if last_add is None else _kernels._f32c(last_add).view(-1)
     N = plan[-1].lin.out_features
-    stats = pending_struct() if pending is not None else None
+    if pending is not None:
+        stats = pending_struct()
+    elif any_bits and not bumped:      # nothing left to join: the head only advances the seed (part = NULL)
+        stats = _BnFwd(None, None, None, None, None, None, None, seed.data_ptr(), None, None, None, None, 0.0, 0.0, None, 0)
+        bumped = True
+    else:
+        stats = None
     _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
                                       float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
                                       out.data_ptr(), M, N, ctypes.byref(stats) if stats is not None else None, s),
                "mi_tail_head_fwd_m")
     st = _State()
     st.k, st.plan, st.zeros = k, plan, zeros
-    st.stat, st.zsize, st.boff = stat, zsize, boff
+    st.stat_b, st.zsize, st.boff, st.hoff = stat_b, zsize, boff, hoff
     st.ps = [L.p for L in plan]
     st.has_head_bias = b_head is not None
     st.add_shape = None if last_add is None else tuple(last_add.shape)
     saved = [x, w_head, *Ws, *Zs, *consts, *[b if b is not None else x.new_empty(0) for b in bits],
-             *[L.bn.weight for L in plan], *acts]
+             *[L.bn.weight if L.bn is not None else x.new_empty(0) for L in plan], *acts]
     st.n_saved = len(saved)
     return out, saved, st
 
@@ -271,21 +331,19 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
     x, w_head = saved[0], saved[1]
     Ws, Zs, consts = saved[2:2 + k], saved[2 + k:2 + 2 * k], saved[2 + 2 * k:2 + 3 * k]
     bits = [b if b.numel() else None for b in saved[2 + 3 * k:2 + 4 * k]]
-    gammas = saved[2 + 4 * k:2 + 5 * k]
+    gammas = [t if t.numel() else None for t in saved[2 + 4 * k:2 + 5 * k]]
     acts = [a if a.numel() else None for a in saved[2 + 5 * k:2 + 6 * k]]
     dev = x.device
     s = _lib.stream_ptr(dev)
     M = x.shape[0]
     gvec = _kernels._f32c(g).view(M)
     later = []           # weight-gradient products for ONE launch at the end
-    # one zero-filled buffer for everything that must start at zero: the split-K weight gradients and the (exactly zero)
-    # gradients of the hidden Linear biases — one fill launch instead of 2k
     sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
     zeros = st.zeros                       # filled by the forward's mask launch; a second backward needs a fresh one
     st.zeros = None
     if zeros is None:
         zeros = torch.zeros((max(st.zsize, sum(a + b for a, b in sizes)),), dtype=torch.float32, device=dev)
-    stat, R = st.stat, STAT_REPS
+    stat, R, Rh = st.stat_b, STAT_REPS, HEAD_REPS
     zoff = [0]
     for a, b in sizes:
         zoff.append(zoff[-1] + a + b)
@@ -294,44 +352,53 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
     # ---- head: dy of the last hidden layer, its column sums, dw / db of the head
     N = Zs[-1].shape[1]
     c = consts[-1]
-    nblk = int(lib.mi_tail_head_blocks(M))
     DY = torch.empty((M, N), dtype=torch.float32, device=dev)
-    part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
-    wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
-    _lib.check(lib.mi_tail_head_bwd(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(st.ps[-1]),
-                                    _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
-                                    wpart.data_ptr(), M, N, s), "mi_tail_head_bwd")
+    if stat:            # sums added into Rh zeroed rows: joined by the next product's prologue, no finalize launch
+        nblk = Rh
+        part = zeros[st.hoff: st.hoff + Rh * 2 * N].view(Rh, N, 2)
+        wpart = zeros[st.hoff + Rh * 2 * N: st.hoff + Rh * (3 * N + 4)].view(Rh, N + 4)
+    else:
+        nblk = int(lib.mi_tail_head_blocks(M))
+        part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
+        wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
+    _lib.check(lib.mi_tail_head_bwd_s(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(st.ps[-1]),
+                                      _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
+                                      wpart.data_ptr(), Rh if stat else 0, M, N, s), "mi_tail_head_bwd_s")
     dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
     db_head = torch.empty((1,), dtype=torch.float32, device=dev)
     part_rows, wp, nw = nblk, wpart, nblk
     dx = None
     for i in range(k - 1, -1, -1):
         N, K = Zs[i].shape[1], Ws[i].shape[1]
+        L = plan[i]
         c = consts[i]
         dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
         dzc = torch.empty((3, N), dtype=torch.float32, device=dev)         # al, bz, de
+        dbias = torch.empty((N,), dtype=torch.float32, device=dev) if (L.fixed and L.lin.bias is not None) else None
         below = Zs[i - 1] if i > 0 else x
         bc = consts[i - 1] if i > 0 else None
         bp = st.ps[i - 1] if i > 0 else 0.0
         bb = bits[i - 1] if i > 0 else None
         runs_dgrad = i > 0 or need_x
         # the column sums behind dz's constants: joined in the input-gradient product's prologue, or (no such product
-        # for this layer, or MERGE_JOINS off) by the finalize launch
+        # for this layer, or the joined forms off) by the finalize launch
         sums = None
-        if (MERGE_JOINS or stat) and runs_dgrad and part_rows <= 128:     # (the head's 256 partial rows keep their finalize launch)
-            sums = _BnBwd(part.data_ptr(), gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+        if (MERGE_JOINS or stat) and runs_dgrad and part_rows <= 128:     # (256 partial rows of the head keep their finalize launch)
+            sums = _BnBwd(part.data_ptr(), _lib.ptr(gammas[i]), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                           dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp),
                           dw_head.data_ptr() if wp is not None else None, db_head.data_ptr() if wp is not None else None,
-                          part_rows, nw)
+                          part_rows, nw, _lib.ptr(dbias), int(L.fixed))
         else:
-            _lib.check(lib.mi_tail_bn_finalize_bwd(
-                part.data_ptr(), part_rows, M, N, gammas[i].data_ptr(), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+            _lib.check(lib.mi_tail_bn_finalize_bwd_a(
+                part.data_ptr(), part_rows, M, N, _lib.ptr(gammas[i]), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                 dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp), nw, dw_head.data_ptr() if wp is not None else None,
-                db_head.data_ptr() if wp is not None else None, s), "mi_tail_bn_finalize_bwd")
+                db_head.data_ptr() if wp is not None else None, int(L.fixed), _lib.ptr(dbias), s), "mi_tail_bn_finalize_bwd_a")
         wp = None
-        grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
-        if need_params[4 * i + 1] and plan[i].lin.bias is not None:
-            grads[4 * i + 1] = zeros[zoff[i] + N * K: zoff[i + 1]]     # exact: the batch mean is removed
+        if L.bn is not None:
+            grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
+        if need_params[4 * i + 1] and L.lin.bias is not None:
+            # under a training-mode BatchNorm the batch mean is removed: exactly zero; otherwise al * sum dy
+            grads[4 * i + 1] = dbias if L.fixed else zeros[zoff[i] + N * K: zoff[i + 1]]
         a_in = x if i == 0 else acts[i]
         defer = need_params[4 * i] and runs_dgrad and a_in is not None and not _kernels.DETERMINISTIC
         dz_keep = torch.empty((M, N), dtype=torch.float32, device=dev) if defer else None
@@ -474,13 +541,16 @@ class DeepFMFusedFn(torch.autograd.Function):
         return (None, None, None, None, None, gW, gw1, gb, None, None, *grads)
 
 
-def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
-                   last_add: Optional[torch.Tensor]) -> torch.Tensor:
+def _plan_params(plan, head):
     params = []
     for L in plan:
-        params += [L.lin.weight, L.lin.bias, L.bn.weight, L.bn.bias]
-    params += [head.weight, head.bias]
-    return FusedTailFn.apply(plan, head, seed, x, last_add, *params)
+        params += [L.lin.weight, L.lin.bias, L.bn.weight if L.bn is not None else None, L.bn.bias if L.bn is not None else None]
+    return params + [head.weight, head.bias]
+
+
+def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
+                   last_add: Optional[torch.Tensor]) -> torch.Tensor:
+    return FusedTailFn.apply(plan, head, seed, x, last_add, *_plan_params(plan, head))
 
 
 # DeepFM's lookup backward in the epilogue of the tail's first input-gradient product (MI_FUSED_FM_EPILOGUE=0: two nodes,
@@ -490,8 +560,4 @@ FM_EPILOGUE = os.environ.get("MI_FUSED_FM_EPILOGUE", "1") == "1"
 
 def run_fused_deepfm(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, idx, offsets, W, w1, bias,
                      sparse_W: bool, sparse_w1: bool) -> torch.Tensor:
-    params = []
-    for L in plan:
-        params += [L.lin.weight, L.lin.bias, L.bn.weight, L.bn.bias]
-    params += [head.weight, head.bias]
-    return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *params)
+    return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *_plan_params(plan, head))

@@ -226,9 +226,10 @@ def test_lookup_backward_in_the_dgrad_epilogue_vs_oracle_and_vs_the_two_node_pat
             if k.startswith("linear_layer") or (k.endswith(".bias") and k.startswith("_deep_branch") and p[k].grad.abs().max() < 1e-6):
                 continue
             assert_close(gr, p[k].grad, 2e-4, atol, f"grad {k} fused={fused}")
-    # the two paths share every kernel but the last: same logits bit for bit, table gradients equal up to the order in
-    # which a row's duplicates are summed when densified
-    assert torch.equal(got[True][0], got[False][0])
+    # the two paths share every forward kernel: same logits up to the order of the float atomics that accumulate the
+    # BatchNorm statistics above one 64-row tile; table gradients equal up to the order in which a row's duplicates are
+    # summed when densified
+    assert_close(got[True][0], got[False][0], 1e-5, 1e-6, "logits: fused epilogue vs two-node path")
     for k in ("embedding._emb_module.weight", "fc.weight", "_bias"):
         assert_close(got[True][1][k], got[False][1][k], 1e-5, atol, f"{k}: fused epilogue vs two-node path")
 

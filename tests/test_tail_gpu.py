@@ -36,10 +36,10 @@ def _fused_tail_on(request, monkeypatch):
     monkeypatch.setattr(_tail_mod, "MERGE_JOINS", request.param == "joins")
 
 
-def _seq(inp, hidden, p):
+def _seq(inp, hidden, p, bn=True):
     layers = []
     for h in hidden:
-        layers += [nn.Linear(inp, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(p)]
+        layers += [nn.Linear(inp, h)] + ([nn.BatchNorm1d(h)] if bn else []) + [nn.ReLU(), nn.Dropout(p)]
         inp = h
     layers.append(nn.Linear(inp, 1))
     seq = nn.Sequential(*layers)
@@ -93,14 +93,28 @@ CASES = [
 ]
 
 
+# the four ways a layer normalises: batch statistics (training-mode BatchNorm1d), running statistics (model.eval(): the
+# reference's validation / inference path, scripts/deepfm/infer_deepfm.py), and none at all (use_batchnorm=False, DeepFM's
+# constructor default src/models/deepfm.py:20) in training (with dropout) and in eval mode
+MODES = ["bn-train", "bn-eval", "nobn-train", "nobn-eval"]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("M,K,hidden,p", CASES)
-def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p):
+def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p, mode, monkeypatch):
+    if mode != "bn-train" and (M, K) == (4096, 352):
+        pytest.skip("one full-size case per mode is enough")
+    # the general path (library products through PyTorch) must not be what computes any of this
+    monkeypatch.setattr(_mlp, "_LinearFn", None)
     torch.manual_seed(M + K + len(hidden))
-    seq = _seq(K, hidden, p).train()
+    training = mode.endswith("train")
+    seq = _seq(K, hidden, p, bn=mode.startswith("bn")).train(training)
     x = torch.randn(M, K) * 0.7 + 0.2
     add = torch.randn(M)
     G = torch.randn(M, 1)
     seed_value = 4242 + M
+    if not training:
+        p = 0.0
     masks = [tail_keep_scale(seed_value, SALT * (i + 1), M, h, p) for i, h in enumerate(hidden)]
 
     ref64 = _reference(seq, x, add, masks, torch.float64)
@@ -128,7 +142,7 @@ def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p):
     check("dadd", fa.grad, ref64[2].grad, ref32[2].grad)
     p64, p32, pf = dict(ref64[0].named_parameters()), dict(ref32[0].named_parameters()), dict(fs.named_parameters())
     lin_in_front_of_bn = {f"{i}.bias" for i, m in enumerate(seq) if isinstance(m, nn.Linear) and i + 1 < len(seq)
-                          and isinstance(seq[i + 1], nn.BatchNorm1d)}
+                          and isinstance(seq[i + 1], nn.BatchNorm1d) and training}
     for name in p64:
         if name in lin_in_front_of_bn:
             # analytically zero (the batch mean is removed); the stock modules return rounding noise, the fused node 0
@@ -233,14 +247,38 @@ def test_fused_tail_default_and_deterministic_weight_gradients_agree():
             assert torch.equal(ga, gb), name
 
 
+def test_inference_without_grad_runs_the_own_kernels_and_keeps_nothing(monkeypatch):
+    """torch.no_grad() + eval(): what the reference's inference scripts time (scripts/deepfm/infer_deepfm.py:318-352, batch
+    64 by default; one sample must work too).  Same values as the stock modules, no general-path product, no state change."""
+    monkeypatch.setattr(_mlp, "_LinearFn", None)
+    for bn in (True, False):
+        torch.manual_seed(3)
+        seq = _seq(416, [400, 400, 400], 0.5, bn=bn).to(DEV).eval()
+        before = copy.deepcopy(seq.state_dict())
+        for M in (1, 64, 4096):
+            x, add = torch.randn(M, 416, device=DEV), torch.randn(M, device=DEV)
+            with torch.no_grad():
+                out = run_tail(seq, x, last_add=add)
+                ref = seq.double()(x.double()) + add.double().view(-1, 1)
+                seq.float()
+            assert out.shape == (M, 1) and not out.requires_grad
+            assert float((out.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max().clamp_min(1.0))
+        for k, v in seq.state_dict().items():
+            assert torch.equal(v, before[k]), k
+
+
 def test_patterns_outside_the_fused_node_keep_the_general_path():
     seq = _seq(16, [8], 0.0).to(DEV)
     x = torch.randn(32, 16, device=DEV)
-    assert fused_tail_plan(seq.eval(), x, _mlp._groups(seq)) is None            # eval-mode BatchNorm
+    plan = fused_tail_plan(seq.eval(), x, _mlp._groups(seq))                    # eval-mode BatchNorm: fixed statistics
+    assert plan is not None and all(L.fixed for L in plan) and plan.grad
     seq.train()
-    assert fused_tail_plan(seq, x, _mlp._groups(seq)) is not None
+    plan = fused_tail_plan(seq, x, _mlp._groups(seq))
+    assert plan is not None and not any(L.fixed for L in plan)
     with torch.no_grad():
-        assert fused_tail_plan(seq, x, _mlp._groups(seq)) is None              # no autograd: inference path
+        plan = fused_tail_plan(seq, x, _mlp._groups(seq))                      # no autograd: nothing is kept for a backward
+        assert plan is not None and not plan.grad
+    assert fused_tail_plan(seq, x[:1], _mlp._groups(seq)) is None               # batch statistics need two samples
     odd = _seq(16, [12], 0.0).to(DEV).train()                                   # 12 columns: not a multiple of 8
     assert fused_tail_plan(odd, x, _mlp._groups(odd)) is None
     out = run_tail(odd, x)                                                      # still runs (general path)
