@@ -883,6 +883,29 @@ MI_API int mi_tail_wgrad_gemm(const float *DY, const float *Zl, int32_t ld, cons
                               const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *slab,
                               float *dW, int32_t M, int32_t N, int32_t K, void *stream);
 
+/* ---- a9: DHEmbedding's MLP (src/models/embeddings/dh_embedding.py:100-117,345-356) -----------------------------------
+ * Per layer Linear -> Mish (use_bn 0) | Linear -> BatchNorm1d -> Mish (use_bn 2, the default) | Linear -> Mish ->
+ * BatchNorm1d (use_bn 1, the LightGCN configs).  The contractions are mi_tail_fwd_gemm_s / mi_tail_dgrad_gemm_s on plain
+ * operands (+ mi_gemm_f32_multi for dW); these three entry points are the column-wise element work between them, with
+ * BatchNorm statistics / gradient column sums as per-64-row-tile partials in the layouts mi_tail_bn_finalize_fwd / _bwd join.
+ *   mi_col_act_fwd: out[M,N] = ACT((in - mu[c]) sc[c] + be[c]), act 0 = identity, 1 = mish (x tanh(log1p(exp x)), as
+ *     torch's CPU kernel); mu / sc / be nullable (0 / 1 / 0); in has row pitch ld; part (nullable,
+ *     mi_tail_part_elems(M, N) floats) = (mean, M2) of `out` per tile and column.
+ *   mi_col_act_bwd: dy = g ACT'(pre) (dy nullable: with act 0 it equals g), part[tile, N, 2] = (sum dy, sum dy (in - mu)).
+ *   mi_bn_mish_bwd (use_bn 1: a = BatchNorm(m), m = mish(z + bias)): dz = (al g + bz (m - mu) + de) mish'(z + bias),
+ *     part[tile, N, 2] = (sum dz, 0); al / bz / de as mi_tail_bn_finalize_bwd[_a] writes them. */
+MI_API int mi_col_act_fwd(const float *in, int32_t ld, const float *mu, const float *sc, const float *be, int32_t act,
+                          float *out, float *part, int32_t M, int32_t N, void *stream);
+MI_API int mi_col_act_bwd(const float *g, const float *in, int32_t ld, const float *mu, const float *sc, const float *be,
+                          int32_t act, float *dy, float *part, int32_t M, int32_t N, void *stream);
+/* dz[M,N] = al dy + bz (z - mu) + de: the BatchNorm backward materialised (a layer whose input needs no gradient has no
+ * input-gradient product that would compute it in its operand load) */
+MI_API int mi_bn_dz(const float *dy, const float *z, int32_t ldz, const float *mu, const float *al, const float *bz,
+                    const float *de, float *dz, int32_t M, int32_t N, void *stream);
+MI_API int mi_bn_mish_bwd(const float *g, const float *m_act, const float *z, int32_t ldz, const float *bias,
+                          const float *mu, const float *al, const float *bz, const float *de, float *dz, float *part,
+                          int32_t M, int32_t N, void *stream);
+
 /* ---- §8e: the sharded lookup's collectives on the CALLER's stream (recsys-benchmark_amd/csrc/comm.hip) ------------------
  * No reference counterpart.  The library owns its own RCCL communicator (resolved with dlopen at first use: every entry
  * point returns MI_ERR_UNSUPPORTED when no librccl can be loaded) so that the all-to-alls and the all-reduce are enqueued

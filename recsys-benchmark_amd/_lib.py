@@ -111,6 +111,10 @@ SIGNATURES = {
     "mi_slot_fm_fwd": [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "mi_slot_fm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p],
     "mi_prof_enable": [_i32],
+    "mi_col_act_fwd": [_p, _i32, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p],
+    "mi_col_act_bwd": [_p, _p, _i32, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p],
+    "mi_bn_dz": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p],
+    "mi_bn_mish_bwd": [_p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_tail_dropout_masks": [_p, _i32, _p, _p, _p, _p, _i32, _p],
     "mi_tail_dropout_masks_z": [_p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p],
     "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p],

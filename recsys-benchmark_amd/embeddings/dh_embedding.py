@@ -45,6 +45,11 @@ def large_primes() -> torch.Tensor:
     return _primes_cache
 
 
+import os as _os
+
+OWN_MLP = _os.environ.get("MI_DHE_OWN_MLP", "1") == "1"      # 0: the MLP as nn.Sequential on the library GEMM (round-3 form)
+
+
 class DHEmbedding(IEmbedding):
     COUNTER = 0
 
@@ -207,7 +212,12 @@ class DHEmbedding(IEmbedding):
             is_flatten = True
             batch, num_field, dimension = embs.shape
             embs = embs.reshape(batch * num_field, dimension)
-        outs = self._seq(embs)
+        # the MLP on the library's own kernels (mish_mlp.py: MFMA products + csrc/mish_mlp.hip) when the pattern fits;
+        # nn.Sequential (library products through PyTorch) otherwise
+        from .. import mish_mlp as _mm
+
+        plan = _mm.mish_mlp_plan(self._seq, self._use_bn, embs) if OWN_MLP else None
+        outs = _mm.run_mish_mlp(plan, self._use_bn, embs) if plan is not None else self._seq(embs)
         if is_flatten:
             outs = outs.reshape(batch, num_field, -1)
         return outs

@@ -219,6 +219,72 @@ def test_dhe_matches_reference_golden(name):
         assert_close(emb(g.t("x2").to(DEV)), g.t("out2"), 1e-4, 1e-5, "compute_v2")
 
 
+@pytest.mark.parametrize("use_bn", [0, 1, 2])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("n,k,hidden,D", [(3000, 1024, [64], 16), (257, 64, [32, 32], 16), (70, 128, [], 8)])
+def test_dhe_mlp_on_own_kernels_vs_float64_all_orderings(use_bn, training, n, k, hidden, D, monkeypatch):
+    """DHEmbedding._forward_mlp (src/models/embeddings/dh_embedding.py:100-117,345-356) on mish_mlp.py's kernels for the
+    three layer orderings (use_bn 0: Linear-Mish, 1: Linear-Mish-BatchNorm, 2: Linear-BatchNorm-Mish), training and eval:
+    output, every parameter gradient and the BatchNorm running statistics against the same nn.Sequential in float64, held
+    to a multiple of the stock float32 modules' own error; nn.Sequential.forward must not be what computes it."""
+    import copy
+
+    from recsys_benchmark_amd import mish_mlp as mm
+
+    torch.manual_seed(n + k + use_bn)
+    DHEmbedding.COUNTER = 0
+    emb = DHEmbedding(n, D, None, k, list(hidden), use_bn=use_bn, cached=False)
+    DHEmbedding.COUNTER = 0
+    seq = emb._seq
+    for m in seq:
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    seq.train(training)
+    x = torch.rand(n, k) * 2 - 1
+    G = torch.randn(n, D)
+    refs = []
+    for dt in (torch.float64, torch.float32):
+        r = copy.deepcopy(seq).to(dt)
+        out = r(x.to(dt))
+        (out * G.to(dt)).sum().backward()
+        refs.append((r, out))
+    mine = copy.deepcopy(seq).to(DEV)
+    xd = x.to(DEV)
+    assert mm.mish_mlp_plan(mine, use_bn, xd) is not None
+    monkeypatch.setattr(torch.nn.Sequential, "forward", lambda self, *a: (_ for _ in ()).throw(AssertionError("stock Sequential ran")))
+    emb._seq = mine
+    out = emb._forward_mlp(xd)
+    (out * G.to(DEV)).sum().backward()
+    monkeypatch.undo()
+
+    def check(name, got, r64, r32, kf=16.0, floor=2e-6):
+        got, r64, r32 = got.detach().double().cpu(), r64.detach().double(), r32.detach().double()
+        scale = r64.abs().max().clamp_min(1e-30)
+        err_f, err_s = (got - r64).abs().max() / scale, (r32 - r64).abs().max() / scale
+        assert err_f <= max(kf * err_s, floor), f"{name}: own {err_f:.3e} vs stock float32 {err_s:.3e}"
+
+    check("out", out, refs[0][1], refs[1][1])
+    p64, p32, pm = dict(refs[0][0].named_parameters()), dict(refs[1][0].named_parameters()), dict(mine.named_parameters())
+    for name in p64:
+        if use_bn == 2 and training and name.endswith(".bias") and isinstance(seq[int(name.split(".")[0])], torch.nn.Linear):
+            assert float(pm[name].grad.abs().max()) == 0.0      # a bias in front of a training-mode BatchNorm: exactly zero
+            continue
+        check(name, pm[name].grad, p64[name].grad, p32[name].grad)
+    b64, b32, bm = dict(refs[0][0].named_buffers()), dict(refs[1][0].named_buffers()), dict(mine.named_buffers())
+    for name in b64:
+        if name.endswith("num_batches_tracked"):
+            assert int(bm[name]) == int(b64[name])
+        else:
+            check(name, bm[name], b64[name], b32[name])
+    with torch.no_grad():            # inference: same values, nothing kept
+        out2 = emb._forward_mlp(xd) if not training else None
+    if out2 is not None:
+        assert torch.equal(out2, out.detach())
+
+
 def test_dhe_per_item_hash_family_matches_reference_golden():
     """use_universal_hash=False (dh_embedding.py:155-196): the host-built feature table is bit-exact, the lookups are the
     HIP row gather + MLP, cached and per-unique-id flows agree with the reference's outputs."""
