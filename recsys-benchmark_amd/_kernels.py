@@ -625,6 +625,80 @@ class CsrPlan:
         return out
 
 
+    # ---- task-balanced, slice-phased form (mi_spmm_sliced, round 4) ----
+    SLICE_BYTES = 2 << 20           # rows of X per column slice: half of an XCD's 4 MiB L2
+    TASK_NNZ = 256                  # nonzeros per task (a wave's share of every slice: ~TASK_NNZ / slices gathers)
+    TASK_ROWS = 8                   # kTaskRows of csrc/spmm.hip
+
+    def sliced(self, D: int, transposed: bool):
+        """The task plan of A (or A^T) for rows of D floats, built once per (pattern, D) on the host: non-hub rows packed
+        in row order into tasks of <= 8 rows and <= TASK_NNZ nonzeros, every task's edges sorted by column slice.  None
+        when the kernel cannot take the matrix (columns >= 2^28, D outside the float4 kernels, > 63 slices)."""
+        key = (int(D), bool(transposed))
+        cache = self.__dict__.setdefault("_sliced", {})
+        if key in cache:
+            return cache[key]
+        import numpy as np
+
+        crow_d, col_d = (self.crow_t, self.col_t) if transposed else (self.crow, self.col)
+        n_rows, n_cols = (self.shape[1], self.shape[0]) if transposed else self.shape
+        plan = None
+        if _float4_rows(D) and n_cols < (1 << 28) and self.nnz > 0 and n_rows > 0:
+            dev = crow_d.device
+            crow = crow_d.cpu().numpy().astype(np.int64)
+            col = col_d.cpu().numpy().astype(np.int64)
+            deg = crow[1:] - crow[:-1]
+            hub = deg > HUB_DEGREE
+            slice_rows = max(1, self.SLICE_BYTES // (4 * D))
+            S = -(-n_cols // slice_rows)
+            if S > 63:
+                slice_rows = -(-n_cols // 63)
+                S = -(-n_cols // slice_rows)
+            task_of = np.full(n_rows, -1, dtype=np.int64)
+            j_of = np.zeros(n_rows, dtype=np.int64)
+            t, cnt, nn = 0, 0, 0
+            degl, hubl = deg.tolist(), hub.tolist()
+            for r in range(n_rows):
+                if hubl[r]:
+                    continue
+                d = degl[r]
+                if cnt == self.TASK_ROWS or (cnt > 0 and nn + d > self.TASK_NNZ):
+                    t, cnt, nn = t + 1, 0, 0
+                task_of[r], j_of[r] = t, cnt
+                cnt += 1
+                nn += d
+            T = t + 1 if (~hub).any() else 0
+            erow = np.repeat(np.arange(n_rows), deg)
+            keep = np.nonzero(~hub[erow])[0]
+            ek = task_of[erow[keep]] * S + col[keep] // slice_rows
+            order = np.argsort(ek, kind="stable")
+            perm = keep[order]
+            ecol = (col[perm] | (j_of[erow[perm]] << 28)).astype(np.int64)
+            ecol = np.where(ecol >= 2 ** 31, ecol - 2 ** 32, ecol).astype(np.int32)       # bit pattern of the uint32 word
+            tptr = np.zeros(T * S + 1, dtype=np.int64)
+            if T:
+                tptr[1:] = np.cumsum(np.bincount(ek, minlength=T * S))
+            trows = np.full((max(T, 1), self.TASK_ROWS), -1, dtype=np.int32)
+            nh = np.nonzero(~hub)[0]
+            trows[task_of[nh], j_of[nh]] = nh
+            plan = dict(T=T, S=int(S), tptr=torch.from_numpy(tptr.astype(np.int32)).to(dev),
+                        trows=torch.from_numpy(trows).to(dev), ecol=torch.from_numpy(ecol).to(dev),
+                        perm=torch.from_numpy(perm.astype(np.int64)).to(dev),
+                        long_rows=torch.from_numpy(np.nonzero(hub)[0].astype(np.int32)).to(dev))
+        cache[key] = plan
+        return plan
+
+    def sliced_values(self, val: torch.Tensor, D: int, transposed: bool) -> torch.Tensor:
+        """`val` (the values of A, or of A^T when transposed) in the task plan's edge order; cached per values tensor."""
+        key = ("_slicedv", int(D), bool(transposed))
+        hit = self.__dict__.get(key)
+        if hit is not None and self._same_values(hit[0], hit[1], val):
+            return hit[2]
+        out = val.index_select(0, self.sliced(D, transposed)["perm"])
+        self.__dict__[key] = (val, val._version, out)
+        return out
+
+
 # The tiled SpMM (csrc/spmm.hip, round 3: row tiles whose sums live in LDS, edges walked column block by column block,
 # one edge per 16-lane group, LDS float adds) is parity-green and OPT-IN (MI_SPMM_TILED=1): on MI355X it runs 13x SLOWER
 # than the row-per-wave kernels (1073 vs 80 us per Yelp2018-shaped layer) because ds_add_f32 executes a wave's 64 lanes
@@ -633,6 +707,10 @@ class CsrPlan:
 import os as _os
 
 TILED_SPMM = _os.environ.get("MI_SPMM_TILED", "0") == "1"
+# The slice-phased SpMM (round 4, mi_spmm_sliced): "1" (default) = for operands larger than an XCD's L2 (where the
+# row-per-wave kernel re-fetches X from all over it), "0" = never, "2" = always (tests).
+SLICED_SPMM = int(_os.environ.get("MI_SPMM_SLICED", "1"))
+SLICED_MIN_BYTES = 4 << 20
 
 _plans = {}
 
@@ -658,6 +736,20 @@ def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b
     those whose hub_need byte is set (repeats allowed: the outputs must then not alias the inputs); the other rows of Y /
     acc_out are left untouched."""
     lib = _lib.load()
+    n_x = plan.shape[0] if transposed else plan.shape[1]
+    if rows is None and (SLICED_SPMM == 2 or (SLICED_SPMM == 1 and n_x * D * 4 > SLICED_MIN_BYTES)) and not TILED_SPMM:
+        sp = plan.sliced(D, transposed)
+        if sp is not None:
+            crow_h, col_h = (plan.crow_t, plan.col_t) if transposed else (plan.crow, plan.col)
+            ev = plan.sliced_values(val, D, transposed)
+            lr = sp["long_rows"]
+            _lib.check(
+                lib.mi_spmm_sliced(crow_h.data_ptr(), col_h.data_ptr(), val.data_ptr(), sp["tptr"].data_ptr(), sp["trows"].data_ptr(),
+                                   sp["ecol"].data_ptr(), ev.data_ptr(), sp["T"], sp["S"], Xa.data_ptr(), _lib.ptr(Xb), x_split,
+                                   _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale), D,
+                                   lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.ptr(xmask), _lib.stream_ptr(val.device)),
+                "mi_spmm_sliced")
+            return
     tp = plan.tiles(D, transposed) if (TILED_SPMM and not DETERMINISTIC and rows is None) else None
     if tp is not None:
         ev = plan.tile_values(val, D, transposed)

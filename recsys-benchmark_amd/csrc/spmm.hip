@@ -179,6 +179,110 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
 }
 
 
+// ------------------------------------------------------------------------------- task-balanced, slice-phased (round 4) ----
+// What bounds the row-per-wave kernels above is not their arithmetic but WHERE their gathers land: every XCD's waves
+// gather rows of X from all over the operand (17.8 MB at Yelp2018 size against 4 MiB of L2 per XCD: hit rate 0.38, 451 MB
+// of fabric traffic per layer against 54 MB compulsory, profiles/r03_pmc_summary.csv).  This form makes all waves of the
+// chip walk the COLUMNS of A in the same order at the same pace:
+//   * the columns (= rows of X) are cut into S slices of <= ~2 MiB of X;
+//   * the rows of A are packed, once per sparsity pattern, into TASKS of <= 8 rows and <= ~256 nonzeros (hubs keep their
+//     own 16-wave workgroup); a wave owns one task at a time and keeps the 8 running sums in registers (no LDS, no atomics);
+//   * a task's edges are stored slice by slice (flat: an edge = column | row-in-task << 28), so a wave spends about the
+//     same number of gathers in every slice as every other wave: while the chip is "in" slice p, each XCD pulls that
+//     slice of X into its L2 ONCE and serves the ~30 re-uses per row from there.  No synchronisation: the alignment is
+//     only as good as the balance, and only speed depends on it.
+//   * every lane group (LPR lanes = one row of X) takes one edge per step, 4 steps in flight; the edge's contribution goes
+//     to the running sum of its row by 8 predicated adds (static register indices).
+// Sum order is fixed by the plan: bit-reproducible.
+constexpr int kTaskRows = 8;
+constexpr int kTaskColBits = 28;
+
+template <int LPR>
+__global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
+    const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val,      // hubs: the CSR itself
+    const int *__restrict__ tptr, const int *__restrict__ trows, const int *__restrict__ ecol, const float *__restrict__ eval,
+    int n_tasks, int n_slices, Seg2 X, float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out,
+    float scale, const int *__restrict__ long_rows, int n_long, const uint32_t *__restrict__ xmask) {
+  constexpr int NPW = kWave / LPR;
+  constexpr int D = LPR * 4;
+  constexpr int U = 4;
+  __shared__ float4 part[kHubWaves][LPR];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int q = lane % LPR, k = lane / LPR;
+  if ((int)blockIdx.x < n_long) {          // a hub row: the whole workgroup strides it (its columns ascend: slice order too)
+    const int row = long_rows[blockIdx.x];
+    const int lo = crow[row], hi = crow[row + 1];
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q, xmask);
+    a = slot_sum<LPR>(a);
+    if (k == 0) part[w][q] = a;
+    __syncthreads();
+    if (w == 0 && k == 0) {
+      float4 s = part[0][q];
+#pragma unroll
+      for (int i = 1; i < kHubWaves; ++i) {
+        const float4 p = part[i][q];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+      }
+      epilogue4(s, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+    }
+    return;
+  }
+  const int nblk = gridDim.x - n_long;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = (blockIdx.x - n_long) * kHubWaves + w; t < n_tasks; t += nblk * kHubWaves) {
+    // the task's slice boundaries (n_slices + 1 <= 64 offsets) and row ids: one coalesced load each, handed round by lane reads
+    const int myp = lane <= n_slices ? tptr[(int64_t)t * n_slices + lane] : 0;
+    const int myr = lane < kTaskRows ? trows[(int64_t)t * kTaskRows + lane] : -1;
+    float4 acc[kTaskRows];
+#pragma unroll
+    for (int j = 0; j < kTaskRows; ++j) acc[j] = z4;
+    for (int p = 0; p < n_slices; ++p) {
+      const int lo = __shfl(myp, p), hi = __shfl(myp, p + 1);
+      for (int base = lo; base < hi; base += NPW * U) {
+        int cw[U];
+        float v[U];
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = base + u * NPW + k;
+          const bool ok = e < hi;
+          cw[u] = ok ? ecol[e] : 0;
+          v[u] = ok ? eval[e] : 0.f;
+        }
+        if (xmask) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = cw[u] & ((1 << kTaskColBits) - 1);
+            const bool on = (xmask[c >> 5] >> (c & 31)) & 1u;
+            x[u] = (on && v[u] != 0.f) ? ld4(seg_row(X, c, D) + q * 4) : z4;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, cw[u] & ((1 << kTaskColBits) - 1), D) + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jr = (unsigned)cw[u] >> kTaskColBits;
+          const float4 c4 = make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w);
+#pragma unroll
+          for (int j = 0; j < kTaskRows; ++j) {
+            const float m = jr == j ? 1.f : 0.f;
+            acc[j].x = fmaf(m, c4.x, acc[j].x); acc[j].y = fmaf(m, c4.y, acc[j].y);
+            acc[j].z = fmaf(m, c4.z, acc[j].z); acc[j].w = fmaf(m, c4.w, acc[j].w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kTaskRows; ++j) {
+      const int row = __shfl(myr, j);
+      const float4 sj = slot_sum<LPR>(acc[j]);
+      if (row >= 0 && k == 0) epilogue4(sj, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- tiled, edge-parallel ----
 // Round 3.  The row-per-wave kernels above keep a row's partial sum in registers, so a row's gathers form a dependent
 // chain and every XCD gathers rows of X from all over the 17.8 MB operand: L2 hit rate 0.38, 411 MB of fabric traffic
@@ -425,6 +529,44 @@ int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, int32_t n
       hipLaunchKernelGGL((k_spmm_tiled<LPR>), dim3(ntiles), dim3(kTileThreads), lds, (hipStream_t)stream, tile_edge0,  \
                          tile_row0, ecr, eval, X, Y, A, has_acc, acc_out, scale);                                       \
   } while (0)
+  switch (D / 4) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    case 16: CALL(16); break;
+    case 32: CALL(32); break;
+    case 64: CALL(64); break;
+    default: return MI_ERR_UNSUPPORTED;
+  }
+#undef CALL
+  return launch_status();
+}
+
+// Task-balanced, slice-phased SpMM (k_spmm_sliced above).  tptr int32[n_tasks * n_slices + 1]: edge offsets of every
+// (task, slice); trows int32[n_tasks, 8]: the task's output rows (-1: none); ecol int32[n_edges] = column | row-in-task << 28
+// and eval fp32[n_edges] in (task, slice) order.  The tasks' rows and long_rows together must cover every output row exactly
+// once; long_rows (hubs) are computed from the CSR (crow, col, val) itself.  n_slices <= 63, columns < 2^28.
+int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, const int32_t *tptr, const int32_t *trows,
+                   const int32_t *ecol, const float *eval, int32_t n_tasks, int32_t n_slices, const float *Xa, const float *Xb,
+                   int32_t x_split, float *Y, const float *acc_in_a, const float *acc_in_b, int32_t acc_split, float *acc_out,
+                   float scale, int32_t D, const int32_t *long_rows, int32_t n_long, const uint32_t *xmask, void *stream) {
+  if (n_tasks < 0 || n_long < 0 || n_slices <= 0 || n_slices > 63 || D <= 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
+  if (n_tasks == 0 && n_long == 0) return MI_OK;
+  if (!Xa || (!Y && !acc_out) || (n_tasks > 0 && (!tptr || !trows || !ecol || !eval))) return MI_ERR_INVALID_ARG;
+  if (n_long > 0 && (!long_rows || !crow || !col || !val)) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(D) || n_long > 60000) return MI_ERR_UNSUPPORTED;
+  if (!aligned16(Xa) || (Xb && !aligned16(Xb)) || (Y && !aligned16(Y)) || (acc_in_a && !aligned16(acc_in_a)) ||
+      (acc_in_b && !aligned16(acc_in_b)) || (acc_out && !aligned16(acc_out)))
+    return MI_ERR_UNSUPPORTED;
+  Seg2 X{Xa, Xb ? Xb : Xa + (int64_t)x_split * D, Xb ? x_split : 0x7fffffff};
+  const int has_acc = acc_in_a != nullptr;
+  Seg2 A{acc_in_a, acc_in_b ? acc_in_b : acc_in_a, acc_in_b ? acc_split : 0x7fffffff};
+  int tb = (n_tasks + kHubWaves - 1) / kHubWaves;
+  if (tb > 2048) tb = 2048;
+#define CALL(LPR)                                                                                                         \
+  MI_LAUNCH("spmm_sliced", (k_spmm_sliced<LPR>), n_long + tb, kHubWaves * kWave, stream, crow, col, val, tptr, trows, ecol, \
+            eval, n_tasks, n_slices, X, Y, A, has_acc, acc_out, scale, long_rows, n_long, xmask)
   switch (D / 4) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;

@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True, params=[0, 2], ids=["row-per-wave", "slice-phased"])
+def _both_spmm_forms(request, monkeypatch):
+    """Every test of this file runs on the row-per-wave SpMM and on the task-balanced, slice-phased one (mi_spmm_sliced;
+    forced on whatever the operand's size, with 4 KiB column slices so that the small test graphs have many of them)."""
+    monkeypatch.setattr(_kernels, "SLICED_SPMM", request.param)
+    monkeypatch.setattr(_kernels.CsrPlan, "SLICE_BYTES", 4096)
+    _kernels._plans.clear()
+
+
 def _sample_graph():
     a = load_golden("cf_sample_adj")
     graph = {}
