@@ -665,7 +665,7 @@ def bench_c5(args, real_stdout):
     kernels = kernel_table(kt)
     full = kernel_table(kt_full)
     alg = 8 * nnz + 4 * (N + 1) + 8 * N * D
-    kname = "spmm_tiled" if "spmm_tiled" in full else "spmm_csr"
+    kname = next((n for n in ("spmm_sliced", "spmm_tiled", "spmm_csr") if n in full), "spmm_csr")
     k = full.get(kname)
     roofline = None
     if k:
