@@ -373,7 +373,7 @@ class DualGather(torch.autograd.Function):
     """out = T1'[idx % mod1] (op) T2'[idx // div2]  (mi_dual_gather_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int, fields=None):
+    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int, fields=None, sparse2: bool = False):
         dev = _lib.require_gpu(idx, T1, T2)
         idxc = _i64c(idx)
         T1c, T2c = _f32c(T1), _f32c(T2)
@@ -406,6 +406,8 @@ class DualGather(torch.autograd.Function):
         ctx.save_for_backward(idxc, T1c, T2c, S1c, S2c, M1c, M2c)
         ctx.meta = (n, F, De, mod1, div2, op, xform)
         ctx.fields = fields if (fields is not None and idx.dim() == 2 and fields[3] == F) else None
+        ctx.sparse2 = bool(sparse2) and xform == XF_NONE
+        ctx.t2_shape = tuple(T2.shape)
         return out
 
     @staticmethod
@@ -415,6 +417,17 @@ class DualGather(torch.autograd.Function):
         dev = g.device
         _no_atomics_promised("the two-table (QR / CERP) gather backward")
         g = _f32c(g)
+        if ctx.sparse2:
+            # table 2 (the quotient table: ~N / divider rows) gets its gradient in ROW form: one value row per lookup, no
+            # atomics into scattered rows and no [n2, De] zero-fill; table 1 (divider rows) stays dense
+            gT1 = torch.zeros_like(T1c)
+            g2vals = torch.empty((n, De), dtype=torch.float32, device=dev)
+            rows2 = torch.empty((n,), dtype=torch.int64, device=dev)
+            _lib.check(_lib.load().mi_dual_gather_bwd_rows(idxc.data_ptr(), g.data_ptr(), T1c.data_ptr(), T2c.data_ptr(), gT1.data_ptr(),
+                                                           g2vals.data_ptr(), rows2.data_ptr(), n, F, De, T1c.shape[0], T2c.shape[0],
+                                                           mod1, div2, op, _lib.stream_ptr(dev)), "mi_dual_gather_bwd_rows")
+            # (ids out of range carry row -1 and a zero value row: clamped to row 0, they add nothing)
+            return None, gT1, _coo(rows2.clamp_(min=0), g2vals, ctx.t2_shape), None, None, None, None, None, None, None, None, None, None
         gT1, gT2 = torch.zeros_like(T1c), torch.zeros_like(T2c)
         gS1 = torch.zeros_like(S1c) if xform == XF_SOFT else None
         gS2 = torch.zeros_like(S2c) if xform == XF_SOFT else None
@@ -427,7 +440,7 @@ class DualGather(torch.autograd.Function):
                 small.numel() if small is not None else 0, _lib.ptr(row0), _lib.ptr(flags), _lib.stream_ptr(dev)),
             "mi_dual_gather_bwd_fields",
         )
-        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None
+        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None, None
 
 
 SMALL_FIELD_ROWS = 16     # kSmallRows of csrc/embed.hip
@@ -454,11 +467,11 @@ def small_field_hint(field_dims, div2: int, device):
             flags.to(device), len(field_dims))
 
 
-def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None, fields=None):
+def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None, fields=None, sparse2=False):
     """fields (optional): small_field_hint(...) — lets the backward sum the gradient of low-cardinality fields per field
     instead of with thousands of same-address atomics; same result up to the order of float additions."""
     xform = XF_SOFT if S1 is not None else (XF_MASK if M1 is not None else XF_NONE)
-    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform, fields)
+    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform, fields, bool(sparse2))
 
 
 def csr_rows(values, crow, col, ids, D: int, N: int) -> torch.Tensor:

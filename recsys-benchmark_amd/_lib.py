@@ -37,6 +37,7 @@ SIGNATURES = {
                            _i32, _i32, _p, _p],
     "mi_dual_gather_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                            _i64, _i64, _i32, _i32, _p],
+    "mi_dual_gather_bwd_rows": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _p],
     "mi_dual_gather_bwd_fields": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                                   _i64, _i64, _i32, _i32, _p, _i32, _p, _p, _p],
     "mi_xform_gather_fwd": [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i32, _i64, _i32, _p, _p],

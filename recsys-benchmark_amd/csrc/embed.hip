@@ -149,6 +149,11 @@ __global__ __launch_bounds__(kBlock) void k_dual_fwd_anyD(const int64_t *__restr
 struct DualGrads {
   float *gT1, *gT2;  // [n1,De], [n2,De]
   float *gS1, *gS2;  // XF_SOFT only
+  // row form of table 2's gradient (xf == XF_NONE): g2vals[i, :] = the contribution of lookup i, rows2[i] = its row of
+  // table 2 (-1 for an id out of range) — an uncoalesced COO gradient, plain coalesced stores instead of float atomics into
+  // scattered rows and no [n2, De] zero-fill.  When set, gT2 is not touched.
+  float *g2vals;
+  int64_t *rows2;
 };
 
 constexpr int kLdsAccFloats = 8192;  // 32 KiB
@@ -226,7 +231,13 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
     const int d = (int)(e % De);
     const int64_t id = idx[i];
     const int64_t i1 = id % t.mod1, i2 = id / t.div2;
-    if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) continue;
+    if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) {
+      if (gr.g2vals) {
+        gr.g2vals[e] = 0.f;
+        if (d == 0) gr.rows2[i] = -1;
+      }
+      continue;
+    }
     int64_t o1, o2;
     out_offsets(op, i, F, De, o1, o2);
     const int64_t a1 = i1 * De + d, a2 = i2 * De + d;
@@ -255,7 +266,10 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
       g2 = t.M2[a2] ? g2 : 0.f;
     }
     if (lds1) atomicAdd(&acc[a1], g1); else atomicAdd(gr.gT1 + a1, g1);
-    if (sm.n > 0 && sm.is_small[i % F]) {}          // table 2 of a small field: the extra workgroups' job
+    if (gr.g2vals) {                                // row form: one coalesced store per element, the row id once per lookup
+      gr.g2vals[e] = g2;
+      if (d == 0) gr.rows2[i] = i2;
+    } else if (sm.n > 0 && sm.is_small[i % F]) {}   // table 2 of a small field: the extra workgroups' job
     else if (lds2) atomicAdd(&acc[n1e + a2], g2);
     else atomicAdd(gr.gT2 + a2, g2);
     if (xf == XF_SOFT) {
@@ -570,6 +584,23 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
                                    nullptr, 0, nullptr, nullptr, stream);
 }
 
+int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float *T1, const float *T2, float *gT1,
+                            float *g2vals, int64_t *rows2, int64_t n, int32_t F, int32_t De, int64_t n1, int64_t n2,
+                            int64_t mod1, int64_t div2, int32_t op, void *stream) {
+  if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
+  if (op < OP_MULT || op > OP_CAT) return MI_ERR_INVALID_ARG;
+  if (n == 0) return MI_OK;
+  if (!idx || !g_out || !T1 || !T2 || !gT1 || !g2vals || !rows2) return MI_ERR_INVALID_ARG;
+  DualTables t{T1, T2, nullptr, nullptr, nullptr, nullptr, n1, n2, mod1, div2};
+  DualGrads gr{gT1, nullptr, nullptr, nullptr, g2vals, rows2};
+  const int lds1 = (n1 * De <= kLdsAccFloats / 2);
+  int grid = grid_for_elems(n * De);
+  if (lds1 && grid > 512) grid = 512;
+  SmallFields sm{nullptr, nullptr, nullptr, 0, grid, 0};
+  MI_LAUNCH("dual_gather_bwd_rows", k_dual_bwd, grid, kBlock, stream, idx, t, g_out, gr, n, F, De, op, (int)XF_NONE, lds1, 0, sm);
+  return launch_status();
+}
+
 int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const float *T1, const float *T2,
                               const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *gT1,
                               float *gT2, float *gS1, float *gS2, int64_t n, int32_t F, int32_t De, int64_t n1,
@@ -583,7 +614,7 @@ int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const floa
   if (xform == XF_SOFT && (!S1 || !S2 || !gS1 || !gS2)) return MI_ERR_INVALID_ARG;
   if (xform == XF_MASK && (!M1 || !M2)) return MI_ERR_INVALID_ARG;
   DualTables t{T1, T2, S1, S2, M1, M2, n1, n2, mod1, div2};
-  DualGrads gr{gT1, gT2, gS1, gS2};
+  DualGrads gr{gT1, gT2, gS1, gS2, nullptr, nullptr};
   // LDS pre-aggregation for small tables; fewer, fatter workgroups then bound the flush traffic
   int lds1 = (n1 * De <= kLdsAccFloats / 2), lds2 = (n2 * De <= kLdsAccFloats / 2);
   int grid = grid_for_elems(n * De);

@@ -36,8 +36,15 @@ class QRHashingEmbedding(IEmbedding):
         divider: Optional[int] = None,
         operation: Literal["cat", "add", "mult"] = "mult",
         initializer="uniform",
+        sparse: bool = False,
     ):
+        """Arguments as the reference's (src/models/embeddings/qr_embedding.py:14-22).  Extra, optional:
+
+        sparse: hand the QUOTIENT table's gradient (emb2: ~N / divider rows, the big one) out in row (COO) form, like
+            nn.Embedding(sparse=True) — for `optim.SparseAdam`; the remainder table (divider rows) stays dense.  Off by
+            default: the reference's optimizers see dense gradients."""
         super().__init__()
+        self._sparse2 = bool(sparse) and mode is None
         assert operation in _COMBINE
         assert operation != "cat" or hidden_size % 2 == 0
         self._operation, self._mode, self._hidden_size = operation, mode, hidden_size
@@ -79,7 +86,8 @@ class QRHashingEmbedding(IEmbedding):
                 if self._hint is None or self._hint[0] != tensor.device:
                     self._hint = (tensor.device, _kernels.small_field_hint(self._field_dims, d, tensor.device))
                 fields = self._hint[1]
-            return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation, fields=fields)
+            return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation, fields=fields,
+                                        sparse2=self._sparse2)
         # EmbeddingBag modes reduce each table's rows BEFORE the combine (two bags in the reference)
         bag1 = _kernels.bag_reduce(_kernels.gather_rows(tensor % d, w1), self._mode)
         bag2 = _kernels.bag_reduce(_kernels.gather_rows(tensor // d, w2), self._mode)
