@@ -231,48 +231,59 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
   const int nblk = gridDim.x - n_long;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = (blockIdx.x - n_long) * kHubWaves + w; t < n_tasks; t += nblk * kHubWaves) {
-    // the task's slice boundaries (n_slices + 1 <= 64 offsets) and row ids: one coalesced load each, handed round by lane reads
-    const int myp = lane <= n_slices ? tptr[(int64_t)t * n_slices + lane] : 0;
+    // The task's edges lie slice by slice in ONE contiguous range: walking it front to back IS the slice order, so the loop
+    // needs no per-slice bounds — 16 edges (NPW lane groups x U) per trip, the next trip's edge words and values loaded
+    // before this trip's rows of X are used (two dependent round trips per trip otherwise: a wave's ~16 trips were a
+    // ~30 us latency chain in the first version of this kernel).
+    const int lo = tptr[(int64_t)t * n_slices], hi = tptr[(int64_t)(t + 1) * n_slices];
     const int myr = lane < kTaskRows ? trows[(int64_t)t * kTaskRows + lane] : -1;
     float4 acc[kTaskRows];
 #pragma unroll
     for (int j = 0; j < kTaskRows; ++j) acc[j] = z4;
-    for (int p = 0; p < n_slices; ++p) {
-      const int lo = __shfl(myp, p), hi = __shfl(myp, p + 1);
-      for (int base = lo; base < hi; base += NPW * U) {
-        int cw[U];
-        float v[U];
-        float4 x[U];
+    int cw[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = lo + u * NPW + k;
+      const bool ok = e < hi;
+      cw[u] = ok ? ecol[e] : 0;
+      v[u] = ok ? eval[e] : 0.f;
+    }
+    for (int base = lo; base < hi; base += NPW * U) {
+      float4 x[U];
+      if (xmask) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int e = base + u * NPW + k;
-          const bool ok = e < hi;
-          cw[u] = ok ? ecol[e] : 0;
-          v[u] = ok ? eval[e] : 0.f;
+          const int c = cw[u] & ((1 << kTaskColBits) - 1);
+          const bool on = (xmask[c >> 5] >> (c & 31)) & 1u;
+          x[u] = (on && v[u] != 0.f) ? ld4(seg_row(X, c, D) + q * 4) : z4;
         }
-        if (xmask) {
+      } else {
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int c = cw[u] & ((1 << kTaskColBits) - 1);
-            const bool on = (xmask[c >> 5] >> (c & 31)) & 1u;
-            x[u] = (on && v[u] != 0.f) ? ld4(seg_row(X, c, D) + q * 4) : z4;
-          }
-        } else {
+        for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, cw[u] & ((1 << kTaskColBits) - 1), D) + q * 4);
+      }
+      int ncw[U];
+      float nv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, cw[u] & ((1 << kTaskColBits) - 1), D) + q * 4);
-        }
+      for (int u = 0; u < U; ++u) {
+        const int e = base + NPW * U + u * NPW + k;
+        const bool ok = e < hi;
+        ncw[u] = ok ? ecol[e] : 0;
+        nv[u] = ok ? eval[e] : 0.f;
+      }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int jr = (unsigned)cw[u] >> kTaskColBits;
-          const float4 c4 = make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w);
+      for (int u = 0; u < U; ++u) {
+        const int jr = (unsigned)cw[u] >> kTaskColBits;
+        const float4 c4 = make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w);
 #pragma unroll
-          for (int j = 0; j < kTaskRows; ++j) {
-            const float m = jr == j ? 1.f : 0.f;
-            acc[j].x = fmaf(m, c4.x, acc[j].x); acc[j].y = fmaf(m, c4.y, acc[j].y);
-            acc[j].z = fmaf(m, c4.z, acc[j].z); acc[j].w = fmaf(m, c4.w, acc[j].w);
-          }
+        for (int j = 0; j < kTaskRows; ++j) {
+          const float m = jr == j ? 1.f : 0.f;
+          acc[j].x = fmaf(m, c4.x, acc[j].x); acc[j].y = fmaf(m, c4.y, acc[j].y);
+          acc[j].z = fmaf(m, c4.z, acc[j].z); acc[j].w = fmaf(m, c4.w, acc[j].w);
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { cw[u] = ncw[u]; v[u] = nv[u]; }
     }
 #pragma unroll
     for (int j = 0; j < kTaskRows; ++j) {

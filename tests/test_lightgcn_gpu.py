@@ -23,6 +23,16 @@ def _both_spmm_forms(request, monkeypatch):
     _kernels._plans.clear()
 
 
+def _same_rows(a, b, what=""):
+    """Rows computed by the batch-rows-only last layer (always the row-per-wave kernel) against the same rows of a full
+    layer: bit for bit when the full layer runs on the row-per-wave kernel too (same order of additions), within float32
+    rounding of the row's terms when it runs on the slice-phased kernel (another fixed order)."""
+    if _kernels.SLICED_SPMM == 2:
+        assert_close(a, b, 2e-5, 2e-6, what)
+    else:
+        assert torch.equal(a, b), what
+
+
 def _sample_graph():
     a = load_golden("cf_sample_adj")
     graph = {}
@@ -243,7 +253,7 @@ def test_propagation_and_regulariser_as_one_node_equal_the_two_calls():
         grads.append((au.detach(), ai.detach(), reg.detach(), model.user_emb_table.get_weight().grad.clone(),
                       model.item_emb_table.get_weight().grad.clone()))
     for a, b, what in zip(grads[0][:3], grads[1][:3], ("user emb", "item emb", "reg")):
-        assert torch.equal(a, b), what
+        _same_rows(a, b, what)
     assert_close(grads[1][3], grads[0][3], 1e-5, 1e-7, "user table gradient")
     assert_close(grads[1][4], grads[0][4], 1e-5, 1e-7, "item table gradient")
 
@@ -279,7 +289,7 @@ def test_last_layer_restricted_to_the_batch_rows_gives_the_same_rows_and_gradien
         if "grad" in what:
             assert_close(b, a, 1e-6, 1e-8, what)      # (BPR / reg rows are scattered with float atomics: order may differ)
         else:
-            assert torch.equal(a, b), what
+            _same_rows(a, b, what)
 
 
 def test_fused_step_paths_with_sparse_dropout_reuse_the_plan_across_draws():
@@ -313,7 +323,8 @@ def test_fused_step_paths_with_sparse_dropout_reuse_the_plan_across_draws():
                              model.item_emb_table.get_weight().grad.clone()))
         results.append(per_draw)
     for d, (a, b) in enumerate(zip(*results)):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), f"draw {d}: rows read by the losses"
+        _same_rows(a[0], b[0], f"draw {d}: rows read by the losses")
+        _same_rows(a[1], b[1], f"draw {d}: rows read by the losses")
         assert_close(b[2], a[2], 1e-5, 1e-7, f"draw {d}: user table gradient")
         assert_close(b[3], a[3], 1e-5, 1e-7, f"draw {d}: item table gradient")
     for p in _kernels._plans.values():
@@ -344,6 +355,6 @@ def test_single_table_model_fused_step_equals_the_two_calls(rows_only):
         (bpr_loss_rows(au, ai, users, pos, neg) + 0.05 * reg).backward()
         outs.append((au.detach()[users], ai.detach()[pos], ai.detach()[neg], reg.detach(), model.emb_table.get_weight().grad.clone()))
     for a, b, what in zip(outs[0][:3], outs[1][:3], ("user rows", "positive rows", "negative rows")):
-        assert torch.equal(a, b), what
+        _same_rows(a, b, what)
     assert_close(outs[1][3], outs[0][3], 1e-5, 1e-7, "reg loss (norm^2 vs sum of squares)")
     assert_close(outs[1][4], outs[0][4], 1e-5, 1e-7, "table gradient")

@@ -52,22 +52,41 @@ def _seq(inp, hidden, p, bn=True):
     return seq
 
 
-def _reference(seq, x, add, masks, dtype):
-    """The reference op sequence with explicit dropout masks, in `dtype`; returns out, grads dict, running stats."""
+KINK = 3e-7     # |float64 pre-activation| below which a float32 evaluation may land on either side of the ReLU kink
+
+
+def _reference(seq, x, add, masks, dtype, flips=None, near_out=None):
+    """The reference op sequence with explicit dropout masks, in `dtype`; returns (modules, x, add, out).
+    A pre-activation within rounding of 0 lands on either side of the ReLU kink in ANY float32 evaluation (the fused products
+    sum in another order than torch's) and one flip changes that unit's whole gradient contribution (one row of dx): the
+    float64 pass lists the (at most 4) pre-activations nearest the kink below KINK in `near_out`, and `flips` (a set of
+    positions in that list) evaluates the reference with those ReLU decisions inverted."""
     seq = copy.deepcopy(seq).to(dtype)
     x = x.detach().clone().to(dtype).requires_grad_(True)
     add = add.detach().clone().to(dtype).requires_grad_(True)
-    h, li = x, 0
-    mods = list(seq)
-    i = 0
-    while i < len(mods):
-        m = mods[i]
+    h, li, layer = x, 0, 0
+    cands = []
+    for m in seq:
         if isinstance(m, nn.Dropout):
             h = h * masks[li].to(dtype)
             li += 1
+        elif isinstance(m, nn.ReLU):
+            pre = h.detach()
+            on = pre > 0
+            if near_out is not None:
+                a = pre.abs().flatten()
+                vals, pos = torch.topk(a, min(4, a.numel()), largest=False)
+                cands += [(float(v), layer, int(q)) for v, q in zip(vals, pos) if float(v) < KINK]
+            if flips:
+                for j, (_, lay, q) in enumerate(flips["list"]):
+                    if lay == layer and j in flips["which"]:
+                        on.view(-1)[q] = ~on.view(-1)[q]
+            h = h * on.to(dtype)
+            layer += 1
         else:
             h = m(h)
-        i += 1
+    if near_out is not None:
+        near_out.extend(sorted(cands)[:4])
     out = h + add.view(-1, 1)
     return seq, x, add, out
 
@@ -117,45 +136,63 @@ def test_fused_tail_brackets_float64_like_the_stock_modules(M, K, hidden, p, mod
         p = 0.0
     masks = [tail_keep_scale(seed_value, SALT * (i + 1), M, h, p) for i, h in enumerate(hidden)]
 
-    ref64 = _reference(seq, x, add, masks, torch.float64)
+    near = []
+    ref64 = _reference(seq, x, add, masks, torch.float64, near_out=near)
     ref32 = _reference(seq, x, add, masks, torch.float32)
     for r in (ref64, ref32):
         (r[3] * G.to(r[3].dtype)).sum().backward()
     fs, fx, fa, fout = _run_fused(seq, x, add, seed_value)
     (fout * G.to(DEV)).sum().backward()
-
-    def check(name, got, r64, r32, k=8.0, floor=1e-6):
-        """|got - r64| <= k * max(|r32 - r64|, floor-scaled noise): the fused result is as close to the float64 value as the
-        stock float32 modules are, up to the factor k (different summation order / fused multiply-adds).  k = 8: over
-        every tensor of every case of this test the measured ratio is at most 4.1 (MI_TEST_REPORT=1 prints them; round 2
-        allowed 32)."""
-        got, r64, r32 = got.detach().double().cpu(), r64.detach().double(), r32.detach().double()
-        scale = r64.abs().max().clamp_min(1e-30)
-        err_f = (got - r64).abs().max() / scale
-        err_s = (r32 - r64).abs().max() / scale
-        if os.environ.get("MI_TEST_REPORT"):
-            print(f"RATIO {name} M={M} K={K} p={p}: fused {float(err_f):.3e} stock {float(err_s):.3e} ratio {float(err_f / err_s.clamp_min(1e-30)):.2f}")
-        assert err_f <= max(k * err_s, floor), f"{name}: fused {err_f:.3e} vs stock {err_s:.3e} (relative to max |ref|)"
-
-    check("out", fout, ref64[3], ref32[3])
-    check("dx", fx.grad, ref64[1].grad, ref32[1].grad)
-    check("dadd", fa.grad, ref64[2].grad, ref32[2].grad)
-    p64, p32, pf = dict(ref64[0].named_parameters()), dict(ref32[0].named_parameters()), dict(fs.named_parameters())
     lin_in_front_of_bn = {f"{i}.bias" for i, m in enumerate(seq) if isinstance(m, nn.Linear) and i + 1 < len(seq)
                           and isinstance(seq[i + 1], nn.BatchNorm1d) and training}
-    for name in p64:
-        if name in lin_in_front_of_bn:
-            # analytically zero (the batch mean is removed); the stock modules return rounding noise, the fused node 0
-            assert float(pf[name].grad.abs().max()) == 0.0
-            continue
-        check(name, pf[name].grad, p64[name].grad, p32[name].grad)
-    b64, bf = dict(ref64[0].named_buffers()), dict(fs.named_buffers())
-    b32 = dict(ref32[0].named_buffers())
-    for name in b64:
-        if name.endswith("num_batches_tracked"):
-            assert int(bf[name]) == int(b64[name])
-        else:
-            check(name, bf[name], b64[name], b32[name])
+
+    def failures(ref64, k=8.0, floor=1e-6):
+        """Checks |got - r64| <= k * max(|r32 - r64|, floor) (relative to max |r64|) for the output, every gradient and the
+        running statistics: the fused result is as close to the float64 value as the stock float32 modules are, up to the
+        factor k (different summation order / fused multiply-adds).  k = 8: over every tensor of every case of this test the
+        measured ratio is at most 4.1 (MI_TEST_REPORT=1 prints them; round 2 allowed 32).  Returns the failed checks."""
+        bad = []
+
+        def check(name, got, r64, r32):
+            got, r64, r32 = got.detach().double().cpu(), r64.detach().double(), r32.detach().double()
+            scale = r64.abs().max().clamp_min(1e-30)
+            err_f = (got - r64).abs().max() / scale
+            err_s = (r32 - r64).abs().max() / scale
+            if os.environ.get("MI_TEST_REPORT"):
+                print(f"RATIO {name} M={M} K={K} p={p}: fused {float(err_f):.3e} stock {float(err_s):.3e} ratio {float(err_f / err_s.clamp_min(1e-30)):.2f}")
+            if not err_f <= max(k * err_s, floor):
+                bad.append(f"{name}: fused {err_f:.3e} vs stock {err_s:.3e} (relative to max |ref|)")
+
+        check("out", fout, ref64[3], ref32[3])
+        check("dx", fx.grad, ref64[1].grad, ref32[1].grad)
+        check("dadd", fa.grad, ref64[2].grad, ref32[2].grad)
+        p64, p32, pf = dict(ref64[0].named_parameters()), dict(ref32[0].named_parameters()), dict(fs.named_parameters())
+        for name in p64:
+            if name in lin_in_front_of_bn:
+                # analytically zero (the batch mean is removed); the stock modules return rounding noise, the fused node 0
+                assert float(pf[name].grad.abs().max()) == 0.0
+                continue
+            check(name, pf[name].grad, p64[name].grad, p32[name].grad)
+        b64, bf = dict(ref64[0].named_buffers()), dict(fs.named_buffers())
+        b32 = dict(ref32[0].named_buffers())
+        for name in b64:
+            if name.endswith("num_batches_tracked"):
+                assert int(bf[name]) == int(b64[name])
+            else:
+                check(name, bf[name], b64[name], b32[name])
+        return bad
+
+    bad = failures(ref64)
+    if bad and near:
+        # pre-activations on the kink: the fused result has to match the float64 evaluation under ONE assignment of their
+        # ReLU decisions (tools/fuzz.py holds its tail cases to the same rule)
+        for bits in range(1, 1 << len(near)):
+            alt = _reference(seq, x, add, masks, torch.float64, flips={"list": near, "which": {j for j in range(len(near)) if bits >> j & 1}})
+            (alt[3] * G.double()).sum().backward()
+            if not failures(alt):
+                bad = []
+                break
+    assert not bad, f"{bad} (pre-activations within {KINK:g} of the kink: {near})"
     # the seed word advanced exactly once per step when there is dropout
     assert int(_mlp._seed_word(torch.device(DEV, 0))) == seed_value + (1 if p > 0 else 0)
 
@@ -236,15 +273,27 @@ def test_fused_tail_default_and_deterministic_weight_gradients_agree():
             res[det] = (out.detach(), xd.grad, {n: q.grad for n, q in seq.named_parameters()})
         finally:
             _kernels.DETERMINISTIC = False
+    from recsys_benchmark_amd import tail as _tail_mod
+
     a, b = res[False], res[True]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    def same(u, v, what):
+        if _tail_mod.STAT_SUMS:
+            # the default accumulates the BatchNorm statistics with float atomics (order varies in the last bits);
+            # deterministic mode joins tile statistics in a fixed order: equal within float32 rounding, not bitwise
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max().clamp_min(1e-30)), what
+        else:
+            assert torch.equal(u, v), what
+
+    same(a[0], b[0], "out")
+    same(a[1], b[1], "dx")
     for name in a[2]:
         ga, gb = a[2][name], b[2][name]
         if name.endswith("weight") and ga.dim() == 2 and ga.shape[0] > 1:          # a hidden Linear's weight: through the split
             scale = float(gb.abs().max())
             assert float((ga - gb).abs().max()) <= 2e-5 * scale, name
         else:
-            assert torch.equal(ga, gb), name
+            same(ga, gb, name)
 
 
 def test_inference_without_grad_runs_the_own_kernels_and_keeps_nothing(monkeypatch):
