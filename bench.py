@@ -508,7 +508,9 @@ def bench_c3(args, real_stdout):
     dims, D, hidden, B, E, r, nl = list(AVAZU_22), 16, [400, 400, 400], args.batch, 4, 64, 3
     F, d = len(dims), len(dims) * D
     torch.manual_seed(2023)
-    emb_cfg = {"name": "qr", "divider": 2}
+    # the quotient table's gradient in row (COO) form, like C2's tables (an extension: the reference's QR has no sparse
+    # option; --dense-grads gives its dense weight.grad: a 64 MB zero-fill + scattered float atomics per step)
+    emb_cfg = {"name": "qr", "divider": 2} if args.dense_grads else {"name": "qr", "divider": 2, "sparse": True}
     model = DCN_Mix(dims, D, hidden, num_layers=nl, num_experts=E, rank=r, embedding_config=emb_cfg, p_dropout=0.5).to(dev).train()
     # resident batches with distinct ids, one hipGraph each (fresh rows every step, no input copy) — like the C2 leg
     batches = [synth_batch(dims, B, 2023 + 7919 * rank + 104729 * i, dev) for i in range(max(1, min(args.ring, 8)))]
@@ -559,7 +561,7 @@ def bench_c3(args, real_stdout):
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay",
            "config": {"workload": f"C3 DCN-Mix Avazu-22field: F={F}, D={D}, d={d}, N={sum(dims)} rows, QR divider 2 (mult), E={E}, "
-                                  f"rank={r}, L={nl}, MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(batches)} distinct uniform-id batches rotated "
+                                  f"rank={r}, L={nl}, MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, quotient-table grad {'dense' if args.dense_grads else 'row-form (COO)'}, {len(batches)} distinct uniform-id batches rotated "
                                   f"(one hipGraph per resident batch)",
                       "global_batch": B * world, "parallelism": "single" if world == 1 else f"{world} independent replicas"},
            "roofline": roofline, "kernels": kernels}

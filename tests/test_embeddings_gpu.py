@@ -69,6 +69,33 @@ def test_qr_vs_oracle(op, N, D, divider, shape):
     assert_close(emb.emb2.weight.grad, e2.grad, 2e-5, 2e-5, "g emb2")
 
 
+@pytest.mark.parametrize("op", ["mult", "add", "cat"])
+def test_qr_row_form_gradient_of_the_quotient_table_is_the_dense_one(op):
+    """QRHashingEmbedding(sparse=True) (an extension, like sparse=True on the DeepFM tables): the quotient table's gradient
+    as uncoalesced COO rows (mi_dual_gather_bwd_rows) — densified it is the dense path's gradient; EXACT on integer-valued
+    data (no rounding, so the order of additions cannot matter), the remainder table's dense gradient likewise."""
+    gen = torch.Generator().manual_seed(11)
+    dims = [241, 8, 3697, 5, 31]
+    N, D, B = sum(dims), 16, 512
+    off = torch.tensor([0] + dims[:-1]).cumsum(0)
+    idx = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1) + off
+    res = {}
+    for sparse in (False, True):
+        torch.manual_seed(3)
+        emb = QRHashingEmbedding(dims, D, None, 2, op, sparse=sparse).to(DEV)
+        with torch.no_grad():
+            for w in (emb.emb1.weight, emb.emb2.weight):
+                w.copy_(torch.randint(-3, 4, w.shape, generator=gen).float())
+        out = emb(idx.to(DEV))
+        G = torch.randint(-2, 3, out.shape, generator=torch.Generator().manual_seed(5)).float()
+        (out * G.to(DEV)).sum().backward()
+        g2 = emb.emb2.weight.grad
+        assert g2.is_sparse == sparse
+        res[sparse] = (out.detach(), emb.emb1.weight.grad.clone(), g2.to_dense() if sparse else g2.clone())
+    for a, b, what in zip(res[False], res[True], ("out", "g emb1", "g emb2")):
+        assert torch.equal(a, b), what
+
+
 def test_qr_bag_modes():
     gen = torch.Generator().manual_seed(1)
     for mode in ("sum", "mean"):
