@@ -980,6 +980,8 @@ def main():
                     "nothing at those places (invalidates the measurement as a benchmark line)")
     ap.add_argument("--no-sweep", action="store_true", help="skip roofline.batch_sweep")
     ap.add_argument("--no-train-step", action="store_true", help="skip the train_step object (fwd+bwd+optimizers as one graph)")
+    ap.add_argument("--prefetch", action="store_true", help="every step touches the NEXT batch's table rows on a side stream under its "
+                    "weight-gradient launch (DeepFM.prefetch_next): the next forward gathers from the Infinity Cache")
     ap.add_argument("--infer", action="store_true", help="the reference's own timing harnesses (scripts/deepfm/infer_deepfm.py, "
                     "scripts/lightgcn/infer_lightgcn.py): eval-mode forward latency at B=64 / 4096, LightGCN request phases, CPU oracle beside")
     ap.add_argument("--windows", type=int, default=10, help="extra windows of --steps replays after the timed region, for "
@@ -1182,8 +1184,12 @@ def main():
         graphs = []
         slots = [cur] if args.copy_batch else ring
         pool = None
-        for blob in slots:
+        for gi, blob in enumerate(slots):
             xb, yb = blob[:nx].view(torch.int64).view(B, F), blob[nx:].view(torch.float32)
+            if args.prefetch and not args.copy_batch:
+                # graph i is followed by graph i + 1 in the timed ring: its step touches that batch's table rows
+                nb = slots[(gi + 1) % len(slots)]
+                model.prefetch_next(nb[:nx].view(torch.int64).view(B, F))
             g = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)          # every capture builds its own gradient buffers (no accumulation)
             with torch.cuda.graph(g, pool=pool):

@@ -95,6 +95,13 @@ MI_API int mi_gather_fm_fwd_sum(const int64_t *idx, const int64_t *offsets,
                                 int64_t B, int32_t F, int32_t D, int64_t N,
                                 int32_t *err, void *stream);
 
+/* Touch the table rows the NEXT batch's lookup will read (idx int64[B,F] raw ids of that batch, other arguments as
+ * mi_gather_fm_fwd_ld): pulls their 128-byte lines into the 256 MiB Infinity Cache.  Meant for a side stream under an
+ * MFMA-bound kernel of the current step; writes nothing.  (No reference counterpart: src/trainer/deepfm.py:40-60 gets the
+ * next batch from its DataLoader while the step runs; this is what the device does with that lead.) */
+MI_API int mi_prefetch_rows(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                            int64_t ldw1, int64_t B, int32_t F, int64_t N, void *stream);
+
 /* Backward of the above, row-sparse form (the MI355X-native default):
  *   gvals[b,f,:] = g_emb[b,f,:] + g_y[b] * (S_b - emb[b,f,:]),  S_b = sum_f emb
  *   g1vals[b,f]  = g_y[b]

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_fwd_ld": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_fwd_sum": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
+    "mi_prefetch_rows": [_p, _p, _p, _i64, _p, _i64, _i64, _i32, _i64, _p],
     "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
     "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
     "mi_gather_rows_fwd": [_p, _p, _p, _i64, _i32, _i64, _p, _p],

@@ -363,7 +363,11 @@ struct FwdArgs {
   const float *stat_rm, *stat_off;
 };
 
-template <bool ACT, bool MERGE, bool DMA = false>
+// NS: the 16-column sub-tiles a workgroup computes (7 = up to 112 columns: the training shapes, one workgroup per CU at
+// M = 4096).  NS = 2 (32 columns) is the SMALL-BATCH form: an inference forward at the reference's default batch 64
+// (scripts/deepfm/infer_deepfm.py:36) is ONE row tile — 4 workgroups of 112 columns leave 252 CUs idle and each still walks
+// 56 MFMAs per slice; 13 workgroups of 32 columns walk 16 (plain forms only: no statistics joins at that size).
+template <bool ACT, bool MERGE, bool DMA = false, int NS = NSUB>
 __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[DMA ? kDmaLdsFloats : kLdsFloats + (MERGE ? kCstFloats : 0)];
   const int mt_total = (a.M + BM - 1) / BM;
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   const LoadAct act = make_act(a.x);
   const LoadPlain xp{a.x.Z, a.x.ld};
   const LoadPlain wp{a.W, a.ldw};
-  const KcOperand<BNT, LoadPlain> opC{wp, n0, cols_valid, a.K};
+  const KcOperand<NS * 16, LoadPlain> opC{wp, n0, cols_valid, a.K};
   if constexpr (MERGE) {
     const lds_cfp c = as_lds(lds + kLdsFloats);
     const LoadActL actl{a.x.Z, a.x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop};
@@ -395,8 +399,8 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   else if constexpr (DMA)
     main_loop_dma(acc, lds, 0, a.K, KcOperand<64, LoadPlain, 128>{xp, m0, rows_valid, a.K}, a.W, a.ldw, n0, cols_valid);
   else if constexpr (ACT)
-    main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
-  else main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
+    main_loop<true, true, NS>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
+  else main_loop<true, true, NS>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
   // ---- epilogue.  A lane holds z[m0 + 16 wave + r][n0 + 16 s + 4 g + v] (waves 0-3); the tile goes through LDS once so
   // that ALL 8 waves store whole 448-byte row segments and the column statistics are plain column walks.
@@ -1096,9 +1100,19 @@ int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const flo
   a.a_out = a_out;
   a.M = M; a.N = N; a.K = K;
   a.ncols = cols_per_tile(N, &a.ntn);
-  const int tiles = ((M + BM - 1) / BM) * a.ntn;
+  int tiles = ((M + BM - 1) / BM) * a.ntn;
   static const bool dma_env = [] { const char *e = getenv("MI_TAIL_DMA"); return e && e[0] == '1'; }();
   const bool dma = dma_env && K >= 2 * BK;
+  // small batches: 32-column tiles put 3.5x as many workgroups on the chip, each with 2/7 of the MFMAs per slice
+  const int mt = (M + BM - 1) / BM;
+  if (!x_stats && !dma && !part && tiles < 128 && N > 32) {
+    a.ncols = 32;
+    a.ntn = (N + 31) / 32;
+    tiles = mt * a.ntn;
+    if (x_mu) MI_LAUNCH("tail_fwd_gemm_small", (k_tail_fwd<true, false, false, 2>), grid8(tiles), kThreads, stream, a);
+    else MI_LAUNCH("tail_fwd_gemm_small", (k_tail_fwd<false, false, false, 2>), grid8(tiles), kThreads, stream, a);
+    return launch_status();
+  }
 
   if (x_stats) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, true>), grid8(tiles), kThreads, stream, a);
   else if (x_mu && dma) MI_LAUNCH("tail_fwd_gemm", (k_tail_fwd<true, false, true>), grid8(tiles), kThreads, stream, a);

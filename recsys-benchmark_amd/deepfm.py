@@ -160,6 +160,15 @@ class DeepFM(nn.Module):
         return _tail.run_fused_deepfm(plan, groups[-1][1], _mlp._seed_word(W.device), x, self.offsets, W, w1, self._bias,
                                       sparse_W, sparse_w1)
 
+    @staticmethod
+    def prefetch_next(x_next) -> None:
+        """Tell the next training step (the fused one-node form) which ids the batch AFTER it will look up: that step then
+        pulls those table rows into the Infinity Cache on a side stream under its weight-gradient launch.  Optional; a
+        DataLoader-driven loop calls it with the batch it already holds for the following iteration."""
+        from . import tail as _tail
+
+        _tail.set_next_batch(x_next)
+
     def forward(self, x):
         """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
         fused = self._fused_step(x)

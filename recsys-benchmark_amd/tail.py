@@ -321,7 +321,7 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
     return out, saved, st
 
 
-def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=None):
+def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=None, beside_wgrad=None):
     """The backward kernels of the tail.  need_params[j]: whether parameter j of (W, b, gamma, beta) x k + (w, b)_head wants
     a gradient.  fm (DeepFM, the tail's input is the embedding block): (emb_sum[M, D], g1vals[M, F] or None, D) — the first
     layer's input-gradient product then writes the lookup table's row-form gradient instead of dx (mi_tail_dgrad_gemm_fm)
@@ -444,7 +444,10 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
                 DY, part, part_rows = OUT, npart, (R if stat else (M + 63) // 64)
             else:
                 dx = OUT
+    join = beside_wgrad() if beside_wgrad is not None else None      # (work for a side stream under the MFMA-bound launch)
     _kernels.gemm_multi(later, transA=True)
+    if join is not None:
+        join()
     grads[4 * k] = dw_head
     grads[4 * k + 1] = db_head if st.has_head_bias else None
     dadd = gvec.view(st.add_shape) if (st.add_shape is not None and need_add) else None
@@ -475,6 +478,39 @@ class FusedTailFn(torch.autograd.Function):
         need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, *params)
         dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[5:], need[4])
         return (None, None, None, dx, dadd, *grads)
+
+
+# The NEXT batch's ids, when the caller knows them (a DataLoader is one batch ahead of the step: DeepFM.prefetch_next(x)):
+# the step then touches that batch's table rows on a side stream under its weight-gradient launch (MFMA-bound, the HBM idle),
+# so the next forward's ~106 K random 128-byte lines come from the Infinity Cache.  Consumed by the next DeepFMFusedFn forward.
+_NEXT_IDS = {}
+_SIDE = {}
+
+
+def set_next_batch(idx: Optional[torch.Tensor]) -> None:
+    if idx is None:
+        _NEXT_IDS.clear()
+    else:
+        _NEXT_IDS[str(idx.device)] = _kernels._i64c(idx)
+
+
+def _next_batch_prefetch(dev, offsets, Wc, ldw, w1c, ldw1, F, N):
+    nxt = _NEXT_IDS.pop(str(dev), None)
+    if nxt is None or nxt.dim() != 2 or nxt.shape[1] != F:
+        return None
+
+    def start():
+        cur = torch.cuda.current_stream(dev)
+        side = _SIDE.get(str(dev))
+        if side is None:
+            side = _SIDE[str(dev)] = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _lib.check(_lib.load().mi_prefetch_rows(nxt.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1,
+                                                    nxt.shape[0], F, N, _lib.stream_ptr(dev)), "mi_prefetch_rows")
+        return lambda: cur.wait_stream(side)
+
+    return start
 
 
 class DeepFMFusedFn(torch.autograd.Function):
@@ -512,6 +548,7 @@ class DeepFMFusedFn(torch.autograd.Function):
         w_head = _kernels._f32c(params[4 * k]).view(-1)
         out, saved, st = _tail_forward(plan, seed, emb, yfm, Ws, w_head, params[4 * k + 1])
         ctx.st = st
+        ctx.prefetch = _next_batch_prefetch(dev, offsets, Wc, ldw, w1c, ldw1, F, N)
         ctx.meta = (B, F, D, N, tuple(W.shape), tuple(w1.shape), bool(sparse_W), bool(sparse_w1), bias is not None)
         ctx.save_for_backward(*saved, rows, esum)
         return out
@@ -526,7 +563,7 @@ class DeepFMFusedFn(torch.autograd.Function):
         dev = rows.device
         g1vals = torch.empty((B * F,), dtype=torch.float32, device=dev) if need_w1 else None
         gvals, _, grads, db_head = _tail_backward(ctx.st, saved[:ctx.st.n_saved], g, True, need[10:], False,
-                                                  fm=(esum, g1vals, D))
+                                                  fm=(esum, g1vals, D), beside_wgrad=ctx.prefetch)
         gvals = gvals.view(B * F, D)
         stream = _lib.stream_ptr(dev)
         gW = gw1 = None
