@@ -328,17 +328,18 @@ MI_API int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, in
                          float scale, int32_t D, void *stream);
 
 /* Round 4: task-balanced, slice-phased SpMM (src/models/lightgcn.py:79-87, the same product).  The columns of A (rows of
- * X) are cut into n_slices slices of <= ~2 MiB of X; the rows of A are packed once per sparsity pattern into tasks of <= 8
- * rows and <= ~256 nonzeros, a task's edges stored slice by slice: every wave of the chip then gathers from the same slice of
- * X at about the same time and each XCD's 4 MiB L2 serves the re-uses (the row-per-wave kernel re-fetches X 8.4x).
- *   tptr  int32[n_tasks * n_slices + 1]  edge offsets of every (task, slice)
- *   trows int32[n_tasks, 8]              the task's output rows, -1 = none
- *   ecol  int32[n_edges]                 column | (row index inside the task) << 28, in (task, slice) order; eval the values
+ * X) are cut into slices of <= ~2 MiB of X; the rows of A are packed once per sparsity pattern into tasks of about equal work
+ * whose edges are stored slice by slice: every wave of the chip then gathers from the same slice of X at about the same time
+ * and each XCD's 4 MiB L2 serves the re-uses (the row-per-wave kernel re-fetches X 8.4x).  NPW = 256 / D lane groups per wave.
+ *   tptr  int32[n_tasks, NPW + 1]  narrow task: lane group k's edges = [tptr[k], tptr[k+1]); wide task: [tptr[0], tptr[1])
+ *   trows int32[n_tasks, 2 NPW]    narrow: group k owns rows trows[k], trows[NPW + k]; wide: rows trows[0], trows[NPW]; -1 = none
+ *   twide uint8[n_tasks]           1 = wide (all groups stride one edge range: rows of 48..256 nonzeros)
+ *   ecol  int32[n_edges]           column | (second row of its owner) << 28, slice by slice inside a range; eval the values
  *   long_rows: hub rows, computed from the CSR (crow, col, val) by a 16-wave workgroup each; tasks + hubs cover every row once.
  * Other arguments as mi_spmm_csr_masked.  Fixed summation order (no atomics). */
 MI_API int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, const int32_t *tptr,
-                          const int32_t *trows, const int32_t *ecol, const float *eval, int32_t n_tasks,
-                          int32_t n_slices, const float *Xa, const float *Xb, int32_t x_split, float *Y,
+                          const int32_t *trows, const uint8_t *twide, const int32_t *ecol, const float *eval,
+                          int32_t n_tasks, const float *Xa, const float *Xb, int32_t x_split, float *Y,
                           const float *acc_in_a, const float *acc_in_b, int32_t acc_split, float *acc_out,
                           float scale, int32_t D, const int32_t *long_rows, int32_t n_long, const uint32_t *xmask,
                           void *stream);

@@ -640,13 +640,15 @@ class CsrPlan:
 
     # ---- task-balanced, slice-phased form (mi_spmm_sliced, round 4) ----
     SLICE_BYTES = 2 << 20           # rows of X per column slice: half of an XCD's 4 MiB L2
-    TASK_NNZ = 256                  # nonzeros per task (a wave's share of every slice: ~TASK_NNZ / slices gathers)
-    TASK_ROWS = 8                   # kTaskRows of csrc/spmm.hip
+    TASK_NNZ = 256                  # nonzeros per task: a wave's share of every slice is ~TASK_NNZ / slices gathers
+    WIDE_MIN = 48                   # rows with more nonzeros than this get a wide task (all lane groups stride them)
 
     def sliced(self, D: int, transposed: bool):
-        """The task plan of A (or A^T) for rows of D floats, built once per (pattern, D) on the host: non-hub rows packed
-        in row order into tasks of <= 8 rows and <= TASK_NNZ nonzeros, every task's edges sorted by column slice.  None
-        when the kernel cannot take the matrix (columns >= 2^28, D outside the float4 kernels, > 63 slices)."""
+        """The task plan of A (or A^T) for rows of D floats, built once per (pattern, D) on the host (csrc/spmm.hip,
+        k_spmm_sliced): NPW = 256 / D lane groups per wave.  Rows in row order; a row of <= WIDE_MIN nonzeros joins the open
+        NARROW task (<= 2 NPW rows, <= TASK_NNZ nonzeros; row i of the task belongs to lane group i % NPW), a heavier one the
+        open WIDE task (<= 2 rows, <= TASK_NNZ nonzeros unless alone), hubs (> HUB_DEGREE) are listed apart.  Inside an
+        owner's range the edges are sorted by column slice.  None when the kernel cannot take the matrix."""
         key = (int(D), bool(transposed))
         cache = self.__dict__.setdefault("_sliced", {})
         if key in cache:
@@ -658,45 +660,65 @@ class CsrPlan:
         plan = None
         if _float4_rows(D) and n_cols < (1 << 28) and self.nnz > 0 and n_rows > 0:
             dev = crow_d.device
+            NPW = 256 // D
             crow = crow_d.cpu().numpy().astype(np.int64)
             col = col_d.cpu().numpy().astype(np.int64)
             deg = crow[1:] - crow[:-1]
             hub = deg > HUB_DEGREE
             slice_rows = max(1, self.SLICE_BYTES // (4 * D))
-            S = -(-n_cols // slice_rows)
-            if S > 63:
-                slice_rows = -(-n_cols // 63)
-                S = -(-n_cols // slice_rows)
             task_of = np.full(n_rows, -1, dtype=np.int64)
-            j_of = np.zeros(n_rows, dtype=np.int64)
-            t, cnt, nn = 0, 0, 0
+            slot_of = np.zeros(n_rows, dtype=np.int64)       # lane group (narrow) / 0 (wide)
+            j_of = np.zeros(n_rows, dtype=np.int64)          # first or second row of its owner
+            wide_flags = []
+            open_n = None         # [task id, rows so far, nonzeros so far] of the open narrow / wide task
+            open_w = None
+            T = 0
             degl, hubl = deg.tolist(), hub.tolist()
             for r in range(n_rows):
                 if hubl[r]:
                     continue
                 d = degl[r]
-                if cnt == self.TASK_ROWS or (cnt > 0 and nn + d > self.TASK_NNZ):
-                    t, cnt, nn = t + 1, 0, 0
-                task_of[r], j_of[r] = t, cnt
-                cnt += 1
-                nn += d
-            T = t + 1 if (~hub).any() else 0
+                if d > self.WIDE_MIN:
+                    if open_w is None or open_w[1] == 2 or open_w[2] + d > self.TASK_NNZ:
+                        open_w = [T, 0, 0]
+                        wide_flags.append(1)
+                        T += 1
+                    task_of[r], slot_of[r], j_of[r] = open_w[0], 0, open_w[1]
+                    open_w[1] += 1
+                    open_w[2] += d
+                else:
+                    if open_n is None or open_n[1] == 2 * NPW or open_n[2] + d > self.TASK_NNZ:
+                        open_n = [T, 0, 0]
+                        wide_flags.append(0)
+                        T += 1
+                    task_of[r], slot_of[r], j_of[r] = open_n[0], open_n[1] % NPW, open_n[1] // NPW
+                    open_n[1] += 1
+                    open_n[2] += d
+            twide = np.asarray(wide_flags, dtype=np.uint8)
             erow = np.repeat(np.arange(n_rows), deg)
             keep = np.nonzero(~hub[erow])[0]
-            ek = task_of[erow[keep]] * S + col[keep] // slice_rows
+            er = erow[keep]
+            nsl = -(-n_cols // slice_rows)
+            # owner = (task, lane group); inside an owner: slice, then first / second row, then the CSR's column order
+            ek = ((task_of[er] * NPW + slot_of[er]) * nsl + col[keep] // slice_rows) * 2 + j_of[er]
             order = np.argsort(ek, kind="stable")
             perm = keep[order]
-            ecol = (col[perm] | (j_of[erow[perm]] << 28)).astype(np.int64)
+            ecol = col[perm] | (j_of[erow[perm]] << 28)
             ecol = np.where(ecol >= 2 ** 31, ecol - 2 ** 32, ecol).astype(np.int32)       # bit pattern of the uint32 word
-            tptr = np.zeros(T * S + 1, dtype=np.int64)
-            if T:
-                tptr[1:] = np.cumsum(np.bincount(ek, minlength=T * S))
-            trows = np.full((max(T, 1), self.TASK_ROWS), -1, dtype=np.int32)
+            owner = task_of[er] * NPW + slot_of[er]
+            cnt = np.bincount(owner, minlength=max(T, 1) * NPW)
+            starts = np.zeros(max(T, 1) * NPW + 1, dtype=np.int64)
+            starts[1:] = np.cumsum(cnt)
+            tptr = np.zeros((max(T, 1), NPW + 1), dtype=np.int64)
+            tptr[:, :NPW] = starts[:-1].reshape(-1, NPW)
+            tptr[:, NPW] = starts[NPW::NPW]
+            # a wide task keeps all its edges under lane group 0: its range is [tptr[0], tptr[1]) = group 0's, as the kernel reads it
+            trows = np.full((max(T, 1), 2 * NPW), -1, dtype=np.int32)
             nh = np.nonzero(~hub)[0]
-            trows[task_of[nh], j_of[nh]] = nh
-            plan = dict(T=T, S=int(S), tptr=torch.from_numpy(tptr.astype(np.int32)).to(dev),
-                        trows=torch.from_numpy(trows).to(dev), ecol=torch.from_numpy(ecol).to(dev),
-                        perm=torch.from_numpy(perm.astype(np.int64)).to(dev),
+            trows[task_of[nh], j_of[nh] * NPW + slot_of[nh]] = nh
+            plan = dict(T=T, NPW=NPW, slice_rows=int(slice_rows), tptr=torch.from_numpy(tptr.astype(np.int32)).to(dev),
+                        trows=torch.from_numpy(trows).to(dev), twide=torch.from_numpy(twide if T else np.zeros(1, np.uint8)).to(dev),
+                        ecol=torch.from_numpy(ecol).to(dev), perm=torch.from_numpy(perm.astype(np.int64)).to(dev),
                         long_rows=torch.from_numpy(np.nonzero(hub)[0].astype(np.int32)).to(dev))
         cache[key] = plan
         return plan
@@ -758,7 +780,7 @@ def _spmm(plan: CsrPlan, transposed: bool, val, Xa, Xb, x_split, Y, acc_a, acc_b
             lr = sp["long_rows"]
             _lib.check(
                 lib.mi_spmm_sliced(crow_h.data_ptr(), col_h.data_ptr(), val.data_ptr(), sp["tptr"].data_ptr(), sp["trows"].data_ptr(),
-                                   sp["ecol"].data_ptr(), ev.data_ptr(), sp["T"], sp["S"], Xa.data_ptr(), _lib.ptr(Xb), x_split,
+                                   sp["twide"].data_ptr(), sp["ecol"].data_ptr(), ev.data_ptr(), sp["T"], Xa.data_ptr(), _lib.ptr(Xb), x_split,
                                    _lib.ptr(Y), _lib.ptr(acc_a), _lib.ptr(acc_b), acc_split, _lib.ptr(acc_out), float(scale), D,
                                    lr.data_ptr() if lr.numel() else None, lr.numel(), _lib.ptr(xmask), _lib.stream_ptr(val.device)),
                 "mi_spmm_sliced")

@@ -53,7 +53,7 @@ SIGNATURES = {
                         _p, _p],
     "mi_batch_row_list": [_p, _p, _p, _i64, _i64, _i64, _p, _i32, _p, _p, _p],
     "mi_row_mask": [_p, _p, _i32, _i32, _i32, _p, _p],
-    "mi_spmm_sliced": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _p, _i32,
+    "mi_spmm_sliced": [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _p, _i32,
                        _p, _p],
     "mi_spmm_tiled": [_p, _p, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _i32, _p, ctypes.c_float, _i32, _p],
     "mi_gemm_f32": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64,

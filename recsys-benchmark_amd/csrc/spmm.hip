@@ -183,26 +183,31 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
 // What bounds the row-per-wave kernels above is not their arithmetic but WHERE their gathers land: every XCD's waves
 // gather rows of X from all over the operand (17.8 MB at Yelp2018 size against 4 MiB of L2 per XCD: hit rate 0.38, 451 MB
 // of fabric traffic per layer against 54 MB compulsory, profiles/r03_pmc_summary.csv).  This form makes all waves of the
-// chip walk the COLUMNS of A in the same order at the same pace:
-//   * the columns (= rows of X) are cut into S slices of <= ~2 MiB of X;
-//   * the rows of A are packed, once per sparsity pattern, into TASKS of <= 8 rows and <= ~256 nonzeros (hubs keep their
-//     own 16-wave workgroup); a wave owns one task at a time and keeps the 8 running sums in registers (no LDS, no atomics);
-//   * a task's edges are stored slice by slice (flat: an edge = column | row-in-task << 28), so a wave spends about the
-//     same number of gathers in every slice as every other wave: while the chip is "in" slice p, each XCD pulls that
-//     slice of X into its L2 ONCE and serves the ~30 re-uses per row from there.  No synchronisation: the alignment is
-//     only as good as the balance, and only speed depends on it.
-//   * every lane group (LPR lanes = one row of X) takes one edge per step, 4 steps in flight; the edge's contribution goes
-//     to the running sum of its row by 8 predicated adds (static register indices).
-// Sum order is fixed by the plan: bit-reproducible.
-constexpr int kTaskRows = 8;
+// chip walk the COLUMNS of A in the same order at about the same pace:
+//   * the columns (= rows of X) are cut into slices of <= ~2 MiB of X;
+//   * the rows of A are packed, once per sparsity pattern, into TASKS of about equal work whose edges are stored slice by
+//     slice; a wave owns one task at a time and keeps its running sums in registers (no LDS, no atomics):
+//       narrow task: 2 rows per lane group (a lane group = the LPR lanes that hold one row of X): every group walks the
+//                    edges of ITS two rows — no combining across groups, one predicated add pair per edge;
+//       wide task:   1-2 rows of 48..256 nonzeros, all lane groups stride the same edge range (combined by shuffles at
+//                    the end), so that a heavy row does not leave the other groups idle;
+//       hubs (> 256 nonzeros) keep their own 16-wave workgroup (their columns ascend: slice order too);
+//   * while the chip is "in" slice p, each XCD pulls that slice of X into its L2 ONCE and serves the ~30 re-uses per row from
+//     there.  No synchronisation: the alignment is only as good as the balance, and only speed depends on it;
+//   * 4 edges in flight per lane group, the next trip's edge words and values loaded before this trip's rows of X are used.
+// An edge = column | (which of the owner's two rows) << 28.  Sum order is fixed by the plan: bit-reproducible.
+// (First version, measured 100 -> 87 us per Yelp2018 layer against 75 for the row-per-wave kernel: 8 rows per wave with ALL
+// groups striding one flat edge list and an 8-way predicated add per edge — ~3 200 vector instructions per task, the
+// vector ALU became the bound.)
 constexpr int kTaskColBits = 28;
 
 template <int LPR>
 __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val,      // hubs: the CSR itself
-    const int *__restrict__ tptr, const int *__restrict__ trows, const int *__restrict__ ecol, const float *__restrict__ eval,
-    int n_tasks, int n_slices, Seg2 X, float *__restrict__ Y, Seg2 acc_in, int has_acc_in, float *__restrict__ acc_out,
-    float scale, const int *__restrict__ long_rows, int n_long, const uint32_t *__restrict__ xmask) {
+    const int *__restrict__ tptr, const int *__restrict__ trows, const uint8_t *__restrict__ twide,
+    const int *__restrict__ ecol, const float *__restrict__ eval, int n_tasks, Seg2 X, float *__restrict__ Y, Seg2 acc_in,
+    int has_acc_in, float *__restrict__ acc_out, float scale, const int *__restrict__ long_rows, int n_long,
+    const uint32_t *__restrict__ xmask) {
   constexpr int NPW = kWave / LPR;
   constexpr int D = LPR * 4;
   constexpr int U = 4;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int q = lane % LPR, k = lane / LPR;
-  if ((int)blockIdx.x < n_long) {          // a hub row: the whole workgroup strides it (its columns ascend: slice order too)
+  if ((int)blockIdx.x < n_long) {          // a hub row: the whole workgroup strides it
     const int row = long_rows[blockIdx.x];
     const int lo = crow[row], hi = crow[row + 1];
     float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q, xmask);
@@ -231,65 +236,58 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
   const int nblk = gridDim.x - n_long;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = (blockIdx.x - n_long) * kHubWaves + w; t < n_tasks; t += nblk * kHubWaves) {
-    // The task's edges lie slice by slice in ONE contiguous range: walking it front to back IS the slice order, so the loop
-    // needs no per-slice bounds — 16 edges (NPW lane groups x U) per trip, the next trip's edge words and values loaded
-    // before this trip's rows of X are used (two dependent round trips per trip otherwise: a wave's ~16 trips were a
-    // ~30 us latency chain in the first version of this kernel).
-    const int lo = tptr[(int64_t)t * n_slices], hi = tptr[(int64_t)(t + 1) * n_slices];
-    const int myr = lane < kTaskRows ? trows[(int64_t)t * kTaskRows + lane] : -1;
-    float4 acc[kTaskRows];
-#pragma unroll
-    for (int j = 0; j < kTaskRows; ++j) acc[j] = z4;
+    const bool wide = twide[t] != 0;
+    const int pb = t * (NPW + 1), rb = t * 2 * NPW;
+    const int lo = tptr[pb + (wide ? 0 : k)], hi = tptr[pb + (wide ? 1 : k + 1)];
+    const int r0 = trows[rb + (wide ? 0 : k)], r1 = trows[rb + NPW + (wide ? 0 : k)];
+    const int step = wide ? NPW : 1;
+    int cur = lo + (wide ? k : 0);
+    float4 a0 = z4, a1 = z4;
     int cw[U];
     float v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = lo + u * NPW + k;
+      const int e = cur + u * step;
       const bool ok = e < hi;
       cw[u] = ok ? ecol[e] : 0;
       v[u] = ok ? eval[e] : 0.f;
     }
-    for (int base = lo; base < hi; base += NPW * U) {
+    while (__any(cur < hi)) {
       float4 x[U];
-      if (xmask) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = cw[u] & ((1 << kTaskColBits) - 1);
-          const bool on = (xmask[c >> 5] >> (c & 31)) & 1u;
-          x[u] = (on && v[u] != 0.f) ? ld4(seg_row(X, c, D) + q * 4) : z4;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = ld4(seg_row(X, cw[u] & ((1 << kTaskColBits) - 1), D) + q * 4);
+      for (int u = 0; u < U; ++u) {
+        const int c = cw[u] & ((1 << kTaskColBits) - 1);
+        bool on = v[u] != 0.f;                     // (an edge past the end, or a zero value: nothing to fetch)
+        if (xmask) on = on && ((xmask[c >> 5] >> (c & 31)) & 1u);
+        x[u] = on ? ld4(seg_row(X, c, D) + q * 4) : z4;
       }
+      cur += U * step;
       int ncw[U];
       float nv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = base + NPW * U + u * NPW + k;
+        const int e = cur + u * step;
         const bool ok = e < hi;
         ncw[u] = ok ? ecol[e] : 0;
         nv[u] = ok ? eval[e] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int jr = (unsigned)cw[u] >> kTaskColBits;
-        const float4 c4 = make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w);
-#pragma unroll
-        for (int j = 0; j < kTaskRows; ++j) {
-          const float m = jr == j ? 1.f : 0.f;
-          acc[j].x = fmaf(m, c4.x, acc[j].x); acc[j].y = fmaf(m, c4.y, acc[j].y);
-          acc[j].z = fmaf(m, c4.z, acc[j].z); acc[j].w = fmaf(m, c4.w, acc[j].w);
-        }
+        const bool second = ((unsigned)cw[u] >> kTaskColBits) != 0;
+        const float v0 = second ? 0.f : v[u], v1 = second ? v[u] : 0.f;
+        a0.x = fmaf(v0, x[u].x, a0.x); a0.y = fmaf(v0, x[u].y, a0.y); a0.z = fmaf(v0, x[u].z, a0.z); a0.w = fmaf(v0, x[u].w, a0.w);
+        a1.x = fmaf(v1, x[u].x, a1.x); a1.y = fmaf(v1, x[u].y, a1.y); a1.z = fmaf(v1, x[u].z, a1.z); a1.w = fmaf(v1, x[u].w, a1.w);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) { cw[u] = ncw[u]; v[u] = nv[u]; }
     }
-#pragma unroll
-    for (int j = 0; j < kTaskRows; ++j) {
-      const int row = __shfl(myr, j);
-      const float4 sj = slot_sum<LPR>(acc[j]);
-      if (row >= 0 && k == 0) epilogue4(sj, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+    if (wide) {
+      a0 = slot_sum<LPR>(a0);
+      a1 = slot_sum<LPR>(a1);
+    }
+    if (!wide || k == 0) {
+      if (r0 >= 0) epilogue4(a0, r0, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+      if (r1 >= 0) epilogue4(a1, r1, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
     }
   }
 }
@@ -554,17 +552,20 @@ int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, int32_t n
   return launch_status();
 }
 
-// Task-balanced, slice-phased SpMM (k_spmm_sliced above).  tptr int32[n_tasks * n_slices + 1]: edge offsets of every
-// (task, slice); trows int32[n_tasks, 8]: the task's output rows (-1: none); ecol int32[n_edges] = column | row-in-task << 28
-// and eval fp32[n_edges] in (task, slice) order.  The tasks' rows and long_rows together must cover every output row exactly
-// once; long_rows (hubs) are computed from the CSR (crow, col, val) itself.  n_slices <= 63, columns < 2^28.
+// Task-balanced, slice-phased SpMM (k_spmm_sliced above), NPW = 256 / D lane groups per wave.
+//   tptr  int32[n_tasks, NPW + 1]: narrow task: edge range of lane group k = [tptr[k], tptr[k + 1]); wide task: [tptr[0], tptr[1])
+//   trows int32[n_tasks, 2 * NPW]: narrow: group k owns rows trows[k] and trows[NPW + k]; wide: rows trows[0], trows[NPW]; -1 = none
+//   twide uint8[n_tasks]: 1 = wide;  ecol int32[n_edges] = column | (second row of the owner) << 28, eval the values
+// The tasks' rows and long_rows together must cover every output row exactly once; long_rows (hubs) are computed from the
+// CSR (crow, col, val) itself.  Columns < 2^28.
 int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, const int32_t *tptr, const int32_t *trows,
-                   const int32_t *ecol, const float *eval, int32_t n_tasks, int32_t n_slices, const float *Xa, const float *Xb,
-                   int32_t x_split, float *Y, const float *acc_in_a, const float *acc_in_b, int32_t acc_split, float *acc_out,
-                   float scale, int32_t D, const int32_t *long_rows, int32_t n_long, const uint32_t *xmask, void *stream) {
-  if (n_tasks < 0 || n_long < 0 || n_slices <= 0 || n_slices > 63 || D <= 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
+                   const uint8_t *twide, const int32_t *ecol, const float *eval, int32_t n_tasks, const float *Xa,
+                   const float *Xb, int32_t x_split, float *Y, const float *acc_in_a, const float *acc_in_b, int32_t acc_split,
+                   float *acc_out, float scale, int32_t D, const int32_t *long_rows, int32_t n_long, const uint32_t *xmask,
+                   void *stream) {
+  if (n_tasks < 0 || n_long < 0 || D <= 0 || x_split < 0 || acc_split < 0) return MI_ERR_INVALID_ARG;
   if (n_tasks == 0 && n_long == 0) return MI_OK;
-  if (!Xa || (!Y && !acc_out) || (n_tasks > 0 && (!tptr || !trows || !ecol || !eval))) return MI_ERR_INVALID_ARG;
+  if (!Xa || (!Y && !acc_out) || (n_tasks > 0 && (!tptr || !trows || !twide || !ecol || !eval))) return MI_ERR_INVALID_ARG;
   if (n_long > 0 && (!long_rows || !crow || !col || !val)) return MI_ERR_INVALID_ARG;
   if (!vec_ok(D) || n_long > 60000) return MI_ERR_UNSUPPORTED;
   if (!aligned16(Xa) || (Xb && !aligned16(Xb)) || (Y && !aligned16(Y)) || (acc_in_a && !aligned16(acc_in_a)) ||
@@ -575,9 +576,9 @@ int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, co
   Seg2 A{acc_in_a, acc_in_b ? acc_in_b : acc_in_a, acc_in_b ? acc_split : 0x7fffffff};
   int tb = (n_tasks + kHubWaves - 1) / kHubWaves;
   if (tb > 2048) tb = 2048;
-#define CALL(LPR)                                                                                                         \
-  MI_LAUNCH("spmm_sliced", (k_spmm_sliced<LPR>), n_long + tb, kHubWaves * kWave, stream, crow, col, val, tptr, trows, ecol, \
-            eval, n_tasks, n_slices, X, Y, A, has_acc, acc_out, scale, long_rows, n_long, xmask)
+#define CALL(LPR)                                                                                                           \
+  MI_LAUNCH("spmm_sliced", (k_spmm_sliced<LPR>), n_long + tb, kHubWaves * kWave, stream, crow, col, val, tptr, trows, twide, \
+            ecol, eval, n_tasks, X, Y, A, has_acc, acc_out, scale, long_rows, n_long, xmask)
   switch (D / 4) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;

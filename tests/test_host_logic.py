@@ -230,13 +230,15 @@ def test_adam_subclass_on_cpu_parameters_is_plain_torch_adam():
 
 
 def test_sliced_spmm_plan_is_a_partition_of_the_matrix(monkeypatch):
-    """CsrPlan.sliced (the host side of mi_spmm_sliced): tasks of <= 8 rows and a bounded number of nonzeros, every
-    non-hub edge exactly once, stored slice by slice; hubs listed apart; A (and A^T) reassembled from the plan is A."""
+    """CsrPlan.sliced (the host side of mi_spmm_sliced): narrow tasks (a lane group owns two rows), wide tasks (rows of more
+    than WIDE_MIN nonzeros, all groups stride one range), hubs apart; every non-hub edge exactly once, inside an owner's
+    range slice by slice; A (and A^T) reassembled from the plan exactly as the kernel reads it is A."""
     import numpy as np
 
     from recsys_benchmark_amd import _kernels as K
 
-    monkeypatch.setattr(K, "HUB_DEGREE", 40)
+    monkeypatch.setattr(K, "HUB_DEGREE", 60)
+    monkeypatch.setattr(K.CsrPlan, "WIDE_MIN", 24)
     monkeypatch.setattr(K.CsrPlan, "SLICE_BYTES", 64 * 4 * 16)         # 16 rows of X (D = 64) per slice
     gen = torch.Generator().manual_seed(0)
     n, m, nnz = 300, 260, 6000
@@ -244,33 +246,46 @@ def test_sliced_spmm_plan_is_a_partition_of_the_matrix(monkeypatch):
     c = (m * torch.rand(nnz, generator=gen).pow(2)).long().clamp_(max=m - 1)
     A = torch.sparse_coo_tensor(torch.stack([r, c]), torch.randn(nnz, generator=gen), (n, m)).coalesce().to_sparse_csr()
     plan = K.CsrPlan(A.crow_indices(), A.col_indices(), tuple(A.shape))
-    for tr in (False, True):
-        sp = plan.sliced(64, tr)
-        val = plan.transposed_values(A.values()) if tr else A.values()
-        ev = plan.sliced_values(val, 64, tr)
-        T, S = sp["T"], sp["S"]
-        nr, nc = (m, n) if tr else (n, m)
-        tptr, trows = sp["tptr"].numpy(), sp["trows"].numpy()
-        ecol = sp["ecol"].numpy().astype(np.int64) & 0xFFFFFFFF
-        per_task = (tptr[1:] - tptr[:-1]).reshape(T, S).sum(1)
-        deg = np.diff((plan.crow_t if tr else plan.crow).numpy())
-        assert per_task.max() <= max(K.CsrPlan.TASK_NNZ, deg[deg <= 40].max())
-        rows_seen = trows[trows >= 0]
-        hubs = sp["long_rows"].numpy()
-        assert sorted(rows_seen.tolist() + hubs.tolist()) == list(range(nr)), "tasks + hubs cover every row once"
-        assert (deg[hubs] > 40).all() and (deg[rows_seen] <= 40).all()
-        dense = torch.zeros(nr, nc)
-        for t in range(T):
-            for p in range(S):
-                for e in range(tptr[t * S + p], tptr[t * S + p + 1]):
-                    cc, j = int(ecol[e]) & ((1 << 28) - 1), int(ecol[e]) >> 28
-                    assert cc // 16 == p and trows[t, j] >= 0
-                    dense[trows[t, j], cc] += ev[e]
-        crow, col = (plan.crow_t if tr else plan.crow).numpy(), (plan.col_t if tr else plan.col).numpy()
-        for hr in hubs.tolist():
-            for e in range(crow[hr], crow[hr + 1]):
-                dense[hr, col[e]] += val[e]
-        assert torch.allclose(dense, A.to_dense().t() if tr else A.to_dense())
+    for D in (64, 16):
+        for tr in (False, True):
+            sp = plan.sliced(D, tr)
+            NPW = 256 // D
+            val = plan.transposed_values(A.values()) if tr else A.values()
+            ev = plan.sliced_values(val, D, tr)
+            T = sp["T"]
+            nr, nc = (m, n) if tr else (n, m)
+            tptr, trows, twide = sp["tptr"].numpy(), sp["trows"].numpy(), sp["twide"].numpy()
+            ecol = sp["ecol"].numpy().astype(np.int64) & 0xFFFFFFFF
+            deg = np.diff((plan.crow_t if tr else plan.crow).numpy())
+            hubs = sp["long_rows"].numpy()
+            rows_seen = trows[trows >= 0]
+            assert sorted(rows_seen.tolist() + hubs.tolist()) == list(range(nr)), "tasks + hubs cover every row once"
+            assert (deg[hubs] > 60).all() and (deg[rows_seen] <= 60).all()
+            assert twide.sum() > 0 and (twide == 0).sum() > 0
+            dense = torch.zeros(nr, nc)
+            sr = sp["slice_rows"]
+            for t in range(T):
+                groups = [0] if twide[t] else range(NPW)
+                for k in groups:
+                    lo, hi = (tptr[t, 0], tptr[t, 1]) if twide[t] else (tptr[t, k], tptr[t, k + 1])
+                    r0, r1 = trows[t, k], trows[t, NPW + k]
+                    if twide[t]:
+                        assert deg[r0] > 24 and (r1 < 0 or deg[r1] > 24) and (trows[t, 1:NPW] < 0).all()
+                    last_slice = -1
+                    for e in range(lo, hi):
+                        cc, j = int(ecol[e]) & ((1 << 28) - 1), int(ecol[e]) >> 28
+                        assert cc // sr >= last_slice, "an owner's edges ascend slice by slice"
+                        last_slice = cc // sr
+                        row = r1 if j else r0
+                        assert row >= 0
+                        dense[row, cc] += ev[e]
+                if twide[t]:
+                    assert (tptr[t, 1:] == tptr[t, 1]).all()
+            crow, col = (plan.crow_t if tr else plan.crow).numpy(), (plan.col_t if tr else plan.col).numpy()
+            for hr in hubs.tolist():
+                for e in range(crow[hr], crow[hr + 1]):
+                    dense[hr, col[e]] += val[e]
+            assert torch.allclose(dense, A.to_dense().t() if tr else A.to_dense())
 
 
 def test_csr_plan_caches_never_serve_a_recycled_address():
