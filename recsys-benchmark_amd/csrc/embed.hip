@@ -179,6 +179,13 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
                                                      const float *__restrict__ g, DualGrads gr, int64_t n,
                                                      int F, int De, int op, int xf, int lds1, int lds2, SmallFields sm) {
   __shared__ float acc[kLdsAccFloats];
+  // lds1 == 2: table 1 has <= 4 rows (QR `divider: 2`: two) and a thread keeps its column d for the whole launch (De divides
+  // the workgroup): the table-1 gradient is summed in REGISTERS, one per row, and joined once per workgroup — every element
+  // used to do an LDS float atomic on one of n1 * De addresses, and ds_add_f32 executes a wave's lanes one after the other
+  // (profiles/r03_lds_atomic_probe.txt): that, not table 2's scattered atomics, was most of this kernel's 26 us
+  const bool reg1 = lds1 == 2;
+  float r1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (reg1) lds1 = 0;
   if (sm.n > 0 && (int)blockIdx.x >= sm.nmain) {
     // ---- a small field's column: thread (lookup slot lk, column d), registers r[row of the field's span]
     const int sb = blockIdx.x - sm.nmain, f = sm.fields[sb / kSmallParts], part = sb % kSmallParts;
@@ -265,7 +272,11 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
       g1 = t.M1[a1] ? g1 : 0.f;
       g2 = t.M2[a2] ? g2 : 0.f;
     }
-    if (lds1) atomicAdd(&acc[a1], g1); else atomicAdd(gr.gT1 + a1, g1);
+    if (reg1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r1[k] += (i1 == k) ? g1 : 0.f;
+    } else if (lds1) atomicAdd(&acc[a1], g1);
+    else atomicAdd(gr.gT1 + a1, g1);
     if (gr.g2vals) {                                // row form: one coalesced store per element, the row id once per lookup
       gr.g2vals[e] = g2;
       if (d == 0) gr.rows2[i] = i2;
@@ -275,6 +286,19 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
     if (xf == XF_SOFT) {
       atomicAdd(gr.gS1 + a1, s1);
       atomicAdd(gr.gS2 + a2, s2);
+    }
+  }
+  if (reg1) {
+    __syncthreads();                       // (acc may hold table-2 sums of the loop above only when lds2; reg1 launches pass lds2 = 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k * kBlock + threadIdx.x] = r1[k];
+    __syncthreads();
+    const int per = kBlock / De;
+    for (int o = threadIdx.x; o < (int)t.n1 * De; o += kBlock) {
+      const int k = o / De, d = o % De;
+      float v = 0.f;
+      for (int l = 0; l < per; ++l) v += acc[k * kBlock + l * De + d];
+      if (v != 0.f) atomicAdd(gr.gT1 + o, v);
     }
   }
   if (n1e + n2e) {
@@ -593,9 +617,13 @@ int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float 
   if (!idx || !g_out || !T1 || !T2 || !gT1 || !g2vals || !rows2) return MI_ERR_INVALID_ARG;
   DualTables t{T1, T2, nullptr, nullptr, nullptr, nullptr, n1, n2, mod1, div2};
   DualGrads gr{gT1, nullptr, nullptr, nullptr, g2vals, rows2};
-  const int lds1 = (n1 * De <= kLdsAccFloats / 2);
+  int lds1 = (n1 * De <= kLdsAccFloats / 2);
   int grid = grid_for_elems(n * De);
-  if (lds1 && grid > 512) grid = 512;
+  if (n1 <= 4 && kBlock % De == 0) {                         // table 1 summed in registers (see k_dual_bwd)
+    lds1 = 2;
+    if (grid > 1024) grid = 1024;       // the loop is a chain of table-2 row gathers per thread: many threads in flight; the
+  }                                     // join is one coalesced atomic instruction per workgroup
+  else if (lds1 && grid > 512) grid = 512;
   SmallFields sm{nullptr, nullptr, nullptr, 0, grid, 0};
   MI_LAUNCH("dual_gather_bwd_rows", k_dual_bwd, grid, kBlock, stream, idx, t, g_out, gr, n, F, De, op, (int)XF_NONE, lds1, 0, sm);
   return launch_status();
@@ -618,7 +646,10 @@ int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const floa
   // LDS pre-aggregation for small tables; fewer, fatter workgroups then bound the flush traffic
   int lds1 = (n1 * De <= kLdsAccFloats / 2), lds2 = (n2 * De <= kLdsAccFloats / 2);
   int grid = grid_for_elems(n * De);
-  if ((lds1 || lds2) && grid > 512) grid = 512;
+  if (n1 <= 4 && kBlock % De == 0 && !lds2 && xform == XF_NONE) {      // table 1 summed in registers (see k_dual_bwd)
+    lds1 = 2;
+    if (grid > 1024) grid = 1024;
+  } else if ((lds1 || lds2) && grid > 512) grid = 512;
   SmallFields sm{nullptr, nullptr, nullptr, 0, grid, 0};
   if (n_small < 0 || (n_small > 0 && (!small_fields || !field_row0 || !is_small))) return MI_ERR_INVALID_ARG;
   // the per-field sums need the [B, F] shape, plain tables, a thread layout of whole rows, table 2 on the atomic path
