@@ -332,10 +332,10 @@ MI_API int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, in
  * whose edges are stored slice by slice: every wave of the chip then gathers from the same slice of X at about the same time
  * and each XCD's 4 MiB L2 serves the re-uses (the row-per-wave kernel re-fetches X 8.4x).  NPW = 256 / D lane groups per wave.
  *   tptr  int32[n_tasks, NPW + 1]  narrow task: lane group k's edges = [tptr[k], tptr[k+1]); wide task: [tptr[0], tptr[1])
- *   trows int32[n_tasks, 2 NPW]    narrow: group k owns rows trows[k], trows[NPW + k]; wide: rows trows[0], trows[NPW]; -1 = none
+ *   trows int32[n_tasks, 4 NPW]    narrow: group k owns rows trows[j NPW + k], j = 0..3; wide: rows trows[j NPW]; -1 = none
  *   twide uint8[n_tasks]           1 = wide (all groups stride one edge range: rows of 48..256 nonzeros)
- *   ecol  int32[n_edges]           column | (second row of its owner) << 28, slice by slice inside a range; eval the values
- *   long_rows: hub rows, computed from the CSR (crow, col, val) by a 16-wave workgroup each; tasks + hubs cover every row once.
+ *   ecol  int32[n_edges]           column | (which of its owner's rows) << 28, slice by slice inside a range; eval the values
+ *   long_rows: hub rows, computed from the CSR (crow, col, val) by an 8-wave workgroup each; tasks + hubs cover every row once.
  * Other arguments as mi_spmm_csr_masked.  Fixed summation order (no atomics). */
 MI_API int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, const int32_t *tptr,
                           const int32_t *trows, const uint8_t *twide, const int32_t *ecol, const float *eval,

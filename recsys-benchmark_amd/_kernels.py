@@ -640,14 +640,15 @@ class CsrPlan:
 
     # ---- task-balanced, slice-phased form (mi_spmm_sliced, round 4) ----
     SLICE_BYTES = 2 << 20           # rows of X per column slice: half of an XCD's 4 MiB L2
-    TASK_NNZ = 256                  # nonzeros per task: a wave's share of every slice is ~TASK_NNZ / slices gathers
+    TASK_NNZ = 512                  # nonzeros per task: few enough tasks that every one is resident at once (one round)
+    GROUP_ROWS = 4                  # kGroupRows of csrc/spmm.hip: rows a lane group (narrow task) / a wide task owns
     WIDE_MIN = 48                   # rows with more nonzeros than this get a wide task (all lane groups stride them)
 
     def sliced(self, D: int, transposed: bool):
         """The task plan of A (or A^T) for rows of D floats, built once per (pattern, D) on the host (csrc/spmm.hip,
         k_spmm_sliced): NPW = 256 / D lane groups per wave.  Rows in row order; a row of <= WIDE_MIN nonzeros joins the open
-        NARROW task (<= 2 NPW rows, <= TASK_NNZ nonzeros; row i of the task belongs to lane group i % NPW), a heavier one the
-        open WIDE task (<= 2 rows, <= TASK_NNZ nonzeros unless alone), hubs (> HUB_DEGREE) are listed apart.  Inside an
+        NARROW task (<= 4 NPW rows, <= TASK_NNZ nonzeros; row i of the task belongs to lane group i % NPW), a heavier one the
+        open WIDE task (<= 4 rows, <= TASK_NNZ nonzeros unless alone), hubs (> HUB_DEGREE) are listed apart.  Inside an
         owner's range the edges are sorted by column slice.  None when the kernel cannot take the matrix."""
         key = (int(D), bool(transposed))
         cache = self.__dict__.setdefault("_sliced", {})
@@ -660,7 +661,7 @@ class CsrPlan:
         plan = None
         if _float4_rows(D) and n_cols < (1 << 28) and self.nnz > 0 and n_rows > 0:
             dev = crow_d.device
-            NPW = 256 // D
+            NPW, GR = 256 // D, self.GROUP_ROWS
             crow = crow_d.cpu().numpy().astype(np.int64)
             col = col_d.cpu().numpy().astype(np.int64)
             deg = crow[1:] - crow[:-1]
@@ -679,7 +680,7 @@ class CsrPlan:
                     continue
                 d = degl[r]
                 if d > self.WIDE_MIN:
-                    if open_w is None or open_w[1] == 2 or open_w[2] + d > self.TASK_NNZ:
+                    if open_w is None or open_w[1] == GR or open_w[2] + d > self.TASK_NNZ:
                         open_w = [T, 0, 0]
                         wide_flags.append(1)
                         T += 1
@@ -687,7 +688,7 @@ class CsrPlan:
                     open_w[1] += 1
                     open_w[2] += d
                 else:
-                    if open_n is None or open_n[1] == 2 * NPW or open_n[2] + d > self.TASK_NNZ:
+                    if open_n is None or open_n[1] == GR * NPW or open_n[2] + d > self.TASK_NNZ:
                         open_n = [T, 0, 0]
                         wide_flags.append(0)
                         T += 1
@@ -700,7 +701,7 @@ class CsrPlan:
             er = erow[keep]
             nsl = -(-n_cols // slice_rows)
             # owner = (task, lane group); inside an owner: slice, then first / second row, then the CSR's column order
-            ek = ((task_of[er] * NPW + slot_of[er]) * nsl + col[keep] // slice_rows) * 2 + j_of[er]
+            ek = ((task_of[er] * NPW + slot_of[er]) * nsl + col[keep] // slice_rows) * GR + j_of[er]
             order = np.argsort(ek, kind="stable")
             perm = keep[order]
             ecol = col[perm] | (j_of[erow[perm]] << 28)
@@ -713,7 +714,7 @@ class CsrPlan:
             tptr[:, :NPW] = starts[:-1].reshape(-1, NPW)
             tptr[:, NPW] = starts[NPW::NPW]
             # a wide task keeps all its edges under lane group 0: its range is [tptr[0], tptr[1]) = group 0's, as the kernel reads it
-            trows = np.full((max(T, 1), 2 * NPW), -1, dtype=np.int32)
+            trows = np.full((max(T, 1), GR * NPW), -1, dtype=np.int32)
             nh = np.nonzero(~hub)[0]
             trows[task_of[nh], j_of[nh] * NPW + slot_of[nh]] = nh
             plan = dict(T=T, NPW=NPW, slice_rows=int(slice_rows), tptr=torch.from_numpy(tptr.astype(np.int32)).to(dev),

@@ -187,22 +187,27 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_planned(
 //   * the columns (= rows of X) are cut into slices of <= ~2 MiB of X;
 //   * the rows of A are packed, once per sparsity pattern, into TASKS of about equal work whose edges are stored slice by
 //     slice; a wave owns one task at a time and keeps its running sums in registers (no LDS, no atomics):
-//       narrow task: 2 rows per lane group (a lane group = the LPR lanes that hold one row of X): every group walks the
-//                    edges of ITS two rows — no combining across groups, one predicated add pair per edge;
-//       wide task:   1-2 rows of 48..256 nonzeros, all lane groups stride the same edge range (combined by shuffles at
-//                    the end), so that a heavy row does not leave the other groups idle;
-//       hubs (> 256 nonzeros) keep their own 16-wave workgroup (their columns ascend: slice order too);
+//       narrow task: kGroupRows = 4 rows per lane group (a lane group = the LPR lanes that hold one row of X): every group
+//                    walks the edges of ITS rows — no combining across groups, four predicated adds per edge;
+//       wide task:   1-4 rows of 48..256 nonzeros each, all lane groups stride the same edge range (combined by shuffles
+//                    at the end), so that a heavy row does not leave the other groups idle;
+//       hubs (> 256 nonzeros) keep a whole 8-wave workgroup (their columns ascend: slice order too);
+//     tasks hold ~512 nonzeros so that ALL of them (5.3 K at Yelp2018 size + the hubs' waves) are resident at once — with
+//     2-row groups and 16-wave workgroups the 11.3 K tasks ran in three rounds of 4096 waves, the later rounds out of phase
+//     with the first: L2 hit rate 0.51 instead of 0.38, 70 us instead of 75 (profiles/r04_spmm_counters.txt);
 //   * while the chip is "in" slice p, each XCD pulls that slice of X into its L2 ONCE and serves the ~30 re-uses per row from
 //     there.  No synchronisation: the alignment is only as good as the balance, and only speed depends on it;
 //   * 4 edges in flight per lane group, the next trip's edge words and values loaded before this trip's rows of X are used.
-// An edge = column | (which of the owner's two rows) << 28.  Sum order is fixed by the plan: bit-reproducible.
+// An edge = column | (which of the owner's four rows) << 28.  Sum order is fixed by the plan: bit-reproducible.
 // (First version, measured 100 -> 87 us per Yelp2018 layer against 75 for the row-per-wave kernel: 8 rows per wave with ALL
 // groups striding one flat edge list and an 8-way predicated add per edge — ~3 200 vector instructions per task, the
 // vector ALU became the bound.)
 constexpr int kTaskColBits = 28;
+constexpr int kGroupRows = 4;
+constexpr int kTaskWaves = 8;          // waves per workgroup of the sliced kernel (a hub row gets all of them)
 
 template <int LPR>
-__global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
+__global__ __launch_bounds__(kTaskWaves * kWave, 6) void k_spmm_sliced(
     const int *__restrict__ crow, const int *__restrict__ col, const float *__restrict__ val,      // hubs: the CSR itself
     const int *__restrict__ tptr, const int *__restrict__ trows, const uint8_t *__restrict__ twide,
     const int *__restrict__ ecol, const float *__restrict__ eval, int n_tasks, Seg2 X, float *__restrict__ Y, Seg2 acc_in,
@@ -211,21 +216,21 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
   constexpr int NPW = kWave / LPR;
   constexpr int D = LPR * 4;
   constexpr int U = 4;
-  __shared__ float4 part[kHubWaves][LPR];
+  __shared__ float4 part[kTaskWaves][LPR];
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int q = lane % LPR, k = lane / LPR;
   if ((int)blockIdx.x < n_long) {          // a hub row: the whole workgroup strides it
     const int row = long_rows[blockIdx.x];
     const int lo = crow[row], hi = crow[row + 1];
-    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kHubWaves, q, xmask);
+    float4 a = row_dot<LPR>(col, val, X, lo, hi, w * NPW + k, NPW * kTaskWaves, q, xmask);
     a = slot_sum<LPR>(a);
     if (k == 0) part[w][q] = a;
     __syncthreads();
     if (w == 0 && k == 0) {
       float4 s = part[0][q];
 #pragma unroll
-      for (int i = 1; i < kHubWaves; ++i) {
+      for (int i = 1; i < kTaskWaves; ++i) {
         const float4 p = part[i][q];
         s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
       }
@@ -235,14 +240,15 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
   }
   const int nblk = gridDim.x - n_long;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = (blockIdx.x - n_long) * kHubWaves + w; t < n_tasks; t += nblk * kHubWaves) {
+  for (int t = (blockIdx.x - n_long) * kTaskWaves + w; t < n_tasks; t += nblk * kTaskWaves) {
     const bool wide = twide[t] != 0;
-    const int pb = t * (NPW + 1), rb = t * 2 * NPW;
+    const int pb = t * (NPW + 1), rb = t * kGroupRows * NPW;
     const int lo = tptr[pb + (wide ? 0 : k)], hi = tptr[pb + (wide ? 1 : k + 1)];
-    const int r0 = trows[rb + (wide ? 0 : k)], r1 = trows[rb + NPW + (wide ? 0 : k)];
     const int step = wide ? NPW : 1;
     int cur = lo + (wide ? k : 0);
-    float4 a0 = z4, a1 = z4;
+    float4 acc[kGroupRows];
+#pragma unroll
+    for (int j = 0; j < kGroupRows; ++j) acc[j] = z4;
     int cw[U];
     float v[U];
 #pragma unroll
@@ -262,32 +268,35 @@ __global__ __launch_bounds__(kHubWaves * kWave) void k_spmm_sliced(
         x[u] = on ? ld4(seg_row(X, c, D) + q * 4) : z4;
       }
       cur += U * step;
-      int ncw[U];
-      float nv[U];
+      int which[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U; ++u) which[u] = (unsigned)cw[u] >> kTaskColBits;
+      float pv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) pv[u] = v[u];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {          // the next trip's edge words and values: in flight under this trip's rows of X
         const int e = cur + u * step;
         const bool ok = e < hi;
-        ncw[u] = ok ? ecol[e] : 0;
-        nv[u] = ok ? eval[e] : 0.f;
+        cw[u] = ok ? ecol[e] : 0;
+        v[u] = ok ? eval[e] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool second = ((unsigned)cw[u] >> kTaskColBits) != 0;
-        const float v0 = second ? 0.f : v[u], v1 = second ? v[u] : 0.f;
-        a0.x = fmaf(v0, x[u].x, a0.x); a0.y = fmaf(v0, x[u].y, a0.y); a0.z = fmaf(v0, x[u].z, a0.z); a0.w = fmaf(v0, x[u].w, a0.w);
-        a1.x = fmaf(v1, x[u].x, a1.x); a1.y = fmaf(v1, x[u].y, a1.y); a1.z = fmaf(v1, x[u].z, a1.z); a1.w = fmaf(v1, x[u].w, a1.w);
-      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) { cw[u] = ncw[u]; v[u] = nv[u]; }
+        for (int j = 0; j < kGroupRows; ++j) {
+          const float vj = which[u] == j ? pv[u] : 0.f;
+          acc[j].x = fmaf(vj, x[u].x, acc[j].x); acc[j].y = fmaf(vj, x[u].y, acc[j].y);
+          acc[j].z = fmaf(vj, x[u].z, acc[j].z); acc[j].w = fmaf(vj, x[u].w, acc[j].w);
+        }
+      }
     }
-    if (wide) {
-      a0 = slot_sum<LPR>(a0);
-      a1 = slot_sum<LPR>(a1);
-    }
-    if (!wide || k == 0) {
-      if (r0 >= 0) epilogue4(a0, r0, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
-      if (r1 >= 0) epilogue4(a1, r1, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
+#pragma unroll
+    for (int j = 0; j < kGroupRows; ++j) {
+      const int row = trows[rb + j * NPW + (wide ? 0 : k)];
+      float4 a = acc[j];
+      if (wide) a = slot_sum<LPR>(a);
+      if (row >= 0 && (!wide || k == 0)) epilogue4(a, row, q, D, Y, acc_in, has_acc_in != 0, acc_out, scale);
     }
   }
 }
@@ -554,8 +563,8 @@ int mi_spmm_tiled(const int32_t *tile_edge0, const int32_t *tile_row0, int32_t n
 
 // Task-balanced, slice-phased SpMM (k_spmm_sliced above), NPW = 256 / D lane groups per wave.
 //   tptr  int32[n_tasks, NPW + 1]: narrow task: edge range of lane group k = [tptr[k], tptr[k + 1]); wide task: [tptr[0], tptr[1])
-//   trows int32[n_tasks, 2 * NPW]: narrow: group k owns rows trows[k] and trows[NPW + k]; wide: rows trows[0], trows[NPW]; -1 = none
-//   twide uint8[n_tasks]: 1 = wide;  ecol int32[n_edges] = column | (second row of the owner) << 28, eval the values
+//   trows int32[n_tasks, 4 * NPW]: narrow: group k owns rows trows[j * NPW + k], j = 0..3; wide: rows trows[j * NPW]; -1 = none
+//   twide uint8[n_tasks]: 1 = wide;  ecol int32[n_edges] = column | (which of the owner's rows) << 28, eval the values
 // The tasks' rows and long_rows together must cover every output row exactly once; long_rows (hubs) are computed from the
 // CSR (crow, col, val) itself.  Columns < 2^28.
 int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, const int32_t *tptr, const int32_t *trows,
@@ -574,10 +583,10 @@ int mi_spmm_sliced(const int32_t *crow, const int32_t *col, const float *val, co
   Seg2 X{Xa, Xb ? Xb : Xa + (int64_t)x_split * D, Xb ? x_split : 0x7fffffff};
   const int has_acc = acc_in_a != nullptr;
   Seg2 A{acc_in_a, acc_in_b ? acc_in_b : acc_in_a, acc_in_b ? acc_split : 0x7fffffff};
-  int tb = (n_tasks + kHubWaves - 1) / kHubWaves;
-  if (tb > 2048) tb = 2048;
-#define CALL(LPR)                                                                                                           \
-  MI_LAUNCH("spmm_sliced", (k_spmm_sliced<LPR>), n_long + tb, kHubWaves * kWave, stream, crow, col, val, tptr, trows, twide, \
+  int tb = (n_tasks + kTaskWaves - 1) / kTaskWaves;
+  if (tb > 4096) tb = 4096;
+#define CALL(LPR)                                                                                                            \
+  MI_LAUNCH("spmm_sliced", (k_spmm_sliced<LPR>), n_long + tb, kTaskWaves * kWave, stream, crow, col, val, tptr, trows, twide, \
             ecol, eval, n_tasks, X, Y, A, has_acc, acc_out, scale, long_rows, n_long, xmask)
   switch (D / 4) {
     case 1: CALL(1); break;

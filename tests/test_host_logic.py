@@ -268,15 +268,15 @@ def test_sliced_spmm_plan_is_a_partition_of_the_matrix(monkeypatch):
                 groups = [0] if twide[t] else range(NPW)
                 for k in groups:
                     lo, hi = (tptr[t, 0], tptr[t, 1]) if twide[t] else (tptr[t, k], tptr[t, k + 1])
-                    r0, r1 = trows[t, k], trows[t, NPW + k]
+                    own = [trows[t, j * NPW + k] for j in range(4)]
                     if twide[t]:
-                        assert deg[r0] > 24 and (r1 < 0 or deg[r1] > 24) and (trows[t, 1:NPW] < 0).all()
+                        assert all(r < 0 or deg[r] > 24 for r in own) and own[0] >= 0 and (trows[t, 1:NPW] < 0).all()
                     last_slice = -1
                     for e in range(lo, hi):
                         cc, j = int(ecol[e]) & ((1 << 28) - 1), int(ecol[e]) >> 28
                         assert cc // sr >= last_slice, "an owner's edges ascend slice by slice"
                         last_slice = cc // sr
-                        row = r1 if j else r0
+                        row = own[j]
                         assert row >= 0
                         dense[row, cc] += ev[e]
                 if twide[t]:
