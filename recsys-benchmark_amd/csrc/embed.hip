@@ -35,6 +35,26 @@ struct DualTables {
   int64_t div2;              // i2 = idx / div2
 };
 
+// i1 = id % mod1, i2 = id / div2 for a NON-NEGATIVE id (callers test id >= 0 first; a negative id takes the 64-bit path and
+// is rejected by the range check like before).  A 64-bit division by a run-time value is a ~150-instruction routine on this
+// ISA and every one of a lookup's De threads runs it twice: 11 of the dual backward's 24 us at the C3 shape.  Same integers,
+// cheaper: power-of-two divisors (QR `divider: 2`, CERP bucket sizes) are a mask and a shift; ids and divisors below 2^32
+// divide in 32 bits.
+__device__ __forceinline__ void split_id(int64_t id, const DualTables &t, int64_t &i1, int64_t &i2) {
+  const uint64_t u = (uint64_t)id;
+  const bool small = (u >> 32) == 0 && ((uint64_t)t.mod1 >> 32) == 0 && ((uint64_t)t.div2 >> 32) == 0;
+  if (id >= 0 && (t.mod1 & (t.mod1 - 1)) == 0 && (t.div2 & (t.div2 - 1)) == 0) {
+    i1 = (int64_t)(u & (uint64_t)(t.mod1 - 1));
+    i2 = (int64_t)(u >> (63 - __clzll((long long)t.div2)));
+  } else if (small) {
+    i1 = (int64_t)((uint32_t)u % (uint32_t)t.mod1);
+    i2 = (int64_t)((uint32_t)u / (uint32_t)t.div2);
+  } else {
+    i1 = id % t.mod1;
+    i2 = id / t.div2;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float s) { return 1.f / (1.f + expf(-s)); }
 __device__ __forceinline__ float signf_(float w) { return (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f); }
 __device__ __forceinline__ float soft_(float w, float s) {
@@ -84,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void k_dual_fwd(const int64_t *__restrict__
     const int64_t i = tile * RS + r;
     if (i >= n) continue;
     const int64_t id = idx[i];
-    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    int64_t i1, i2;
+    split_id(id, t, i1, i2);
     const bool ok = id >= 0 && i1 < t.n1 && i2 < t.n2;
     bad |= !ok;
     float4 a = z, b = z;
@@ -124,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_dual_fwd_anyD(const int64_t *__restr
     const int64_t i = e / De;
     const int d = (int)(e % De);
     const int64_t id = idx[i];
-    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    int64_t i1, i2;
+    split_id(id, t, i1, i2);
     const bool ok = id >= 0 && i1 < t.n1 && i2 < t.n2;
     bad |= !ok;
     const float a = ok ? load_el(xf, t.T1, t.S1, t.M1, i1 * De + d) : 0.f;
@@ -197,7 +219,8 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
     for (int64_t b = (int64_t)part * LK + lk; b < sm.B; b += (int64_t)kSmallParts * LK) {
       const int64_t i = b * F + f;
       const int64_t id = idx[i];
-      const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+      int64_t i1, i2;
+    split_id(id, t, i1, i2);
       if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) continue;
       int64_t o1, o2;
       out_offsets(op, i, F, De, o1, o2);
@@ -237,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
     const int64_t i = e / De;
     const int d = (int)(e % De);
     const int64_t id = idx[i];
-    const int64_t i1 = id % t.mod1, i2 = id / t.div2;
+    int64_t i1, i2;
+    split_id(id, t, i1, i2);
     if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) {
       if (gr.g2vals) {
         gr.g2vals[e] = 0.f;
@@ -646,10 +670,9 @@ int mi_dual_gather_bwd_fields(const int64_t *idx, const float *g_out, const floa
   // LDS pre-aggregation for small tables; fewer, fatter workgroups then bound the flush traffic
   int lds1 = (n1 * De <= kLdsAccFloats / 2), lds2 = (n2 * De <= kLdsAccFloats / 2);
   int grid = grid_for_elems(n * De);
-  if (n1 <= 4 && kBlock % De == 0 && !lds2 && xform == XF_NONE) {      // table 1 summed in registers (see k_dual_bwd)
-    lds1 = 2;
-    if (grid > 1024) grid = 1024;
-  } else if ((lds1 || lds2) && grid > 512) grid = 512;
+  // (the register form of table 1's sums — lds1 = 2, mi_dual_gather_bwd_rows — measured SLOWER here, 33 vs 27 us at the C3
+  //  shape: with twice the workgroups in flight the scattered table-2 atomics contend more)
+  if ((lds1 || lds2) && grid > 512) grid = 512;
   SmallFields sm{nullptr, nullptr, nullptr, 0, grid, 0};
   if (n_small < 0 || (n_small > 0 && (!small_fields || !field_row0 || !is_small))) return MI_ERR_INVALID_ARG;
   // the per-field sums need the [B, F] shape, plain tables, a thread layout of whole rows, table 2 on the atomic path
