@@ -508,6 +508,11 @@ def dhe_hash(ids, slopes, bias, primes, prefix: int, m: int) -> torch.Tensor:
 HUB_DEGREE = 256  # rows with more nonzeros than this get a whole workgroup
 
 
+def _os_env(name, default):
+    import os
+    return os.environ.get(name, default)
+
+
 class CsrPlan:
     """int32 CSR of A and of A^T plus the short/hub row split, built once per sparsity pattern.
 
@@ -639,8 +644,8 @@ class CsrPlan:
 
 
     # ---- task-balanced, slice-phased form (mi_spmm_sliced, round 4) ----
-    SLICE_BYTES = 2 << 20           # rows of X per column slice: half of an XCD's 4 MiB L2
-    TASK_NNZ = 512                  # nonzeros per task: few enough tasks that every one is resident at once (one round)
+    SLICE_BYTES = int(_os_env("MI_SPMM_SLICE_KB", "2048")) << 10      # rows of X per column slice (default: half of an XCD's 4 MiB L2)
+    TASK_NNZ = int(_os_env("MI_SPMM_TASK_NNZ", "512"))                # nonzeros per task: few enough tasks that all are resident at once
     GROUP_ROWS = 4                  # kGroupRows of csrc/spmm.hip: rows a lane group (narrow task) / a wide task owns
     WIDE_MIN = 48                   # rows with more nonzeros than this get a wide task (all lane groups stride them)
 
