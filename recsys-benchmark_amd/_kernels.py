@@ -748,9 +748,12 @@ class CsrPlan:
 import os as _os
 
 TILED_SPMM = _os.environ.get("MI_SPMM_TILED", "0") == "1"
-# The slice-phased SpMM (round 4, mi_spmm_sliced): "1" (default) = for operands larger than an XCD's L2 (where the
-# row-per-wave kernel re-fetches X from all over it), "0" = never, "2" = always (tests).
-SLICED_SPMM = int(_os.environ.get("MI_SPMM_SLICED", "1"))
+# The slice-phased SpMM (round 4, mi_spmm_sliced) is parity-green and OPT-IN: "0" (default) = never, "1" = for operands
+# larger than an XCD's L2, "2" = always (tests).  Measured on MI355X at the Yelp2018 shape (profiles/r04_spmm_counters.txt):
+# L2 hit rate 0.38 -> 0.50 and 12 % fewer fabric-side bytes, but 70-82 us per layer against 75 for the row-per-wave kernel
+# whatever the slice size (128 KiB ... 4 MiB) and whether the tasks run in one round or three: the waves do not stay in phase,
+# and what bounds both kernels is the rate at which the cache hierarchy serves random 256-B rows (~8 TB/s), not its hit rate.
+SLICED_SPMM = int(_os.environ.get("MI_SPMM_SLICED", "0"))
 SLICED_MIN_BYTES = 4 << 20
 
 _plans = {}
