@@ -19,7 +19,7 @@ for cfg in c2 c3 c5; do
     timeout -k 10 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc_${cfg}_$tag -- python3 $R/bench.py --config $cfg --steps 5 --warmup 2 --windows 0 --no-cpu-baseline --no-graph --no-gather-leg --no-train-step --no-sweep --no-eager-leg > $OUT/pmc_${cfg}_$tag.json 2> $OUT/pmc_${cfg}_$tag.err || echo "pmc $cfg $tag failed"
   done
 done
-python3 $R/tools/summarise_profiles.py $OUT ${2:-r02} $OUT/summary
+python3 $R/tools/summarise_profiles.py $OUT ${2:-r04} $OUT/summary
 # raw traces are tens of MB: keep only the summaries (gpurun copies back at most 64 MiB)
 rm -rf $OUT/stats_c?/ $OUT/pmc_*/
 echo done
