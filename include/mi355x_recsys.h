@@ -180,10 +180,14 @@ MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const floa
 /* Row form of table 2's gradient (round 4; plain tables only — QRHashingEmbedding, src/models/embeddings/qr_embedding.py:95-109
  * through autograd): g2vals fp32[n, De] receives lookup i's contribution to row rows2[i] = idx[i] / div2 of table 2 (rows2
  * int64[n], -1 for an id out of range) — an uncoalesced COO gradient like nn.Embedding(sparse=True)'s, written with plain
- * coalesced stores: no float atomics into scattered rows, no [n2, De] zero-fill.  gT1 (caller-zeroed, dense) as above. */
+ * coalesced stores: no float atomics into scattered rows, no [n2, De] zero-fill.  gT1 (caller-zeroed, dense) as above.
+ * workspace (nullable): mi_dual_gather_bwd_rows_workspace_elems(De, n1) floats (0: this shape has no use for one) whose first
+ * word is ZERO on entry (the kernel leaves it zero): table 1's per-workgroup sums are then joined by the last workgroup to
+ * arrive, in a fixed order, instead of by same-address float atomics. */
+MI_API int64_t mi_dual_gather_bwd_rows_workspace_elems(int32_t De, int64_t n1);
 MI_API int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float *T1, const float *T2, float *gT1,
                                    float *g2vals, int64_t *rows2, int64_t n, int32_t F, int32_t De, int64_t n1,
-                                   int64_t n2, int64_t mod1, int64_t div2, int32_t op, void *stream);
+                                   int64_t n2, int64_t mod1, int64_t div2, int32_t op, float *workspace, void *stream);
 /* The same, told which FIELDS of idx[B, F] have a handful of values (n = B * F; xform 0 only, else the hint is ignored):
  * small_fields int32[n_small] = their column indices, is_small uint8[F] the same as flags, field_row0 int64[F] = the first
  * row of table 2 a field's ids reach (all device arrays).  A small field's B lookups land on <= 16 rows of table 2 from

@@ -423,9 +423,10 @@ class DualGather(torch.autograd.Function):
             gT1 = torch.zeros_like(T1c)
             g2vals = torch.empty((n, De), dtype=torch.float32, device=dev)
             rows2 = torch.empty((n,), dtype=torch.int64, device=dev)
+            ws = _dual_rows_workspace(dev, De, T1c.shape[0])
             _lib.check(_lib.load().mi_dual_gather_bwd_rows(idxc.data_ptr(), g.data_ptr(), T1c.data_ptr(), T2c.data_ptr(), gT1.data_ptr(),
                                                            g2vals.data_ptr(), rows2.data_ptr(), n, F, De, T1c.shape[0], T2c.shape[0],
-                                                           mod1, div2, op, _lib.stream_ptr(dev)), "mi_dual_gather_bwd_rows")
+                                                           mod1, div2, op, _lib.ptr(ws), _lib.stream_ptr(dev)), "mi_dual_gather_bwd_rows")
             # (ids out of range carry row -1 and a zero value row: clamped to row 0, they add nothing)
             return None, gT1, _coo(rows2.clamp_(min=0), g2vals, ctx.t2_shape), None, None, None, None, None, None, None, None, None, None
         gT1, gT2 = torch.zeros_like(T1c), torch.zeros_like(T2c)
@@ -441,6 +442,19 @@ class DualGather(torch.autograd.Function):
             "mi_dual_gather_bwd_fields",
         )
         return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None, None
+
+
+_DUAL_WS = {}
+
+
+def _dual_rows_workspace(dev, De: int, n1: int):
+    """The persistent join workspace of mi_dual_gather_bwd_rows for this device and shape (its ticket word is zero between
+    launches: allocated zeroed once, the kernel resets it), or None when the shape has no use for one."""
+    key = (str(dev), int(De), int(n1))
+    if key not in _DUAL_WS:
+        ne = int(_lib.load().mi_dual_gather_bwd_rows_workspace_elems(De, n1))
+        _DUAL_WS[key] = torch.zeros((ne,), dtype=torch.float32, device=dev) if ne else None
+    return _DUAL_WS[key]
 
 
 SMALL_FIELD_ROWS = 16     # kSmallRows of csrc/embed.hip

@@ -38,7 +38,8 @@ SIGNATURES = {
                            _i32, _i32, _p, _p],
     "mi_dual_gather_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                            _i64, _i64, _i32, _i32, _p],
-    "mi_dual_gather_bwd_rows": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _p],
+    "mi_dual_gather_bwd_rows_workspace_elems": [_i32, _i64],
+    "mi_dual_gather_bwd_rows": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _p, _p],
     "mi_dual_gather_bwd_fields": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                                   _i64, _i64, _i32, _i32, _p, _i32, _p, _p, _p],
     "mi_xform_gather_fwd": [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i32, _i64, _i32, _p, _p],
@@ -167,7 +168,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"mi_strerror": ctypes.c_char_p, "mi_route_workspace_elems": ctypes.c_int64,
              "mi_bpr_workspace_elems": ctypes.c_int64, "mi_lse_diag_workspace_elems": ctypes.c_int64,
-             "mi_sort_field_rows_workspace_bytes": ctypes.c_int64, "mi_tail_part_elems": ctypes.c_int64}
+             "mi_sort_field_rows_workspace_bytes": ctypes.c_int64, "mi_tail_part_elems": ctypes.c_int64,
+             "mi_dual_gather_bwd_rows_workspace_elems": ctypes.c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()

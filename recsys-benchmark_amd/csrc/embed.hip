@@ -203,11 +203,17 @@ struct SmallFields {
 // (one float4 per row of table 1: a thread's q never changes), joined per workgroup through LDS and added with ONE
 // coalesced atomic instruction per row.  (The element-per-thread kernel below ran this case as a chain of dependent
 // round trips, 5-6 per thread: 24 us at the C3 shape for 20 MB of traffic.)
+// ws (nullable): [1 + gridDim.x * n1 * De] floats, word 0 an arrival ticket that is zero between launches.  With it the
+// workgroups' table-1 sums are joined by the LAST workgroup to arrive instead of by float atomics: 512 workgroups adding to
+// the same 32 addresses serialise at ~26 ns apiece (13 us of this kernel).  Hand-off as MI355X_MICROARCH.md prescribes:
+// device-scope (sc1) stores, every storing wave's s_waitcnt vmcnt(0), workgroup barrier, one agent-scope ticket add; the
+// workgroup whose add came back last reads with device-scope loads behind a barrier that lane joins.  Fixed order of
+// additions: deterministic.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void k_dual_bwd_rows4(const int64_t *__restrict__ idx, DualTables t,
                                                            const float *__restrict__ g, float *__restrict__ gT1,
                                                            float *__restrict__ g2vals, int64_t *__restrict__ rows2,
-                                                           int64_t n, int F, int op) {
+                                                           int64_t n, int F, int op, float *__restrict__ ws) {
   constexpr int De = LPR * 4;
   constexpr int U = 2;
   __shared__ float4 red[4][kBlock];
@@ -270,9 +276,45 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd_rows4(const int64_t *__rest
       const float4 p = red[k][l];
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    float *o = gT1 + (int64_t)k * De + qq * 4;
-    atomicAdd(o + 0, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+    if (ws) {
+      float *o = ws + 1 + ((int64_t)blockIdx.x * t.n1 + k) * De + qq * 4;
+      __hip_atomic_store(o + 0, s.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 1, s.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 2, s.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(o + 3, s.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      float *o = gT1 + (int64_t)k * De + qq * 4;
+      atomicAdd(o + 0, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+    }
   }
+  if (!ws) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  // (several workgroups share a CU here, which none of the guide's measured sc1-only hand-offs covers: the last workgroup also
+  //  takes the agent-scope acquire — one L1 invalidate in one workgroup, ~2 us)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the last workgroup: value j of the n1 * De sums by threads j, j + nv, ... (each a share of the workgroups), joined in LDS
+  const int nv = (int)t.n1 * De;
+  float *redf = reinterpret_cast<float *>(red);
+  const int j = threadIdx.x % nv, part = threadIdx.x / nv, parts = kBlock / nv;
+  float a = 0.f;
+  if (part < parts)
+    for (int b = part; b < (int)gridDim.x; b += parts) a += __hip_atomic_load(ws + 1 + (int64_t)b * nv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();                       // (red is re-used)
+  redf[threadIdx.x] = a;
+  __syncthreads();
+  if ((int)threadIdx.x < nv) {
+    float v = 0.f;
+    for (int p = 0; p < parts; ++p) v += redf[p * nv + threadIdx.x];
+    gT1[threadIdx.x] += v;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned *>(ws), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__ idx, DualTables t,
@@ -710,9 +752,13 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
                                    nullptr, 0, nullptr, nullptr, stream);
 }
 
+int64_t mi_dual_gather_bwd_rows_workspace_elems(int32_t De, int64_t n1) {
+  return (n1 >= 1 && n1 <= 4 && De > 0 && n1 * De <= kBlock) ? 1 + (int64_t)512 * n1 * De : 0;
+}
+
 int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float *T1, const float *T2, float *gT1,
                             float *g2vals, int64_t *rows2, int64_t n, int32_t F, int32_t De, int64_t n1, int64_t n2,
-                            int64_t mod1, int64_t div2, int32_t op, void *stream) {
+                            int64_t mod1, int64_t div2, int32_t op, float *workspace, void *stream) {
   if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
   if (op < OP_MULT || op > OP_CAT) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
@@ -724,7 +770,8 @@ int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float 
     int64_t fg = (n * lpr / 2 + kBlock - 1) / kBlock;          // two lookups per thread and trip
     if (fg > 512) fg = 512;
     if (fg < 1) fg = 1;
-#define CALL(LPR) MI_LAUNCH("dual_gather_bwd_rows", (k_dual_bwd_rows4<LPR>), (int)fg, kBlock, stream, idx, t, g_out, gT1, g2vals, rows2, n, F, op)
+    float *ws = (workspace && n1 * De <= kBlock && kBlock % (n1 * De) == 0) ? workspace : nullptr;
+#define CALL(LPR) MI_LAUNCH("dual_gather_bwd_rows", (k_dual_bwd_rows4<LPR>), (int)fg, kBlock, stream, idx, t, g_out, gT1, g2vals, rows2, n, F, op, ws)
     switch (lpr) {
       case 1: CALL(1); break;
       case 2: CALL(2); break;
