@@ -304,8 +304,22 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd_rows4(const int64_t *__rest
   float *redf = reinterpret_cast<float *>(red);
   const int j = threadIdx.x % nv, part = threadIdx.x / nv, parts = kBlock / nv;
   float a = 0.f;
-  if (part < parts)
-    for (int b = part; b < (int)gridDim.x; b += parts) a += __hip_atomic_load(ws + 1 + (int64_t)b * nv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (part < parts) {
+    // 16 loads in flight per thread (a loop of single device-scope loads ran them one round trip after the other: 64 trips,
+    // ~25 us in the last workgroup alone)
+    constexpr int CH = 16;
+    for (int b0 = part; b0 < (int)gridDim.x; b0 += parts * CH) {
+      float v[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int b = min(b0 + u * parts, (int)gridDim.x - 1);
+        v[u] = __hip_atomic_load(ws + 1 + (int64_t)b * nv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (b0 + u * parts < (int)gridDim.x) a += v[u];
+    }
+  }
   __syncthreads();                       // (red is re-used)
   redf[threadIdx.x] = a;
   __syncthreads();

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The round's tracked evidence, two GPU calls (each under gpurun's 20-minute limit):
-#   tools/final_runs.sh <tag> bench   default bench lines of C2 / C3 / C5 (cpu_baseline, sweep, train_step), --infer, the sharded
-#                                     world-1 line, C4 (1e9 rows), Zipf ids / 39 fields, the -m gpu suite's log
+#   tools/final_runs.sh <tag> bench1  default bench lines of C2 / C3 / C5 (cpu_baseline, sweep, train_step), --infer, the sharded
+#                                     world-1 line
+#   tools/final_runs.sh <tag> bench2  C4 (1e9 rows), Zipf ids / 39 fields, the -m gpu suite's log
 #   tools/final_runs.sh <tag> prof    tools/collect_profiles.sh (kernel statistics + PMC passes), the fused pair's PMC passes,
 #                                     the two SpMM forms' counters
 R=${GRAFT_REPO_ROOT:-.}
@@ -9,13 +10,14 @@ tag=${1:-r04}
 what=${2:-bench}
 O=$R/gpurun_out/$tag
 mkdir -p $O
-if [ $what = bench ]; then
+if [ $what = bench1 ]; then
   for cfg in c2 c3 c5; do
     timeout -k 10 400 python $R/bench.py --config $cfg > $O/${tag}_bench_$cfg.json 2> $O/bench_$cfg.err || { tail -5 $O/bench_$cfg.err; exit 1; }
     echo "$cfg done"
   done
   timeout -k 10 300 python $R/bench.py --infer > $O/${tag}_bench_infer.json 2> $O/bench_infer.err || tail -5 $O/bench_infer.err
   timeout -k 10 300 python $R/bench.py --sharded --no-cpu-baseline > $O/${tag}_bench_sharded_world1.json 2> $O/bench_sharded.err || tail -5 $O/bench_sharded.err
+elif [ $what = bench2 ]; then
   timeout -k 10 400 python $R/bench.py --c4 --no-cpu-baseline > $O/${tag}_bench_c4_1e9rows_world1.json 2> $O/bench_c4.err || tail -5 $O/bench_c4.err
   timeout -k 10 300 python $R/bench.py --ids zipf --no-cpu-baseline --no-train-step > $O/${tag}_bench_c2_zipf.json 2> $O/bench_zipf.err || tail -5 $O/bench_zipf.err
   timeout -k 10 300 python $R/bench.py --fields 39 --no-cpu-baseline --no-train-step > $O/${tag}_bench_c2_fields39.json 2> $O/bench_f39.err || tail -5 $O/bench_f39.err
