@@ -1231,8 +1231,10 @@ int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float
   if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
   const ActDesc x{Z, ldz, mu, sc, be, p, keep};
   if (stats) {
-    // every workgroup joins the statistics itself: one workgroup per CU, its waves walking the rows
-    const int grid = (M + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (M + kWavesPerBlock - 1) / kWavesPerBlock : 256;
+    // every workgroup joins the statistics itself.  Tile statistics (205 KB per join): one workgroup per CU, its waves walking
+    // the rows; shifted sums (a few KB per join): a wave per row like the plain form — the join is cheap enough to repeat
+    const int per_cu = (M + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (M + kWavesPerBlock - 1) / kWavesPerBlock : 256;
+    const int grid = bn.nrep > 0 ? grid_for_waves(M) : per_cu;
     MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<true>), grid, kBlock, stream, x, w, b, add, out, M, N, bn, (int64_t *)nullptr);
   } else {
     MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<false>), grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N, bn, bump);
