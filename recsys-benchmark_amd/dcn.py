@@ -11,7 +11,7 @@ from torch import nn
 from . import _kernels
 from .embeddings import IEmbedding, get_embedding
 from .layer_dcn import DCN_MixHead, DCNHead
-from .mlp import run_tail
+from .mlp import hidden_stack, run_tail
 
 # config keys of a saved checkpoint that are not constructor arguments here (nothing is compiled: the cross network is
 # the kernel path; "name" selected the class)
@@ -19,12 +19,7 @@ _NOT_CTOR_ARGS = ("compile_model", "name")
 
 
 def _hidden_stack(width: int, hidden_sizes: List[int], p_dropout: float):
-    """[Linear, BatchNorm1d, ReLU, Dropout] per hidden size; returns (modules, output width)."""
-    mods: List[nn.Module] = []
-    for h in hidden_sizes:
-        mods.extend((nn.Linear(width, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(p_dropout)))
-        width = h
-    return mods, width
+    return hidden_stack(width, hidden_sizes, p_dropout, True)
 
 
 def _no_atomics_promised(model) -> None:

@@ -19,7 +19,7 @@ from torch import nn
 
 from . import _kernels
 from .embeddings import IEmbedding, VanillaEmbedding, get_embedding
-from .mlp import run_tail
+from .mlp import field_offsets, hidden_stack, run_tail
 
 
 class DeepFM(nn.Module):
@@ -43,37 +43,17 @@ class DeepFM(nn.Module):
             (src/models/deepfm.py:163-184) feeds `fc.weight` to dense Adam.
         """
         super().__init__()
-
-        if not embedding_config:
-            embedding_config = {"name": "vanilla"}
-
-        num_inputs = sum(field_dims)
-
+        # (registration order and the order of the random draws are the reference's — src/models/deepfm.py:26-76 — so that
+        #  a seeded construction gives bit-identical initial weights and state_dict() lists the same keys in the same order)
         if not empty_embedding:
-            self.embedding = get_embedding(
-                embedding_config, field_dims, num_factor, mode=None, field_name="deepfm"
-            )
-
-        self.fc = nn.EmbeddingBag(num_inputs, 1, mode="sum", sparse=fc_sparse)
-        self.linear_layer = nn.Linear(1, 1)
+            self.embedding = get_embedding(embedding_config or {"name": "vanilla"}, field_dims, num_factor, mode=None,
+                                           field_name="deepfm")
+        self.fc = nn.EmbeddingBag(sum(field_dims), 1, mode="sum", sparse=fc_sparse)
+        self.linear_layer = nn.Linear(1, 1)          # (unused by forward there too; kept for the checkpoint keys)
         self._bias = nn.Parameter(torch.zeros(1))
-
-        deep_branch_inp = num_factor * len(field_dims)
-        layers: List[nn.Module] = []
-        for size in hidden_sizes:
-            layers.append(nn.Linear(deep_branch_inp, size))
-            if use_batchnorm:
-                layers.append(nn.BatchNorm1d(size))
-            layers.append(nn.ReLU())
-            layers.append(nn.Dropout(p_dropout))
-            deep_branch_inp = size
-        layers.append(nn.Linear(deep_branch_inp, 1))
-        self._deep_branch = nn.Sequential(*layers)
-
-        field_dims_tensor = torch.tensor(field_dims)
-        field_dims_tensor = torch.cat([torch.tensor([0], dtype=torch.long), field_dims_tensor])
-        offsets = torch.cumsum(field_dims_tensor[:-1], 0).unsqueeze(0)
-        self.register_buffer("offsets", offsets)
+        stack, top = hidden_stack(num_factor * len(field_dims), hidden_sizes, p_dropout, use_batchnorm)
+        self._deep_branch = nn.Sequential(*stack, nn.Linear(top, 1))
+        self.register_buffer("offsets", field_offsets(field_dims))
 
     PACKED_ROW_FLOATS = 32      # one 128-byte line per row: D <= 16 embedding floats, the first-order weight, padding
 

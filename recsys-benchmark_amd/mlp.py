@@ -246,6 +246,25 @@ class _BNReLUDropFn(torch.autograd.Function):
         return (dz, dgamma, dbeta) + (None,) * 14 + (dW1, db1, dadd, None)
 
 
+def hidden_stack(width: int, hidden_sizes, p_dropout: float, use_batchnorm: bool = True):
+    """[Linear, (BatchNorm1d), ReLU, Dropout] per hidden size (src/models/deepfm.py:53-64, src/models/dcn.py:56-64);
+    returns (modules, output width)."""
+    mods: List[nn.Module] = []
+    for h in hidden_sizes:
+        mods.append(nn.Linear(width, h))
+        if use_batchnorm:
+            mods.append(nn.BatchNorm1d(h))
+        mods.extend((nn.ReLU(), nn.Dropout(p_dropout)))
+        width = h
+    return mods, width
+
+
+def field_offsets(field_dims) -> torch.Tensor:
+    """int64[1, F]: the first row of every field in the concatenated table (src/models/deepfm.py:71-76)."""
+    starts = torch.tensor([0] + list(field_dims[:-1]), dtype=torch.long).cumsum(0)
+    return starts.unsqueeze(0)
+
+
 def _groups(seq: nn.Sequential) -> List[List]:
     """Split the Sequential into fusable (Linear, [BN], ReLU, [Dropout]) groups and single modules."""
     mods = list(seq)
