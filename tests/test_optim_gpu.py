@@ -133,10 +133,15 @@ def test_sparse_sgd_and_factory_end_to_end():
 
 
 @pytest.mark.parametrize("optimizer", ["adam", "sgd"])
-def test_packed_tables_train_like_the_two_tensor_layout(optimizer):
+def test_packed_tables_train_like_the_two_tensor_layout(optimizer, monkeypatch):
     """DeepFM.pack_tables() only changes where the two lookup tables live: five training steps with the reference's sparse
     optimizer config leave every parameter BIT-identical to the model that keeps them as two tensors (same kernels, same
-    order of operations; the row-sparse Adam addresses the packed rows through its row stride)."""
+    order of operations; the row-sparse Adam addresses the packed rows through its row stride).  (Run with the tail's
+    column sums joined in a fixed order: the default adds them with float atomics, whose order — not the layout — would
+    make two runs differ in the last bits.)"""
+    from recsys_benchmark_amd import tail as _tail_mod
+
+    monkeypatch.setattr(_tail_mod, "STAT_SUMS", False)
     dims = [20, 30, 5, 400]
     cfg = {"sparse": True, "optimizer": optimizer, "learning_rate": 1e-2, "weight_decay": 1e-6}
     x = torch.stack([torch.randint(0, d, (257,), generator=torch.Generator().manual_seed(3)) for d in dims], 1).to(DEV)
