@@ -789,6 +789,8 @@ typedef struct mi_tail_bn_bwd {
   float *dw, *db;
   int32_t nblk, nwblk;
   float *dbias;           /* affine != 0, nullable: the Linear bias's gradient al * sum dy, [N] */
+  float *db2;             /* nullable: a second destination of db[0] (DeepFM: the scalar `_bias` is added to every logit like
+                             the head's bias, so it has the same gradient — written here instead of by a copy launch) */
   int32_t affine;         /* != 0: fixed statistics (eval-mode BatchNorm) or none: dz = al dy, bz = de = 0 (mi_tail_bn_finalize_bwd_a) */
 } mi_tail_bn_bwd;
 MI_API int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
@@ -907,6 +909,11 @@ MI_API int mi_tail_bn_finalize_bwd_a(const float *part, int32_t nblk, int32_t M,
                                      const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
                                      const float *wpart, int32_t nwblk, float *dw, float *db, int32_t affine,
                                      float *dbias, void *stream);
+/* ... and with a second destination db2[0] (nullable) for the head bias's gradient (see mi_tail_bn_bwd.db2) */
+MI_API int mi_tail_bn_finalize_bwd_b(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma,
+                                     const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
+                                     const float *wpart, int32_t nwblk, float *dw, float *db, int32_t affine,
+                                     float *dbias, float *db2, void *stream);
 MI_API int mi_tail_dgrad_gemm(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
                               const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
                               int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,

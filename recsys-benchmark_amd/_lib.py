@@ -143,6 +143,7 @@ SIGNATURES = {
     "mi_tail_bn_finalize_bwd": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "mi_tail_affine_consts": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mi_tail_bn_finalize_bwd_a": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _p],
+    "mi_tail_bn_finalize_bwd_b": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _p, _p],
     "mi_tail_dgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
                            _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_wgrad_splits": [_i32, _i32, _i32],

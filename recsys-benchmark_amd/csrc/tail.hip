@@ -273,6 +273,7 @@ struct BnBwd {           // device view of mi_tail_bn_bwd
   const float *wpart;    // [nwblk, N + 4] head pieces, nullable
   int nwblk;
   float *dw, *db;
+  float *db2;            // nullable: a second destination of db (DeepFM's scalar bias gets the head bias's gradient: no copy launch)
   // affine != 0: the layer normalised with FIXED statistics (eval-mode BatchNorm: rstd of the running variance) or not at
   // all (no BatchNorm: gamma null, rstd = 1): dz = al dy with al = gamma rstd, no batch terms (bz = de = 0); dbias
   // (nullable) receives the Linear bias's gradient sum_m dz = al * sum_m dy (under a training-mode BatchNorm it is zero)
@@ -336,7 +337,11 @@ __device__ __forceinline__ void bn_merge_bwd_impl(const BnBwd &b, int M, int N, 
         for (int u = 0; u < CH; ++u)
           if (base + u < b.nwblk) sw += v[u];
       }
-      if (n < N) b.dw[n] = sw; else if (b.db) b.db[0] = sw;
+      if (n < N) b.dw[n] = sw;
+      else {
+        if (b.db) b.db[0] = sw;
+        if (b.db2) b.db2[0] = sw;
+      }
     }
   }
 }
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
                                                             float *__restrict__ al, float *__restrict__ bz,
                                                             float *__restrict__ de, const float *__restrict__ wpart,
                                                             int nwblk, float *__restrict__ dw, float *__restrict__ db,
-                                                            int affine, float *__restrict__ dbias) {
+                                                            int affine, float *__restrict__ dbias, float *__restrict__ db2) {
   // 16 columns x 16 row groups per workgroup (see k_bn_finalize_fwd): a group adds its run of partial rows in row order
   // with up to 16 loads in flight (64 partial rows: 4 per thread, one round trip; the head's 256: 16 per thread, one
   // trip), the 16 groups are added in group order through LDS.  Column N of the head's pieces is db.
@@ -776,7 +781,11 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
 #pragma unroll
   for (int q = 0; q < kFinGroups; ++q) { s1 += sh[q][cl][0]; s2 += sh[q][cl][1]; sw += sh[q][cl][2]; }
   if (wpart) {
-    if (n < N) dw[n] = sw; else if (db) db[0] = sw;
+    if (n < N) dw[n] = sw;
+    else {
+      if (db) db[0] = sw;
+      if (db2) db2[0] = sw;
+    }
   }
   if (n >= N) return;
   const float dg = s2 * r;
@@ -1231,10 +1240,9 @@ int mi_tail_head_fwd_m(const float *Z, int32_t ldz, const float *mu, const float
   if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
   const ActDesc x{Z, ldz, mu, sc, be, p, keep};
   if (stats) {
-    // every workgroup joins the statistics itself.  Tile statistics (205 KB per join): one workgroup per CU, its waves walking
-    // the rows; shifted sums (a few KB per join): a wave per row like the plain form — the join is cheap enough to repeat
+    // every workgroup joins the statistics itself: one workgroup per CU, its waves walking the rows
     const int per_cu = (M + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (M + kWavesPerBlock - 1) / kWavesPerBlock : 256;
-    const int grid = bn.nrep > 0 ? grid_for_waves(M) : per_cu;
+    const int grid = per_cu;      // (a wave per row — 1024 workgroups each deriving all constants — measured no better: 0.2428 vs 0.2419 ms)
     MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<true>), grid, kBlock, stream, x, w, b, add, out, M, N, bn, (int64_t *)nullptr);
   } else {
     MI_LAUNCH("tail_head_fwd", (k_tail_head_fwd<false>), grid_for_waves(M), kBlock, stream, x, w, b, add, out, M, N, bn, bump);
@@ -1278,10 +1286,17 @@ int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t 
 int mi_tail_bn_finalize_bwd_a(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma, const float *rstd,
                               float *dgamma, float *dbeta, float *al, float *bz, float *de, const float *wpart,
                               int32_t nwblk, float *dw, float *db, int32_t affine, float *dbias, void *stream) {
+  return mi_tail_bn_finalize_bwd_b(part, nblk, M, N, gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db, affine, dbias,
+                                   nullptr, stream);
+}
+
+int mi_tail_bn_finalize_bwd_b(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma, const float *rstd,
+                              float *dgamma, float *dbeta, float *al, float *bz, float *de, const float *wpart,
+                              int32_t nwblk, float *dw, float *db, int32_t affine, float *dbias, float *db2, void *stream) {
   if (M <= 0 || N <= 0 || nblk <= 0 || !part || !rstd || !al || !bz || !de) return MI_ERR_INVALID_ARG;
   if (wpart && !dw) return MI_ERR_INVALID_ARG;
   MI_LAUNCH("tail_bn_finalize_bwd", k_bn_finalize_bwd, (N + 1 + kFinCols - 1) / kFinCols, kBlock, stream, part, nblk, M, N,
-            gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db, affine, dbias);
+            gamma, rstd, dgamma, dbeta, al, bz, de, wpart, nwblk, dw, db, affine, dbias, db2);
   return launch_status();
 }
 
@@ -1362,7 +1377,7 @@ static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const floa
     if (!sums->part || !aligned16(sums->part) || sums->nblk <= 0 || !sums->rstd || !sums->al || !sums->bz || !sums->de || !mu || !Zl) return MI_ERR_INVALID_ARG;
     if (sums->wpart && (!sums->dw || sums->nwblk <= 0)) return MI_ERR_INVALID_ARG;
     a.bn = BnBwd{sums->part, sums->nblk, sums->gamma, sums->rstd, mu, sums->dgamma, sums->dbeta, sums->al, sums->bz, sums->de,
-                 sums->wpart, sums->nwblk, sums->dw, sums->db, sums->affine, sums->dbias};
+                 sums->wpart, sums->nwblk, sums->dw, sums->db, sums->db2, sums->affine, sums->dbias};
     al = sums->al; bz = sums->bz; de = sums->de;
   }
   if (al && (!Zl || !mu || !bz || !de)) return MI_ERR_INVALID_ARG;

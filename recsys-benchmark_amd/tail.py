@@ -61,7 +61,8 @@ class _BnFwd(ctypes.Structure):          # mi_tail_bn_fwd (include/mi355x_recsys
 
 class _BnBwd(ctypes.Structure):          # mi_tail_bn_bwd
     _fields_ = [(n, ctypes.c_void_p) for n in ("part", "gamma", "rstd", "dgamma", "dbeta", "al", "bz", "de", "wpart", "dw", "db")] + \
-               [("nblk", ctypes.c_int32), ("nwblk", ctypes.c_int32), ("dbias", ctypes.c_void_p), ("affine", ctypes.c_int32)]
+               [("nblk", ctypes.c_int32), ("nwblk", ctypes.c_int32), ("dbias", ctypes.c_void_p), ("db2", ctypes.c_void_p),
+                ("affine", ctypes.c_int32)]
 
 
 class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
@@ -366,6 +367,9 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
                                       wpart.data_ptr(), Rh if stat else 0, M, N, s), "mi_tail_head_bwd_s")
     dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
     db_head = torch.empty((1,), dtype=torch.float32, device=dev)
+    # DeepFM's scalar bias is added to every logit like the head's bias: same gradient, written to a second word by the
+    # same join (a clone would be a copy launch per step)
+    db_twin = torch.empty((1,), dtype=torch.float32, device=dev) if fm is not None else None
     part_rows, wp, nw = nblk, wpart, nblk
     dx = None
     for i in range(k - 1, -1, -1):
@@ -387,12 +391,13 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
             sums = _BnBwd(part.data_ptr(), _lib.ptr(gammas[i]), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                           dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp),
                           dw_head.data_ptr() if wp is not None else None, db_head.data_ptr() if wp is not None else None,
-                          part_rows, nw, _lib.ptr(dbias), int(L.fixed))
+                          part_rows, nw, _lib.ptr(dbias), _lib.ptr(db_twin) if wp is not None else None, int(L.fixed))
         else:
-            _lib.check(lib.mi_tail_bn_finalize_bwd_a(
+            _lib.check(lib.mi_tail_bn_finalize_bwd_b(
                 part.data_ptr(), part_rows, M, N, _lib.ptr(gammas[i]), c[3].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                 dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(), _lib.ptr(wp), nw, dw_head.data_ptr() if wp is not None else None,
-                db_head.data_ptr() if wp is not None else None, int(L.fixed), _lib.ptr(dbias), s), "mi_tail_bn_finalize_bwd_a")
+                db_head.data_ptr() if wp is not None else None, int(L.fixed), _lib.ptr(dbias),
+                _lib.ptr(db_twin) if wp is not None else None, s), "mi_tail_bn_finalize_bwd_b")
         wp = None
         if L.bn is not None:
             grads[4 * i + 2], grads[4 * i + 3] = dgb[0], dgb[1]
@@ -451,7 +456,7 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
     grads[4 * k] = dw_head
     grads[4 * k + 1] = db_head if st.has_head_bias else None
     dadd = gvec.view(st.add_shape) if (st.add_shape is not None and need_add) else None
-    return dx, dadd, grads, db_head
+    return dx, dadd, grads, (db_twin if db_twin is not None else db_head)
 
 
 class FusedTailFn(torch.autograd.Function):
@@ -574,7 +579,7 @@ class DeepFMFusedFn(torch.autograd.Function):
             gw1 = (_kernels._coo(rows, g1vals.view((-1,) + (1,) * (len(w1shape) - 1)), w1shape) if sparse_w1
                    else _kernels._scatter_rows(rows, g1vals, N, 1, stream).view(w1shape))
         # the scalar bias is added to every logit, like the head's bias: the same gradient, sum_m g[m]
-        gb = db_head.clone() if (has_bias and need_b) else None
+        gb = db_head if (has_bias and need_b) else None            # (the twin word the join wrote: no copy)
         return (None, None, None, None, None, gW, gw1, gb, None, None, *grads)
 
 

@@ -3,6 +3,7 @@
 #   tools/final_runs.sh <tag> bench1  default bench lines of C2 / C3 / C5 (cpu_baseline, sweep, train_step), --infer, the sharded
 #                                     world-1 line
 #   tools/final_runs.sh <tag> bench2  C4 (1e9 rows), Zipf ids / 39 fields, the -m gpu suite's log
+#   tools/final_runs.sh <tag> pair    only the fused pair's PMC passes
 #   tools/final_runs.sh <tag> prof    tools/collect_profiles.sh (kernel statistics + PMC passes), the fused pair's PMC passes,
 #                                     the two SpMM forms' counters
 R=${GRAFT_REPO_ROOT:-.}
@@ -23,6 +24,15 @@ elif [ $what = bench2 ]; then
   timeout -k 10 300 python $R/bench.py --fields 39 --no-cpu-baseline --no-train-step > $O/${tag}_bench_c2_fields39.json 2> $O/bench_f39.err || tail -5 $O/bench_f39.err
   echo "benches done"
   timeout -k 10 500 python -m pytest $R/tests -q -m gpu > $O/${tag}_pytest_gpu.log 2>&1; tail -3 $O/${tag}_pytest_gpu.log
+elif [ $what = pair ]; then
+  cd /tmp && export TMPDIR=/tmp
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    t=$(echo $pmc | tr ' ' '+')
+    timeout -k 10 200 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $O/pair/pass_$t -- python3 $R/tools/pmc_pair.py > /dev/null 2> $O/pair_$t.err || echo "pair pass $t failed"
+  done
+  python3 $R/tools/pmc_pair_summarise.py $O/pair > $O/${tag}_pair_traffic.txt 2>&1; cat $O/${tag}_pair_traffic.txt
+  find $O/pair -name "*_counter_collection.csv" | head -3 | while read f; do head -4 $f | cut -c1-400; done > $O/pair_names.txt
+  rm -rf $O/pair
 else
   bash $R/tools/collect_profiles.sh $tag/prof $tag > $O/collect.log 2>&1
   tail -2 $O/collect.log

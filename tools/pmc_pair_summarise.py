@@ -6,14 +6,16 @@ import collections
 import csv
 import glob
 import os
+import re
 import sys
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "pass_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = ("gather_fm_fwd" if "k_gather_fm_fwd" in n else "dgrad_fm" if ("k_tail_dgrad" in n and n.rstrip(">)( ").endswith("true")) else
-               "dgrad_plain" if "k_tail_dgrad" in n else None)
+        m = re.search(r"k_tail_dgrad<([^>]*)>", n)          # template arguments <DZ, MID, MERGE, FM>: the last one marks the epilogue
+        key = ("gather_fm_fwd" if "k_gather_fm_fwd" in n else None if not m else
+               "dgrad_fm" if m.group(1).replace(" ", "").split(",")[-1] in ("true", "1") else "dgrad_plain")
         if key:
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
