@@ -980,6 +980,8 @@ def main():
                     "nothing at those places (invalidates the measurement as a benchmark line)")
     ap.add_argument("--no-sweep", action="store_true", help="skip roofline.batch_sweep")
     ap.add_argument("--no-train-step", action="store_true", help="skip the train_step object (fwd+bwd+optimizers as one graph)")
+    ap.add_argument("--no-head-loss", action="store_true", help="model(x) without the step's labels: head, criterion and head backward as "
+                    "three launches (default: model(x, labels=y), one launch)")
     ap.add_argument("--prefetch", action="store_true", help="every step touches the NEXT batch's table rows on a side stream under its "
                     "weight-gradient launch (DeepFM.prefetch_next): the next forward gathers from the Infinity Cache")
     ap.add_argument("--infer", action="store_true", help="the reference's own timing harnesses (scripts/deepfm/infer_deepfm.py, "
@@ -1101,6 +1103,13 @@ def main():
 
     lossf = BCEWithLogitsLoss()      # same criterion as the reference trainer, one launch each way
     state = {"i": 0}
+    # the labels handed to the forward (DeepFM.forward(x, labels=y), what the package's trainer does): the head launch also
+    # evaluates the criterion and the head's backward sums, lossf() picks them up (--no-head-loss: the reference's two calls
+    # as they stand — head, criterion and head backward are three launches)
+    labels_in_forward = not args.no_head_loss and not sharded
+
+    def fwd(xb, yb):
+        return model(xb, labels=yb) if labels_in_forward else model(xb)
 
     def next_batch():
         cur.copy_(ring[state["i"] % len(ring)])
@@ -1109,7 +1118,7 @@ def main():
     def eager_step():
         next_batch()
         model.zero_grad(set_to_none=True)
-        loss = lossf(model(x), y)
+        loss = lossf(fwd(x, y), y)
         loss.backward()
         if sharded:
             model.allreduce_dense_grads()
@@ -1197,7 +1206,7 @@ def main():
                     from recsys_benchmark_amd import _lib as _pl
                     _pl.load().mi_prof_empty_launch(1, 256, _pl.stream_ptr(dev))
                     _pl.load().mi_prof_empty_launch(2, 256, _pl.stream_ptr(dev))
-                lossf(model(xb), yb).backward(one)
+                lossf(fwd(xb, yb), yb).backward(one)
                 if args.probe_empties:
                     _pl.load().mi_prof_empty_launch(3, 256, _pl.stream_ptr(dev))
             pool = g.pool()
@@ -1371,7 +1380,8 @@ def main():
             "config": {"workload": f"{'C4' if args.c4 else 'C2'} DeepFM Criteo-{F}field full embedding: F={F}, D={D}, N={sum(dims)} rows, "
                                    f"MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(ring)} distinct {args.ids}-id batches "
                                    f"rotated (fresh ids every step), "
-                                   f"{'row-form (COO)' if sparse else 'dense'} table grads, tables stored as "
+                                   f"{'row-form (COO)' if sparse else 'dense'} table grads, "
+                                   f"{'criterion evaluated in the head launch (model(x, labels=y)), ' if labels_in_forward else ''}tables stored as "
                                    f"{'one packed [N,32] buffer (row + first-order weight per 128-B line)' if (args.layout == 'packed128' and not sharded) else 'row-sharded packed rows' if sharded else 'the two reference tensors'}",
                        "global_batch": B * world, "parallelism": parallelism},
             "ms_per_step_windows": ({"min": round(window_ms[0], 4), "median": round(window_ms[len(window_ms) // 2], 4),

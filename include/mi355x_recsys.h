@@ -874,6 +874,15 @@ MI_API int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, co
                                      const float *mean_offset, float *running_mean, float *running_var, float momentum,
                                      float eps, int64_t *num_batches_tracked, int64_t *seed_bump, float *mu, float *sc,
                                      float *be, float *rstd, const mi_tail_mask_ride *ride, void *stream);
+/* The gather + FM forward (mi_gather_fm_fwd_sum) carrying the same job in extra workgroups at the end of its grid: in
+ * DeepFM's fused step (src/models/deepfm.py:79-105) it is the first kernel of the step — every reader of the keep bits
+ * and every adder into zero_buf is launched later — so the tail needs no mask launch and no finalize launch to carry one.
+ * ride == NULL: mi_gather_fm_fwd_sum.  A gather form without the extra workgroups (D % 4, F > 64, unaligned) runs the job
+ * as a launch of its own first.  The seed must be advanced by a LATER kernel. */
+MI_API int mi_gather_fm_fwd_ride(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                                 int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,
+                                 float *sum_out, int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err,
+                                 const mi_tail_mask_ride *ride, void *stream);
 MI_API int mi_tail_head_fwd(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                             const uint8_t *keep, const float *w, const float *b, const float *add, float *out,
                             int32_t M, int32_t N, void *stream);
@@ -887,6 +896,19 @@ MI_API int mi_tail_head_bwd(const float *Z, int32_t ldz, const float *mu, const 
 MI_API int mi_tail_head_bwd_s(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                               const uint8_t *keep, const float *g, const float *w, float *DY, float *part, float *wpart,
                               int32_t sum_reps, int32_t M, int32_t N, void *stream);
+/* Head + criterion + head backward in ONE launch, for a step whose labels are known at forward time and whose criterion is
+ * BCE-with-logits, reduction "mean" (the reference trainer's: src/trainer/deepfm.py:32,51 around the head of
+ * src/models/deepfm.py:100-105).  Per row m: out[m] = the logit (mi_tail_head_fwd_m), its loss term, g[m] =
+ * (sigmoid(out[m]) - y[m]) / M (mi_bce_logits_fwd's dx_unit), DY / part / wpart as mi_tail_head_bwd_s(g) writes them
+ * (sum_reps > 0 rows, zeroed by the caller).  loss_ws: fp32[mi_tail_head_bce_ws_elems(sum_reps)], ZEROED by the caller;
+ * loss_ws[0] is the loss afterwards (the rest are per-replica partial sums and arrival counts).  The sums are those of an
+ * upstream gradient of exactly 1: a backward that arrives with another gradient calls mi_tail_head_bwd_s (after zeroing
+ * part / wpart again).  N <= 512.  stats as in mi_tail_head_fwd_m (NULL: mu / sc / be are read). */
+MI_API int32_t mi_tail_head_bce_ws_elems(int32_t sum_reps);
+MI_API int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                            const uint8_t *keep, const float *w, const float *b, const float *add, const float *y,
+                            float *out, float *g, float *DY, float *part, float *wpart, int32_t sum_reps, float *loss_ws,
+                            int32_t M, int32_t N, const mi_tail_bn_fwd *stats, void *stream);
 MI_API int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma,
                                    const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
                                    const float *wpart, int32_t nwblk, float *dw, float *db, void *stream);

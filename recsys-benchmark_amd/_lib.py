@@ -28,6 +28,7 @@ SIGNATURES = {
     "mi_gather_fm_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_fwd_ld": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
     "mi_gather_fm_fwd_sum": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p],
+    "mi_gather_fm_fwd_ride": [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _p, _p],
     "mi_prefetch_rows": [_p, _p, _p, _i64, _p, _i64, _i64, _i32, _i64, _p],
     "mi_gather_fm_bwd_rows": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
     "mi_gather_fm_bwd_dense": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p],
@@ -140,6 +141,8 @@ SIGNATURES = {
     "mi_tail_head_blocks": [_i32],
     "mi_tail_head_bwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_tail_head_bwd_s": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
+    "mi_tail_head_bce_ws_elems": [_i32],
+    "mi_tail_head_bce": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
     "mi_tail_bn_finalize_bwd": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "mi_tail_affine_consts": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mi_tail_bn_finalize_bwd_a": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _p],

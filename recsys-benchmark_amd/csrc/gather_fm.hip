@@ -18,6 +18,7 @@
 // byte is used once); the dense backward stages a 1 KiB tile per wave in LDS to
 // turn 16-B-strided float4 fragments into 256-B contiguous atomic instructions.
 #include "common.hpp"
+#include "tail_masks.hpp"
 
 namespace {
 using namespace mi;
@@ -33,18 +34,19 @@ using namespace mi;
 // line instead of two unrelated 64-B sectors (DeepFM.pack_tables()); (D + 4, D + 4) for the packed rows a sharded
 // lookup received (route.hip).
 // (SHFL is ignored by the generic NIT = 0 form.)
+// (blk of nblk: the workgroups of the launch that gather — a launch may carry others, k_gather_fm_fwd_ride)
 template <int LPR, int NIT, bool SHFL>
-__global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
+__device__ __forceinline__ void gather_fm_fwd_blocks(
     const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
     const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
-    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out) {
+    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out, int blk, int nblk) {
   constexpr int RS = kWave / LPR;
   constexpr int D = LPR * 4;
   const int lane = threadIdx.x & 63;
   const int q = lane % LPR, r = lane / LPR;
-  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t wave0 = (int64_t)blk * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)nblk * kWavesPerBlock;
   const float bv = bias ? bias[0] : 0.f;
   int bad = 0;
   int64_t myoff = 0;
@@ -117,6 +119,37 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
     if (lane == 0) yfm[b] = t + bv;
   }
   if (bad && err) atomicOr(err, MI_IDX_OUT_OF_RANGE);
+}
+template <int LPR, int NIT, bool SHFL>
+__global__ __launch_bounds__(kBlock) void k_gather_fm_fwd(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+    const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
+    float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
+    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out) {
+  gather_fm_fwd_blocks<LPR, NIT, SHFL>(idx, offsets, W, w1, bias, emb, yfm, rows_out, B, F, N, ldw, ldw1, err, sum_out,
+                                       (int)blockIdx.x, (int)gridDim.x);
+}
+// The same launch carrying the MLP tail's dropout keep bits and the zero fill of its accumulation buffer in workgroups
+// past the first `ngather` (tail_masks.hpp): in DeepFM's fused step this kernel is the first of the step, every reader of
+// the bits and every adder into the buffer comes later, and the mask work (~1 us spread over the chip, all ALU) runs
+// beside a gather that waits on memory — one launch less per step.  The extra workgroups sit at the END of the grid: the
+// gather's are dispatched first.
+template <int LPR, int NIT>
+__global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_ride(
+    const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
+    const float *__restrict__ W, const float *__restrict__ w1, const float *__restrict__ bias,
+    float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
+    int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out, int ngather, MaskRide ride) {
+  if ((int)blockIdx.x >= ngather) {
+    mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, (int)blockIdx.x - ngather, (int)gridDim.x - ngather);
+    return;
+  }
+  gather_fm_fwd_blocks<LPR, NIT, true>(idx, offsets, W, w1, bias, emb, yfm, rows_out, B, F, N, ldw, ldw1, err, sum_out,
+                                       (int)blockIdx.x, ngather);
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_job(MaskRide ride) {
+  mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Any D (scalar accesses): wave per sample, lanes stride over d.
@@ -614,6 +647,44 @@ int mi_gather_fm_fwd_sum(const int64_t *idx, const int64_t *offsets, const float
     MI_LAUNCH("gather_fm_fwd", k_gather_fm_fwd_anyD, grid, kBlock, stream, idx, offsets, W, w1,
               bias, emb_out, yfm_out, rows_out, B, F, D, N, err, sum_out);
   }
+  return launch_status();
+}
+
+int mi_gather_fm_fwd_ride(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
+                          int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out, float *sum_out,
+                          int64_t B, int32_t F, int32_t D, int64_t N, int32_t *err, const mi_tail_mask_ride *ride,
+                          void *stream) {
+  if (!ride) return mi_gather_fm_fwd_sum(idx, offsets, W, ldw, w1, ldw1, bias, emb_out, yfm_out, rows_out, sum_out, B, F, D, N, err, stream);
+  if (B < 0 || F < 0 || D <= 0 || N < 0 || ldw < D || ldw1 < 1) return MI_ERR_INVALID_ARG;
+  MaskRide r;
+  int64_t extra = 0;
+  const int rc = mask_job(ride->seed, ride->nlayers, ride->salts, ride->ps, ride->lds, ride->bits, ride->M, ride->zero_buf,
+                          ride->zero_floats, r.j, &extra);
+  if (rc != MI_OK) return rc;
+  r.seed = ride->seed;
+  r.zero4 = reinterpret_cast<float4 *>(ride->zero_buf);
+  r.nzero4 = ride->zero_floats / 4;
+  const int lpr = D / 4, nit = vec_ok(D) ? nit_for(F, lpr) : 0;
+  const bool fits = B > 0 && idx && offsets && W && w1 && emb_out && yfm_out && vec_ok(D) && aligned16(W) && (ldw & 3) == 0 &&
+                    aligned16(emb_out) && nit > 0 && F <= kWave;
+  if (extra == 0 || !fits) {      // nothing to carry, or a gather form without the extra workgroups: two launches
+    if (extra > 0) {
+      MI_LAUNCH("tail_dropout_masks", k_mask_job, (int)extra, kBlock, stream, r);
+      const int st = launch_status();
+      if (st != MI_OK) return st;
+    }
+    return mi_gather_fm_fwd_sum(idx, offsets, W, ldw, w1, ldw1, bias, emb_out, yfm_out, rows_out, sum_out, B, F, D, N, err, stream);
+  }
+  const int ngather = grid_for_waves(B);
+  // (mask workgroups: a quarter of what the job would take alone — each walks four strides — so the launch stays one wave
+  //  of workgroups over the chip's slots)
+  int nmask = (int)((extra + 3) / 4);
+  if (nmask > 1024) nmask = 1024;
+#define CALL(LPR, NIT)                                                                                         \
+  MI_LAUNCH("gather_fm_fwd_ride", (k_gather_fm_fwd_ride<LPR, NIT>), ngather + nmask, kBlock, stream, idx, offsets, \
+            W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err, sum_out, ngather, r)
+  MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
+#undef CALL
   return launch_status();
 }
 

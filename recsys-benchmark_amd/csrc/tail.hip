@@ -19,14 +19,12 @@
 
 #include "common.hpp"
 #include "tail_gemm.hpp"
+#include "tail_masks.hpp"
 
 namespace {
 using namespace mi;
 using namespace tg;
 
-__device__ __forceinline__ uint64_t layer_seed(const int64_t *seed, int64_t salt) {
-  return (seed ? (uint64_t)seed[0] : 0ull) + 0xD1B54A32D192ED03ull * (uint64_t)salt;
-}
 __device__ __forceinline__ Drop make_drop(const uint8_t *bits, float p, int ld) {
   Drop d;
   d.bits = p > 0.f ? bits : nullptr;
@@ -35,35 +33,6 @@ __device__ __forceinline__ Drop make_drop(const uint8_t *bits, float p, int ld) 
   return d;
 }
 
-// keep bits of up to 8 layers in one launch: byte b of layer l covers elements 8b .. 8b+7 of its [M, ld] activation
-struct MaskJob {
-  uint8_t *bits[8];
-  int64_t salt[8];
-  int64_t nbytes[8];       // M * ld / 8
-  uint32_t thr[8];
-  int n;
-};
-// workgroup `blk` of `nblk` that share the job
-__device__ __forceinline__ void mask_blocks(const MaskJob &j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4,
-                                            int blk, int nblk) {
-  // rides along: the zero fill of the backward pass's accumulation buffer (split-K weight gradients), one launch less
-  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < nzero4; i += (int64_t)nblk * kBlock)
-    zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int l = 0; l < j.n; ++l) {
-    const uint64_t sd = layer_seed(seed, j.salt[l]);
-    const uint32_t thr = j.thr[l];
-    for (int64_t b = (int64_t)blk * kBlock + threadIdx.x; b < j.nbytes[l]; b += (int64_t)nblk * kBlock) {
-      uint32_t byte = 0;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const uint64_t h = mix64(sd, (uint64_t)(2 * b + half));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) byte |= (((uint32_t)(h >> (16 * e)) & 0xFFFFu) >= thr ? 1u : 0u) << (4 * half + e);
-      }
-      j.bits[l][b] = (uint8_t)byte;
-    }
-  }
-}
 __global__ __launch_bounds__(kBlock) void k_tail_dropmask(MaskJob j, const int64_t *seed, float4 *__restrict__ zero4, int64_t nzero4) {
   mask_blocks(j, seed, zero4, nzero4, blockIdx.x, gridDim.x);
 }
@@ -483,12 +452,6 @@ constexpr int kFinCols = 16, kFinGroups = kBlock / kFinCols;      // a workgroup
 // of its own (a kernel boundary inside a step costs ~2.5 us, the mask work itself under 1 us spread over the chip; this
 // kernel is the first of the step whose successors need the bits).  The seed the bits are drawn from must not be bumped
 // by this launch (seed_bump rides with a later one).
-struct MaskRide {
-  MaskJob j;
-  const int64_t *seed;
-  float4 *zero4;
-  int64_t nzero4;
-};
 template <bool RIDE>
 __global__ __launch_bounds__(kBlock) void k_bn_finalize_fwd(const float *__restrict__ part, int M, int N,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -730,6 +693,161 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
     st4(wpart + (int64_t)blockIdx.x * (N + 4) + c, s_ga);
   }
   if (threadIdx.x == 0) wpart[(int64_t)blockIdx.x * (N + 4) + N] = s_g;
+}
+
+// Head + criterion + the head's backward in ONE launch (round 4): when the labels are known at forward time and the
+// criterion is BCE-with-logits (mean) — the reference trainer's (src/trainer/deepfm.py:32,51) — a row's logit, its loss
+// term, g[m] = (sigmoid(logit) - y) / M and its contributions to every column sum of k_tail_head_bwd depend on that row
+// alone (given the layer's constants), so one pass over Z does what k_tail_head_fwd, k_bce_logits_fwd and
+// k_tail_head_bwd do in three launches with two passes.  Wave per row (up to 4 rows in flight), lane owns columns
+// 4 lane .. + 3 and 256 + 4 lane .. + 3 (N <= 512); column sums are kept per lane across the wave's rows, met in LDS,
+// and added into row (block % reps) of part / wpart with linear float atomics exactly like k_tail_head_bwd's summed form.
+//   loss_ws: [0] the loss (mean), [4 .. 4 + reps) per-replica partial sums, [4 + reps .. 4 + 2 reps) arrival counts
+//   (uint32) — all zero at launch.  The workgroups of a replica add their partial, the last of them (ticket) moves the
+//   replica's sum into [0]: <= gridDim / reps adders per address at each level, no single word that every workgroup hits.
+// The sums assume an upstream gradient of exactly 1 (the criterion is the last op of a step); tail.py falls back to
+// k_tail_head_bwd when the backward arrives with anything else.
+constexpr int kHeadLossCols = 512;
+constexpr int kHeadLossRed = 3 * kHeadLossCols + 4;
+template <bool MERGE>
+__global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float *__restrict__ w, const float *__restrict__ b,
+                                                          const float *__restrict__ add, const float *__restrict__ y,
+                                                          float *__restrict__ out, float *__restrict__ gout,
+                                                          float *__restrict__ DY, float *__restrict__ part,
+                                                          float *__restrict__ wpart, float *__restrict__ loss_ws, int M,
+                                                          int N, BnFwd bn, int reps, int64_t *bump) {
+  __shared__ __attribute__((aligned(16))) float cst[MERGE ? 3 * kCstPitch : 4];
+  __shared__ __attribute__((aligned(16))) float red[kWavesPerBlock][kHeadLossRed];
+  if (bump && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave0 = blockIdx.x * kWavesPerBlock + wv, nw = gridDim.x * kWavesPerBlock;
+  const Drop drop = make_drop(x.keep, x.p, x.ld);
+  const float bv = b ? b[0] : 0.f;
+  const float inv_m = 1.f / (float)M;
+  const int c0 = lane * 4, c1 = lane * 4 + 256;
+  const bool v0 = c0 < N, v1 = c1 < N;
+  const float4 w0 = v0 ? ld4(w + c0) : zero4(), w1 = v1 ? ld4(w + c1) : zero4();
+  float4 mu0 = zero4(), sc0 = zero4(), be0 = zero4(), mu1 = zero4(), sc1 = zero4(), be1 = zero4();
+  float4 dy0 = zero4(), dz0 = zero4(), ga0 = zero4(), dy1 = zero4(), dz1 = zero4(), ga1 = zero4();
+  float s_g = 0.f, s_loss = 0.f;
+  bool first = true;
+  for (int m0 = wave0; m0 < M || first; m0 += 4 * nw) {
+    float4 z0[4], z1[4];
+    uint32_t k0[4], k1[4];
+    float av[4], yv[4];
+    if (m0 < M) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = min(m0 + u * nw, M - 1);
+        if (v0) { z0[u] = ld4(x.Z + (int64_t)m * x.ld + c0); k0[u] = drop.fetch(m, c0); }
+        if (v1) { z1[u] = ld4(x.Z + (int64_t)m * x.ld + c1); k1[u] = drop.fetch(m, c1); }
+        av[u] = add ? add[m] : 0.f;
+        yv[u] = y[m];
+      }
+    }
+    if (first) {      // the constants are not needed to ISSUE the row loads: their join runs under the rows' round trip
+      if constexpr (MERGE) {
+        bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
+        __syncthreads();
+        const lds_cfp c = as_lds(cst);
+        if (v0) { mu0 = vld4(c + c0); sc0 = vld4(c + kCstPitch + c0); be0 = vld4(c + 2 * kCstPitch + c0); }
+        if (v1) { mu1 = vld4(c + c1); sc1 = vld4(c + kCstPitch + c1); be1 = vld4(c + 2 * kCstPitch + c1); }
+      } else {
+        if (v0) { mu0 = ld4(x.mu + c0); sc0 = ld4(x.sc + c0); be0 = ld4(x.be + c0); }
+        if (v1) { mu1 = ld4(x.mu + c1); sc1 = ld4(x.sc + c1); be1 = ld4(x.be + c1); }
+      }
+    }
+    first = false;
+    if (m0 >= M) break;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * nw;
+      if (m >= M) break;
+      float4 zc0 = zero4(), zc1 = zero4(), pre0 = zero4(), pre1 = zero4(), kk0 = zero4(), kk1 = zero4();
+      float s = 0.f;
+      if (v0) {
+        kk0 = drop.scale4(k0[u], c0);
+        zc0 = make_float4(z0[u].x - mu0.x, z0[u].y - mu0.y, z0[u].z - mu0.z, z0[u].w - mu0.w);
+        pre0 = make_float4(fmaf(zc0.x, sc0.x, be0.x), fmaf(zc0.y, sc0.y, be0.y), fmaf(zc0.z, sc0.z, be0.z), fmaf(zc0.w, sc0.w, be0.w));
+        s += fmaxf(pre0.x, 0.f) * kk0.x * w0.x + fmaxf(pre0.y, 0.f) * kk0.y * w0.y + fmaxf(pre0.z, 0.f) * kk0.z * w0.z +
+             fmaxf(pre0.w, 0.f) * kk0.w * w0.w;
+      }
+      if (v1) {
+        kk1 = drop.scale4(k1[u], c1);
+        zc1 = make_float4(z1[u].x - mu1.x, z1[u].y - mu1.y, z1[u].z - mu1.z, z1[u].w - mu1.w);
+        pre1 = make_float4(fmaf(zc1.x, sc1.x, be1.x), fmaf(zc1.y, sc1.y, be1.y), fmaf(zc1.z, sc1.z, be1.z), fmaf(zc1.w, sc1.w, be1.w));
+        s += fmaxf(pre1.x, 0.f) * kk1.x * w1.x + fmaxf(pre1.y, 0.f) * kk1.y * w1.y + fmaxf(pre1.z, 0.f) * kk1.z * w1.z +
+             fmaxf(pre1.w, 0.f) * kk1.w * w1.w;
+      }
+      s = wave_sum(s);
+      const float xl = s + bv + av[u];
+      // the criterion's own arithmetic (k_bce_logits_fwd / _bwd, cross.hip)
+      const float gm = inv_m * (1.f / (1.f + expf(-xl)) - yv[u]);
+      s_loss += fmaxf(xl, 0.f) - xl * yv[u] + log1pf(expf(-fabsf(xl)));
+      s_g += gm;
+      if (lane == 0) { out[m] = xl; gout[m] = gm; }
+      if (v0) {
+        float4 d;
+        d.x = pre0.x > 0.f ? gm * w0.x * kk0.x : 0.f;
+        d.y = pre0.y > 0.f ? gm * w0.y * kk0.y : 0.f;
+        d.z = pre0.z > 0.f ? gm * w0.z * kk0.z : 0.f;
+        d.w = pre0.w > 0.f ? gm * w0.w * kk0.w : 0.f;
+        st4(DY + (int64_t)m * x.ld + c0, d);
+        dy0.x += d.x; dy0.y += d.y; dy0.z += d.z; dy0.w += d.w;
+        dz0.x += d.x * zc0.x; dz0.y += d.y * zc0.y; dz0.z += d.z * zc0.z; dz0.w += d.w * zc0.w;
+        ga0.x += gm * fmaxf(pre0.x, 0.f) * kk0.x; ga0.y += gm * fmaxf(pre0.y, 0.f) * kk0.y;
+        ga0.z += gm * fmaxf(pre0.z, 0.f) * kk0.z; ga0.w += gm * fmaxf(pre0.w, 0.f) * kk0.w;
+      }
+      if (v1) {
+        float4 d;
+        d.x = pre1.x > 0.f ? gm * w1.x * kk1.x : 0.f;
+        d.y = pre1.y > 0.f ? gm * w1.y * kk1.y : 0.f;
+        d.z = pre1.z > 0.f ? gm * w1.z * kk1.z : 0.f;
+        d.w = pre1.w > 0.f ? gm * w1.w * kk1.w : 0.f;
+        st4(DY + (int64_t)m * x.ld + c1, d);
+        dy1.x += d.x; dy1.y += d.y; dy1.z += d.z; dy1.w += d.w;
+        dz1.x += d.x * zc1.x; dz1.y += d.y * zc1.y; dz1.z += d.z * zc1.z; dz1.w += d.w * zc1.w;
+        ga1.x += gm * fmaxf(pre1.x, 0.f) * kk1.x; ga1.y += gm * fmaxf(pre1.y, 0.f) * kk1.y;
+        ga1.z += gm * fmaxf(pre1.z, 0.f) * kk1.z; ga1.w += gm * fmaxf(pre1.w, 0.f) * kk1.w;
+      }
+    }
+  }
+  // the four waves' sums meet in LDS: [0, 2 * 512) (sum dy, sum dy (z - mu)) interleaved per column, [1024, 1536) the
+  // head's dw pieces, [1536] sum g, [1537] the loss terms
+  float *rp = red[wv];
+  if (v0) {
+    st4(rp + 2 * c0, make_float4(dy0.x, dz0.x, dy0.y, dz0.y));
+    st4(rp + 2 * c0 + 4, make_float4(dy0.z, dz0.z, dy0.w, dz0.w));
+    st4(rp + 2 * kHeadLossCols + c0, ga0);
+  }
+  if (v1) {
+    st4(rp + 2 * c1, make_float4(dy1.x, dz1.x, dy1.y, dz1.y));
+    st4(rp + 2 * c1 + 4, make_float4(dy1.z, dz1.z, dy1.w, dz1.w));
+    st4(rp + 2 * kHeadLossCols + c1, ga1);
+  }
+  if (lane == 0) { rp[3 * kHeadLossCols] = s_g; rp[3 * kHeadLossCols + 1] = s_loss; }
+  __syncthreads();
+  const int rr = blockIdx.x % reps;
+  float *o = part + (int64_t)rr * N * 2;
+  for (int i = threadIdx.x; i < 2 * N; i += kBlock) atomicAdd(o + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+  float *q = wpart + (int64_t)rr * (N + 4);
+  for (int i = threadIdx.x; i <= N; i += kBlock) {
+    const int j = i < N ? 2 * kHeadLossCols + i : 3 * kHeadLossCols;
+    atomicAdd(q + i, (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
+  }
+  if (threadIdx.x == 0) {
+    const int j = 3 * kHeadLossCols + 1;
+    const float lp = ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j])) * inv_m;
+    atomicAdd(loss_ws + 4 + rr, lp);
+    __threadfence();
+    const uint32_t mine = ((uint32_t)gridDim.x - (uint32_t)rr + (uint32_t)reps - 1u) / (uint32_t)reps;   // workgroups of this replica
+    const uint32_t old = atomicAdd(reinterpret_cast<uint32_t *>(loss_ws + 4 + reps) + rr, 1u);
+    if (old == mine - 1u) {
+      __threadfence();
+      const float v = __hip_atomic_load(loss_ws + 4 + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(loss_ws, v);
+    }
+  }
 }
 
 // Join the backward column sums (block order), write dgamma / dbeta and the three constants of LoadDz.
@@ -1137,34 +1255,6 @@ int mi_tail_fwd_gemm(const float *X, int32_t ldx, const float *x_mu, const float
   return mi_tail_fwd_gemm_m(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, nullptr, stream);
 }
 
-// builds the device job; *grid = workgroups that suit it (0: nothing to do)
-static int mask_job(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
-                    uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, MaskJob &j, int64_t *grid_out) {
-  *grid_out = 0;
-  j.n = 0;
-  if (nlayers < 0 || nlayers > 8 || M < 0 || zero_floats < 0 || (zero_floats & 3)) return MI_ERR_INVALID_ARG;
-  if (zero_floats && (!zero_buf || !aligned16(zero_buf))) return MI_ERR_INVALID_ARG;
-  if ((nlayers == 0 || M == 0) && zero_floats == 0) return MI_OK;
-  if (nlayers && M && (!seed || !salts || !ps || !lds || !bits)) return MI_ERR_INVALID_ARG;
-  int64_t most = zero_floats / 4;
-  for (int l = 0; l < nlayers && M > 0; ++l) {
-    if (ps[l] <= 0.f) continue;
-    if (!bits[l] || lds[l] <= 0 || lds[l] % 8 || ps[l] >= 1.f) return MI_ERR_INVALID_ARG;
-    j.bits[j.n] = bits[l];
-    j.salt[j.n] = salts[l];
-    j.nbytes[j.n] = (int64_t)M * lds[l] / 8;
-    j.thr[j.n] = (uint32_t)(ps[l] * 65536.f + 0.5f);
-    most = j.nbytes[j.n] > most ? j.nbytes[j.n] : most;
-    ++j.n;
-  }
-  if (j.n == 0 && zero_floats == 0) return MI_OK;
-  int64_t grid = (most + kBlock - 1) / kBlock;
-  if (grid > kMaxGrid) grid = kMaxGrid;
-  if (grid < 1) grid = 1;
-  *grid_out = grid;
-  return MI_OK;
-}
-
 int mi_tail_dropout_masks_z(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,
                             uint8_t *const *bits, int32_t M, float *zero_buf, int64_t zero_floats, void *stream) {
   MaskJob j;
@@ -1273,6 +1363,39 @@ int mi_tail_head_bwd_s(const float *Z, int32_t ldz, const float *mu, const float
   if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
   const ActDesc x{Z, ldz, mu, sc, be, p, keep};
   MI_LAUNCH("tail_head_bwd", k_tail_head_bwd, mi_tail_head_blocks(M), kBlock, stream, x, g, w, DY, part, wpart, M, N, sum_reps);
+  return launch_status();
+}
+
+int32_t mi_tail_head_bce_ws_elems(int32_t sum_reps) { return sum_reps > 0 ? (4 + 2 * sum_reps + 3) / 4 * 4 : 0; }
+
+int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
+                     const uint8_t *keep, const float *w, const float *b, const float *add, const float *y, float *out,
+                     float *g, float *DY, float *part, float *wpart, int32_t sum_reps, float *loss_ws, int32_t M, int32_t N,
+                     const mi_tail_bn_fwd *stats, void *stream) {
+  if (M <= 0 || N <= 0 || sum_reps <= 0 || sum_reps > 64) return MI_ERR_INVALID_ARG;
+  BnFwd bn{};
+  int64_t *bump = nullptr;
+  if (stats && !stats->part) {        // nothing to join: only the seed (if given) is advanced
+    bump = stats->seed_bump;
+    stats = nullptr;
+  }
+  if (stats) {
+    if (!bn_fwd_view(stats, &bn)) return MI_ERR_INVALID_ARG;
+    mu = stats->mu; sc = stats->sc; be = stats->be;
+  }
+  if (!Z || !mu || !sc || !be || !w || !y || !out || !g || !DY || !part || !wpart || !loss_ws) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(Z, ldz) || N % 4 || N > kHeadLossCols || !aligned16(w) || !aligned16(DY)) return MI_ERR_UNSUPPORTED;
+  if (p > 0.f && (!keep || ldz % 8)) return MI_ERR_INVALID_ARG;
+  const ActDesc x{Z, ldz, mu, sc, be, p, keep};
+  // one workgroup per CU, 16 rows each at M = 4096 (a single trip of 4 rows per wave)
+  const int waves = (M + 3) / 4;
+  const int grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (waves + kWavesPerBlock - 1) / kWavesPerBlock : 256;
+  if (stats)
+    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<true>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws, M,
+              N, bn, sum_reps, (int64_t *)nullptr);
+  else
+    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<false>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws,
+              M, N, bn, sum_reps, bump);
   return launch_status();
 }
 

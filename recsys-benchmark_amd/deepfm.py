@@ -114,7 +114,7 @@ class DeepFM(nn.Module):
         return _kernels.fm_first_order(emb, rows, self.fc.weight, self._bias,
                                        sparse_w1=bool(self.fc.sparse))
 
-    def _fused_step(self, x):
+    def _fused_step(self, x, labels=None):
         """The whole forward as one autograd node (tail.DeepFMFusedFn) when the pieces fit: the full table with row-form
         gradients (or deterministic mode, which builds its dense gradients from row-form values too) in front of a tail the
         fused kernels take.  The lookup's backward then runs in the epilogue of the tail's first input-gradient product.
@@ -138,7 +138,7 @@ class DeepFM(nn.Module):
         if plan is None:
             return None
         return _tail.run_fused_deepfm(plan, groups[-1][1], _mlp._seed_word(W.device), x, self.offsets, W, w1, self._bias,
-                                      sparse_W, sparse_w1)
+                                      sparse_W, sparse_w1, labels if self.training else None)
 
     @staticmethod
     def prefetch_next(x_next) -> None:
@@ -149,9 +149,13 @@ class DeepFM(nn.Module):
 
         _tail.set_next_batch(x_next)
 
-    def forward(self, x):
-        """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid)."""
-        fused = self._fused_step(x)
+    def forward(self, x, labels=None):
+        """x: integer tensor [B, F] of per-field ids -> logits [B] (before sigmoid).
+        labels (optional extension, [B]): the step's targets, when the caller is about to evaluate BCEWithLogitsLoss on the
+        result (the reference trainer does, src/trainer/deepfm.py:51-52) — the fused training step then evaluates the
+        criterion and the head's backward inside its head launch, and recsys_benchmark_amd.BCEWithLogitsLoss(logits, labels)
+        finds them.  The logits are the same with or without; anything else ignores the argument."""
+        fused = self._fused_step(x, labels)
         if fused is not None:
             return fused.squeeze(-1)
         emb, y_fm = self._fm_and_embedding(x)

@@ -53,8 +53,39 @@ class _BCEFn(torch.autograd.Function):
         return dx.view(ctx.shape), None
 
 
+class _HeadBCEFn(torch.autograd.Function):
+    """The criterion as the model's head launch already evaluated it (tail.mi_tail_head_bce: DeepFM.forward(x, labels=y)):
+    the loss and the gradient for an upstream 1 exist, nothing is launched either way.  Any other upstream gradient takes
+    mi_bce_logits_bwd like _BCEFn (and the model's backward then runs its own head backward)."""
+
+    @staticmethod
+    def forward(ctx, logits, head):
+        ctx.head = head
+        ctx.shape = tuple(logits.shape)
+        ctx.save_for_backward(logits)
+        return head.loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        head = ctx.head
+        (x,) = ctx.saved_tensors
+        if g.data_ptr() == unit_scalar(x.device).data_ptr():
+            return head.gvec.view(ctx.shape), None
+        g = _kernels._f32c(g).view(1)
+        x = x.reshape(-1)
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().mi_bce_logits_bwd(x.data_ptr(), head.y.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(),
+                                                 _lib.stream_ptr(x.device)), "mi_bce_logits_bwd")
+        return dx.view(ctx.shape), None
+
+
 class BCEWithLogitsLoss(nn.Module):
     def forward(self, logits, target):
+        from . import tail as _tail
+
+        head = _tail.take_head_loss(logits, target)
+        if head is not None:
+            return _HeadBCEFn.apply(logits, head)
         return _BCEFn.apply(logits, target.float())
 
 

@@ -194,22 +194,71 @@ def _fixed_constants(plan: List[_Layer], dev, stream):
 
 class _State:
     """What the forward leaves for the backward: tensors (flattened for ctx.save_for_backward) + plain metadata."""
-    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat_b", "zsize", "boff", "hoff")
+    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat_b", "zsize", "boff", "hoff", "head")
 
 
-def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
-    """The forward kernels of the tail; returns (out[M, 1], tensors to save, state)."""
+# The gather + FM forward in front of DeepFM's tail carries the keep bits and the zero fill (mi_gather_fm_fwd_ride): the
+# first layer's statistics can then be shifted sums like the others' and the step has no finalize launch at all
+# (MI_TAIL_LEAD_RIDE=0: the first layer keeps its tile statistics and the finalize launch that carries the masks)
+LEAD_RIDE = os.environ.get("MI_TAIL_LEAD_RIDE", "1") == "1"
+# Labels known at forward time (DeepFM.forward(x, labels=y)): head + BCE-with-logits + the head's backward sums in one
+# launch (mi_tail_head_bce) instead of three (MI_TAIL_HEAD_LOSS=0: off)
+HEAD_LOSS = os.environ.get("MI_TAIL_HEAD_LOSS", "1") == "1"
+
+
+class _Lead:
+    """The kernel in front of the tail that produces its input (DeepFM: gather + FM): `launch(job)` runs it — carrying the
+    mask job (a mi_tail_mask_ride or None) — and returns (x[M, K], last_add or None)."""
+    __slots__ = ("M", "dev", "launch")
+
+    def __init__(self, M, dev, launch):
+        self.M, self.dev, self.launch = M, dev, launch
+
+
+class _HeadLoss:
+    """What mi_tail_head_bce left for the criterion: losses.BCEWithLogitsLoss(logits, labels) picks it up when it is handed
+    exactly these logits and labels (take_head_loss), otherwise computes the loss itself."""
+    __slots__ = ("out", "y", "y_key", "loss", "gvec")
+
+
+_HEAD_LOSS = {}
+
+
+def _label_key(t):
+    return (t.data_ptr(), t._version, t.dtype, t.numel())
+
+
+def take_head_loss(logits: torch.Tensor, target: torch.Tensor):
+    if not _HEAD_LOSS or not logits.is_cuda:
+        return None
+    h = _HEAD_LOSS.pop(str(logits.device), None)
+    if h is None:
+        return None
+    if (logits.dtype == torch.float32 and logits.requires_grad and logits.data_ptr() == h.out.data_ptr()
+            and logits.numel() == h.out.numel() and logits.is_contiguous() and _label_key(target) == h.y_key):
+        return h
+    return None
+
+
+def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_Lead] = None, labels=None):
+    """The forward kernels of the tail; returns (out[M, 1], tensors to save, state).  lead (instead of x / last_add): the
+    launch that produces them, run here once the mask job it carries is known.  labels ([M] fp32, optional): the head
+    launch also evaluates BCE-with-logits against them and the head's backward sums (state.head)."""
     lib = _lib.load()
-    dev = _lib.require_gpu(x)
+    dev = lead.dev if lead is not None else _lib.require_gpu(x)
     s = _lib.stream_ptr(dev)
-    M = x.shape[0]
+    M = lead.M if lead is not None else x.shape[0]
     k = len(plan)
     grad = bool(getattr(plan, "grad", True))
     merge = MERGE_JOINS
     R, Rh = STAT_REPS, HEAD_REPS
     sums_ok = STAT_SUMS and not merge and not _kernels.DETERMINISTIC
-    stat_f = [sums_ok and i >= 1 and not L.fixed for i, L in enumerate(plan)]      # this product ADDS its statistics
+    lead_ride = lead is not None and LEAD_RIDE and sums_ok
+    # this product ADDS its statistics (the first layer's only when a launch in front of it has zeroed the sums)
+    stat_f = [sums_ok and (i >= 1 or lead_ride) and not L.fixed for i, L in enumerate(plan)]
     stat_b = sums_ok and grad
+    head_loss = (labels is not None and HEAD_LOSS and stat_b and plan[-1].lin.out_features <= 512
+                 and plan[-1].lin.out_features % 4 == 0)
     # ONE zero-filled buffer per step for everything that accumulates: the split-K weight gradients and the (exactly zero)
     # bias gradients under a training-mode BatchNorm (backward), the forward sums of the layers above the first, the
     # backward column sums of every layer and of the head
@@ -217,7 +266,7 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
     if grad:
         zsize = sum(L.lin.out_features * L.lin.in_features + L.lin.out_features for L in plan)
         zsize = (zsize + 3) // 4 * 4
-    foff, boff, hoff = {}, {}, None
+    foff, boff, hoff, loff = {}, {}, None, None
     for i, L in enumerate(plan):
         if stat_f[i]:
             foff[i] = zsize
@@ -229,11 +278,21 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
         hoff = zsize
         zsize += Rh * (3 * plan[-1].lin.out_features + 4)
         zsize = (zsize + 3) // 4 * 4
+        if head_loss:
+            loff = zsize
+            zsize += int(lib.mi_tail_head_bce_ws_elems(Rh))
     zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if zsize else None
     # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that launch
     # exists (a training-mode BatchNorm on the first layer) and a LATER kernel can advance the seed
-    ride = RIDE_MASKS and not merge and k >= 2 and not plan[0].fixed
-    bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
+    ride = RIDE_MASKS and not merge and k >= 2 and not plan[0].fixed and not lead_ride
+    if lead_ride:
+        bits, lead_job = _masks(seed, plan, M, dev, zeros, ride=True)
+        x, last_add = lead.launch(lead_job[0] if lead_job is not None else None)
+        job = None
+    else:
+        if lead is not None:
+            x, last_add = lead.launch(None)
+        bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
     keep_inputs = grad and not _kernels.DETERMINISTIC
     fixed_c = _fixed_constants(plan, dev, s)
     Zs, consts, acts = [], [], []
@@ -306,12 +365,30 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head):
         bumped = True
     else:
         stats = None
-    _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
-                                      float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
-                                      out.data_ptr(), M, N, ctypes.byref(stats) if stats is not None else None, s),
-               "mi_tail_head_fwd_m")
+    head = None
+    if head_loss:
+        y = _kernels._f32c(labels).view(-1)
+        if y.numel() != M:
+            raise ValueError("labels must hold one value per row of the batch")
+        head = _HeadLoss()
+        head.out, head.y, head.y_key = out, y, _label_key(labels)
+        head.gvec = torch.empty((M,), dtype=torch.float32, device=dev)
+        head.loss = zeros[loff: loff + 1]
+        DY = torch.empty((M, N), dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_tail_head_bce(
+            prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(), float(prev_p), _lib.ptr(prev_bits),
+            w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add), y.data_ptr(), out.data_ptr(), head.gvec.data_ptr(), DY.data_ptr(),
+            zeros[hoff:].data_ptr(), zeros[hoff + Rh * 2 * N:].data_ptr(), Rh, zeros[loff:].data_ptr(), M, N,
+            ctypes.byref(stats) if stats is not None else None, s), "mi_tail_head_bce")
+        _HEAD_LOSS[str(dev)] = head
+    else:
+        _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
+                                          float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
+                                          out.data_ptr(), M, N, ctypes.byref(stats) if stats is not None else None, s),
+                   "mi_tail_head_fwd_m")
     st = _State()
     st.k, st.plan, st.zeros = k, plan, zeros
+    st.head = (head.gvec, DY) if head is not None else None
     st.stat_b, st.zsize, st.boff, st.hoff = stat_b, zsize, boff, hoff
     st.ps = [L.p for L in plan]
     st.has_head_bias = b_head is not None
@@ -340,7 +417,7 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
     gvec = _kernels._f32c(g).view(M)
     later = []           # weight-gradient products for ONE launch at the end
     sizes = [(Zs[i].shape[1] * Ws[i].shape[1], Zs[i].shape[1]) for i in range(k)]
-    zeros = st.zeros                       # filled by the forward's mask launch; a second backward needs a fresh one
+    zeros = st_zeros = st.zeros            # filled by the forward's mask launch; a second backward needs a fresh one
     st.zeros = None
     if zeros is None:
         zeros = torch.zeros((max(st.zsize, sum(a + b for a, b in sizes)),), dtype=torch.float32, device=dev)
@@ -353,7 +430,7 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
     # ---- head: dy of the last hidden layer, its column sums, dw / db of the head
     N = Zs[-1].shape[1]
     c = consts[-1]
-    DY = torch.empty((M, N), dtype=torch.float32, device=dev)
+    DY = None if st.head is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     if stat:            # sums added into Rh zeroed rows: joined by the next product's prologue, no finalize launch
         nblk = Rh
         part = zeros[st.hoff: st.hoff + Rh * 2 * N].view(Rh, N, 2)
@@ -362,9 +439,17 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
         nblk = int(lib.mi_tail_head_blocks(M))
         part = torch.empty((nblk, N, 2), dtype=torch.float32, device=dev)
         wpart = torch.empty((nblk, N + 4), dtype=torch.float32, device=dev)
-    _lib.check(lib.mi_tail_head_bwd_s(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(st.ps[-1]),
-                                      _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
-                                      wpart.data_ptr(), Rh if stat else 0, M, N, s), "mi_tail_head_bwd_s")
+    fused_head, st.head = st.head, None
+    if (fused_head is not None and stat and zeros is st_zeros and gvec.data_ptr() == fused_head[0].data_ptr()):
+        DY = fused_head[1]        # the forward's head launch wrote DY and the sums for exactly this gradient
+    else:
+        if fused_head is not None and zeros is st_zeros:
+            zeros[st.hoff: st.hoff + Rh * (3 * N + 4)].zero_()      # ... for an upstream gradient of 1: not this one
+        if DY is None:
+            DY = torch.empty((M, N), dtype=torch.float32, device=dev)
+        _lib.check(lib.mi_tail_head_bwd_s(Zs[-1].data_ptr(), N, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), float(st.ps[-1]),
+                                          _lib.ptr(bits[-1]), gvec.data_ptr(), w_head.data_ptr(), DY.data_ptr(), part.data_ptr(),
+                                          wpart.data_ptr(), Rh if stat else 0, M, N, s), "mi_tail_head_bwd_s")
     dw_head = torch.empty((1, N), dtype=torch.float32, device=dev)
     db_head = torch.empty((1,), dtype=torch.float32, device=dev)
     # DeepFM's scalar bias is added to every logit like the head's bias: same gradient, written to a second word by the
@@ -530,7 +615,7 @@ class DeepFMFusedFn(torch.autograd.Function):
     _kernels.GatherFM.backward does with the same values."""
 
     @staticmethod
-    def forward(ctx, plan, head, seed, idx, offsets, W, w1, bias, sparse_W: bool, sparse_w1: bool, *params):
+    def forward(ctx, plan, head, seed, idx, offsets, W, w1, bias, sparse_W: bool, sparse_w1: bool, labels, *params):
         dev = _lib.require_gpu(idx, offsets, W, w1, bias)
         lib = _lib.load()
         idx = _kernels._i64c(idx)
@@ -543,15 +628,21 @@ class DeepFMFusedFn(torch.autograd.Function):
         yfm = torch.empty((B,), dtype=torch.float32, device=dev)
         rows = torch.empty((B, F), dtype=torch.int64, device=dev)
         esum = torch.empty((B, D), dtype=torch.float32, device=dev)
-        _lib.check(lib.mi_gather_fm_fwd_sum(idx.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1,
-                                            _lib.ptr(bias), emb.data_ptr(), yfm.data_ptr(), rows.data_ptr(), esum.data_ptr(),
-                                            B, F, D, N, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
-                   "mi_gather_fm_fwd_sum")
+
+        def gather(job):      # (job: the tail's mask work, carried in extra workgroups of this launch)
+            _lib.check(lib.mi_gather_fm_fwd_ride(idx.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1,
+                                                 _lib.ptr(bias), emb.data_ptr(), yfm.data_ptr(), rows.data_ptr(), esum.data_ptr(),
+                                                 B, F, D, N, _lib.err_word(dev).data_ptr(),
+                                                 ctypes.byref(job) if job is not None else None, _lib.stream_ptr(dev)),
+                       "mi_gather_fm_fwd_ride")
+            return emb, yfm
+
         _kernels.note_field_layout(rows, offsets, N)
         k = len(plan)
         Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
         w_head = _kernels._f32c(params[4 * k]).view(-1)
-        out, saved, st = _tail_forward(plan, seed, emb, yfm, Ws, w_head, params[4 * k + 1])
+        out, saved, st = _tail_forward(plan, seed, None, None, Ws, w_head, params[4 * k + 1], lead=_Lead(B, dev, gather),
+                                       labels=labels)
         ctx.st = st
         ctx.prefetch = _next_batch_prefetch(dev, offsets, Wc, ldw, w1c, ldw1, F, N)
         ctx.meta = (B, F, D, N, tuple(W.shape), tuple(w1.shape), bool(sparse_W), bool(sparse_w1), bias is not None)
@@ -563,11 +654,11 @@ class DeepFMFusedFn(torch.autograd.Function):
         B, F, D, N, Wshape, w1shape, sparse_W, sparse_w1, has_bias = ctx.meta
         saved = ctx.saved_tensors
         rows, esum = saved[-2], saved[-1]
-        need = ctx.needs_input_grad           # (plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *params)
+        need = ctx.needs_input_grad       # (plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, labels, *params)
         need_W, need_w1, need_b = need[5], need[6], need[7]
         dev = rows.device
         g1vals = torch.empty((B * F,), dtype=torch.float32, device=dev) if need_w1 else None
-        gvals, _, grads, db_head = _tail_backward(ctx.st, saved[:ctx.st.n_saved], g, True, need[10:], False,
+        gvals, _, grads, db_head = _tail_backward(ctx.st, saved[:ctx.st.n_saved], g, True, need[11:], False,
                                                   fm=(esum, g1vals, D), beside_wgrad=ctx.prefetch)
         gvals = gvals.view(B * F, D)
         stream = _lib.stream_ptr(dev)
@@ -580,7 +671,7 @@ class DeepFMFusedFn(torch.autograd.Function):
                    else _kernels._scatter_rows(rows, g1vals, N, 1, stream).view(w1shape))
         # the scalar bias is added to every logit, like the head's bias: the same gradient, sum_m g[m]
         gb = db_head if (has_bias and need_b) else None            # (the twin word the join wrote: no copy)
-        return (None, None, None, None, None, gW, gw1, gb, None, None, *grads)
+        return (None, None, None, None, None, gW, gw1, gb, None, None, None, *grads)
 
 
 def _plan_params(plan, head):
@@ -601,5 +692,8 @@ FM_EPILOGUE = os.environ.get("MI_FUSED_FM_EPILOGUE", "1") == "1"
 
 
 def run_fused_deepfm(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, idx, offsets, W, w1, bias,
-                     sparse_W: bool, sparse_w1: bool) -> torch.Tensor:
-    return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, *_plan_params(plan, head))
+                     sparse_W: bool, sparse_w1: bool, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """labels (optional, [B]): the step's targets — the head launch then also evaluates nn.BCEWithLogitsLoss against them and
+    the head's backward (losses.BCEWithLogitsLoss finds both when it is called with these logits and labels)."""
+    return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, labels,
+                               *_plan_params(plan, head))

@@ -13,6 +13,7 @@ and read back at the logging steps only (the reference calls `.item()` every bat
 """
 import datetime
 import logging
+import inspect
 import warnings
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -84,6 +85,8 @@ class GraphedTrainStep:
         self.extra_sum: Optional[torch.Tensor] = None
         self.optimizers: List[torch.optim.Optimizer] = optimizers if isinstance(optimizers, list) else [optimizers]
         self.criterion = criterion if criterion is not None else losses.BCEWithLogitsLoss()
+        self._labels_in_forward = (isinstance(self.criterion, losses.BCEWithLogitsLoss)
+                                   and "labels" in inspect.signature(model.forward).parameters)
         self.warmup = warmup
         self.clip_grad = clip_grad
         # clip_grad_norm_ reads the norm back on some paths and row-form gradients have no dense norm: eager only
@@ -101,8 +104,11 @@ class GraphedTrainStep:
         self._seen = 0
 
     def _body(self, inputs, labels):
-        outputs = self.model(inputs)
-        loss = self.criterion(outputs, labels.float())
+        labels = labels.float()
+        # (a model that takes the step's labels — DeepFM's fused step — evaluates the criterion inside its head launch; the
+        #  criterion call below then only picks the result up)
+        outputs = self.model(inputs, labels=labels) if self._labels_in_forward else self.model(inputs)
+        loss = self.criterion(outputs, labels)
         total = loss
         if self.extra_loss is not None:
             extra = self.extra_loss()
