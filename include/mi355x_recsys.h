@@ -168,6 +168,16 @@ MI_API int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *
                               int32_t De, int64_t n1, int64_t n2, int64_t mod1,
                               int64_t div2, int32_t op, int32_t xform, int32_t *err,
                               void *stream);
+/* ... with the model's `x + offsets` (src/models/dcn.py:204 / deepfm.py:86: per-field ids [B, F] + cumulative field
+ * offsets [F]) done inside the lookup: idx holds the raw ids, id i gets offsets[i % F] added, and the sums — what the
+ * reference hands to its embedding module, what the backward and the sparse optimizer's field sort read — are written to
+ * rows_out int64[n].  offsets == NULL: mi_dual_gather_fwd (rows_out untouched).  De % 4 == 0 with 16-byte aligned
+ * tables only (MI_ERR_UNSUPPORTED otherwise: add the offsets first). */
+MI_API int mi_dual_gather_fwd_off(const int64_t *idx, const int64_t *offsets, int64_t *rows_out, const float *T1,
+                                  const float *T2, const float *S1, const float *S2, const uint8_t *M1,
+                                  const uint8_t *M2, float *out, int64_t n, int32_t F, int32_t De, int64_t n1,
+                                  int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform, int32_t *err,
+                                  void *stream);
 
 /* Dense gradients of the above into caller-zeroed gT1/gT2 (and gS1/gS2 for xform 1),
  * float atomics; tables of <= 4096 elements are pre-summed per workgroup in LDS. */
@@ -179,11 +189,14 @@ MI_API int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const floa
                               int32_t op, int32_t xform, void *stream);
 /* Row form of table 2's gradient (round 4; plain tables only — QRHashingEmbedding, src/models/embeddings/qr_embedding.py:95-109
  * through autograd): g2vals fp32[n, De] receives lookup i's contribution to row rows2[i] = idx[i] / div2 of table 2 (rows2
- * int64[n], -1 for an id out of range) — an uncoalesced COO gradient like nn.Embedding(sparse=True)'s, written with plain
- * coalesced stores: no float atomics into scattered rows, no [n2, De] zero-fill.  gT1 (caller-zeroed, dense) as above.
+ * int64[n]; an id out of range gets row 0 and a ZERO value row) — an uncoalesced COO gradient like
+ * nn.Embedding(sparse=True)'s, written with plain coalesced stores: no float atomics into scattered rows, no [n2, De]
+ * zero-fill.  gT1 (dense) is added to (caller-zeroed) as above, EXCEPT in the joined form below.
  * workspace (nullable): mi_dual_gather_bwd_rows_workspace_elems(De, n1) floats (0: this shape has no use for one) whose first
  * word is ZERO on entry (the kernel leaves it zero): table 1's per-workgroup sums are then joined by the last workgroup to
- * arrive, in a fixed order, instead of by same-address float atomics. */
+ * arrive, in a fixed order, instead of by same-address float atomics — and gT1 is WRITTEN, not added to (no zero fill
+ * needed), whenever a workspace is passed and mi_dual_gather_bwd_rows_overwrites(De, n1) != 0 (16-byte aligned operands). */
+MI_API int32_t mi_dual_gather_bwd_rows_overwrites(int32_t De, int64_t n1);
 MI_API int64_t mi_dual_gather_bwd_rows_workspace_elems(int32_t De, int64_t n1);
 MI_API int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float *T1, const float *T2, float *gT1,
                                    float *g2vals, int64_t *rows2, int64_t n, int32_t F, int32_t De, int64_t n1,
@@ -779,7 +792,7 @@ typedef struct mi_tail_bn_fwd {
   float *mu, *sc, *be, *rstd;
   float momentum, eps;
   const float *shift;     /* nrep > 0: the shift the sums were taken around, [N] (mi_tail_fwd_gemm_s's shift_out) */
-  int32_t nrep;           /* 0: `part` = tile statistics [MT, N, 2]; > 0: `part` = shifted sums [nrep, 2, N] (mi_tail_fwd_gemm_s) */
+  int32_t nrep;           /* 0: `part` = tile statistics [MT, N, 2]; > 0: `part` = shifted sums fp64[nrep, 2, N] (mi_tail_fwd_gemm_s) */
 } mi_tail_bn_fwd;
 typedef struct mi_tail_bn_bwd {
   const float *part;
@@ -799,10 +812,12 @@ MI_API int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, co
                               const mi_tail_bn_fwd *x_stats, void *stream);
 /* BatchNorm statistics WITHOUT finalize launches (round 4).  The producing product adds, per column c and 64-row tile,
  *   t1 = sum (z - s_c),  t2 = sum (z - s_c)^2,   s_c = shift_running_mean[c] - shift_mean_offset[c]  (each nullable: 0)
- * into part[r, 0, c] / part[r, 1, c] (fp32[sum_reps, 2, N], ZEROED by the caller, r = row tile % sum_reps) with float atomics
+ * (formed from the tile's exact count / mean / M2) into part[r, 0, c] / part[r, 1, c] — `part` holds DOUBLES here:
+ * fp64[sum_reps, 2, N] = 4 sum_reps N floats, 8-byte aligned, ZEROED by the caller, r = row tile % sum_reps — with f64
+ * atomics (the two sums cancel by (mean - s)^2 / var when the variance is derived: fp32 sums lose that many digits)
  * and stores s into shift_out[N]; the consuming kernel (mi_tail_fwd_gemm_* / mi_tail_head_fwd_m with a mi_tail_bn_fwd whose
  * nrep = sum_reps, part and shift point at these buffers) derives mean = s + t1/M, M2 = t2 - t1^2/M and the constants in
- * its prologue from (2 nrep + 3) N floats and its first workgroup writes mu / sc / be / rstd and the running statistics
+ * its prologue from (4 nrep + 3) N floats and its first workgroup writes mu / sc / be / rstd and the running statistics
  * (F.batch_norm(training=True) semantics, src/models/deepfm.py:57-58).  sum_reps = 0 is mi_tail_fwd_gemm_m.
  * mi_tail_dgrad_gemm_s: the backward mirror — part_reps > 0: part is fp32[part_reps, K, 2] (zeroed by the caller), every row
  * tile ADDS its column sums (sum dy, sum dy (z - mu)) into row (tile % part_reps); a mi_tail_bn_bwd with nblk = part_reps

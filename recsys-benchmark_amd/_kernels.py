@@ -373,7 +373,10 @@ class DualGather(torch.autograd.Function):
     """out = T1'[idx % mod1] (op) T2'[idx // div2]  (mi_dual_gather_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int, fields=None, sparse2: bool = False):
+    def forward(ctx, idx, T1, T2, S1, S2, M1, M2, mod1: int, div2: int, op: int, xform: int, fields=None, sparse2: bool = False,
+                offsets=None):
+        """offsets ([F], optional): idx holds the model's raw per-field ids and the per-field row offsets are added inside
+        the lookup; the second output is then the row ids idx + offsets (int64, not differentiable)."""
         dev = _lib.require_gpu(idx, T1, T2)
         idxc = _i64c(idx)
         T1c, T2c = _f32c(T1), _f32c(T2)
@@ -396,22 +399,32 @@ class DualGather(torch.autograd.Function):
         else:
             oshape = tuple(idx.shape) + (De,)
         out = torch.empty(oshape, dtype=torch.float32, device=dev)
+        rows = None
+        if offsets is not None:
+            if idx.dim() != 2 or offsets.numel() != F:
+                raise ValueError("offsets go with [B, F] ids, one per field")
+            offs = _i64c(offsets.reshape(-1))
+            rows = torch.empty_like(idxc)
         _lib.check(
-            _lib.load().mi_dual_gather_fwd(
-                idxc.data_ptr(), T1c.data_ptr(), T2c.data_ptr(), _lib.ptr(S1c), _lib.ptr(S2c),
-                _lib.ptr(M1c), _lib.ptr(M2c), out.data_ptr(), n, F, De, T1c.shape[0], T2c.shape[0],
+            _lib.load().mi_dual_gather_fwd_off(
+                idxc.data_ptr(), _lib.ptr(offs) if rows is not None else None, _lib.ptr(rows), T1c.data_ptr(), T2c.data_ptr(),
+                _lib.ptr(S1c), _lib.ptr(S2c), _lib.ptr(M1c), _lib.ptr(M2c), out.data_ptr(), n, F, De, T1c.shape[0], T2c.shape[0],
                 mod1, div2, op, xform, _lib.err_word(dev).data_ptr(), _lib.stream_ptr(dev)),
-            "mi_dual_gather_fwd",
+            "mi_dual_gather_fwd_off",
         )
+        if rows is not None:
+            idxc = rows              # the backward reads the finished row ids
+            ctx.mark_non_differentiable(rows)
         ctx.save_for_backward(idxc, T1c, T2c, S1c, S2c, M1c, M2c)
         ctx.meta = (n, F, De, mod1, div2, op, xform)
         ctx.fields = fields if (fields is not None and idx.dim() == 2 and fields[3] == F) else None
         ctx.sparse2 = bool(sparse2) and xform == XF_NONE
         ctx.t2_shape = tuple(T2.shape)
-        return out
+        ctx.with_rows = rows is not None
+        return (out, rows) if rows is not None else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_rows=None):
         idxc, T1c, T2c, S1c, S2c, M1c, M2c = ctx.saved_tensors
         n, F, De, mod1, div2, op, xform = ctx.meta
         dev = g.device
@@ -420,15 +433,17 @@ class DualGather(torch.autograd.Function):
         if ctx.sparse2:
             # table 2 (the quotient table: ~N / divider rows) gets its gradient in ROW form: one value row per lookup, no
             # atomics into scattered rows and no [n2, De] zero-fill; table 1 (divider rows) stays dense
-            gT1 = torch.zeros_like(T1c)
+            ws = _dual_rows_workspace(dev, De, T1c.shape[0])
+            # (with the workspace the last workgroup WRITES table 1's gradient: no zero fill)
+            written = ws is not None and _lib.load().mi_dual_gather_bwd_rows_overwrites(De, T1c.shape[0]) != 0
+            gT1 = torch.empty_like(T1c) if written else torch.zeros_like(T1c)
             g2vals = torch.empty((n, De), dtype=torch.float32, device=dev)
             rows2 = torch.empty((n,), dtype=torch.int64, device=dev)
-            ws = _dual_rows_workspace(dev, De, T1c.shape[0])
             _lib.check(_lib.load().mi_dual_gather_bwd_rows(idxc.data_ptr(), g.data_ptr(), T1c.data_ptr(), T2c.data_ptr(), gT1.data_ptr(),
                                                            g2vals.data_ptr(), rows2.data_ptr(), n, F, De, T1c.shape[0], T2c.shape[0],
                                                            mod1, div2, op, _lib.ptr(ws), _lib.stream_ptr(dev)), "mi_dual_gather_bwd_rows")
-            # (ids out of range carry row -1 and a zero value row: clamped to row 0, they add nothing)
-            return None, gT1, _coo(rows2.clamp_(min=0), g2vals, ctx.t2_shape), None, None, None, None, None, None, None, None, None, None
+            # (ids out of range carry row 0 and a zero value row: they add nothing)
+            return None, gT1, _coo(rows2, g2vals, ctx.t2_shape), None, None, None, None, None, None, None, None, None, None, None
         gT1, gT2 = torch.zeros_like(T1c), torch.zeros_like(T2c)
         gS1 = torch.zeros_like(S1c) if xform == XF_SOFT else None
         gS2 = torch.zeros_like(S2c) if xform == XF_SOFT else None
@@ -441,7 +456,7 @@ class DualGather(torch.autograd.Function):
                 small.numel() if small is not None else 0, _lib.ptr(row0), _lib.ptr(flags), _lib.stream_ptr(dev)),
             "mi_dual_gather_bwd_fields",
         )
-        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None, None
+        return None, gT1, gT2, gS1, gS2, None, None, None, None, None, None, None, None, None
 
 
 _DUAL_WS = {}
@@ -481,11 +496,12 @@ def small_field_hint(field_dims, div2: int, device):
             flags.to(device), len(field_dims))
 
 
-def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None, fields=None, sparse2=False):
+def dual_gather(idx, T1, T2, mod1, div2, op="add", S1=None, S2=None, M1=None, M2=None, fields=None, sparse2=False, offsets=None):
     """fields (optional): small_field_hint(...) — lets the backward sum the gradient of low-cardinality fields per field
-    instead of with thousands of same-address atomics; same result up to the order of float additions."""
+    instead of with thousands of same-address atomics; same result up to the order of float additions.
+    offsets (optional, [F]): idx holds raw per-field ids; returns (out, idx + offsets), the addition done by the lookup."""
     xform = XF_SOFT if S1 is not None else (XF_MASK if M1 is not None else XF_NONE)
-    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform, fields, bool(sparse2))
+    return DualGather.apply(idx, T1, T2, S1, S2, M1, M2, int(mod1), int(div2), OPS[op], xform, fields, bool(sparse2), offsets)
 
 
 def csr_rows(values, crow, col, ids, D: int, N: int) -> torch.Tensor:

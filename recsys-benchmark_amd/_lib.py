@@ -40,6 +40,8 @@ SIGNATURES = {
     "mi_dual_gather_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                            _i64, _i64, _i32, _i32, _p],
     "mi_dual_gather_bwd_rows_workspace_elems": [_i32, _i64],
+    "mi_dual_gather_bwd_rows_overwrites": [_i32, _i64],
+    "mi_dual_gather_fwd_off": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _p, _p],
     "mi_dual_gather_bwd_rows": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _p, _p],
     "mi_dual_gather_bwd_fields": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _i64,
                                   _i64, _i64, _i32, _i32, _p, _i32, _p, _p, _p],

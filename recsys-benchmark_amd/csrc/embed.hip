@@ -87,10 +87,13 @@ __device__ __forceinline__ void out_offsets(int op, int64_t i, int F, int De, in
   }
 }
 
+// offsets (nullable, [F]): per-field row offsets added to the ids here (idx is then the model's raw [B, F] input), the sums
+// written to rows_out (nullable, [n]) for the backward and the optimizer — the model's `x + offsets` without a launch
 template <int LPR, int XF>
 __global__ __launch_bounds__(kBlock) void k_dual_fwd(const int64_t *__restrict__ idx, DualTables t,
                                                      float *__restrict__ out, int64_t n, int F, int op,
-                                                     int *err) {
+                                                     int *err, const int64_t *__restrict__ offsets,
+                                                     int64_t *__restrict__ rows_out) {
   constexpr int RS = kWave / LPR;
   constexpr int De = LPR * 4;
   const int lane = threadIdx.x & 63;
@@ -103,7 +106,11 @@ __global__ __launch_bounds__(kBlock) void k_dual_fwd(const int64_t *__restrict__
   for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
     const int64_t i = tile * RS + r;
     if (i >= n) continue;
-    const int64_t id = idx[i];
+    int64_t id = idx[i];
+    if (offsets) {
+      id += offsets[(uint64_t)i % (uint32_t)F];
+      if (rows_out && q == 0) rows_out[i] = id;
+    }
     int64_t i1, i2;
     split_id(id, t, i1, i2);
     const bool ok = id >= 0 && i1 < t.n1 && i2 < t.n2;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd_rows4(const int64_t *__rest
         g2 = make_float4(go[u].x * e1[u].x, go[u].y * e1[u].y, go[u].z * e1[u].z, go[u].w * e1[u].w);
       } else { g1 = g2 = go[u]; }
       st4(g2vals + i * De + q * 4, ok[u] ? g2 : z);
-      if (q == 0) rows2[i] = ok[u] ? i2[u] : -1;
+      if (q == 0) rows2[i] = ok[u] ? i2[u] : 0;      // (an id out of range: row 0 with a zero value row)
       if (ok[u]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd_rows4(const int64_t *__rest
   if ((int)threadIdx.x < nv) {
     float v = 0.f;
     for (int p = 0; p < parts; ++p) v += redf[p * nv + threadIdx.x];
-    gT1[threadIdx.x] += v;
+    gT1[threadIdx.x] = v;            // WRITTEN, not added to: the caller's gT1 need not be zeroed in this form
   }
   if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned *>(ws), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_dual_bwd(const int64_t *__restrict__
     if (!(id >= 0 && i1 < t.n1 && i2 < t.n2)) {
       if (gr.g2vals) {
         gr.g2vals[e] = 0.f;
-        if (d == 0) gr.rows2[i] = -1;
+        if (d == 0) gr.rows2[i] = 0;
       }
       continue;
     }
@@ -720,6 +727,14 @@ int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2, con
                        const float *S2, const uint8_t *M1, const uint8_t *M2, float *out, int64_t n,
                        int32_t F, int32_t De, int64_t n1, int64_t n2, int64_t mod1, int64_t div2, int32_t op,
                        int32_t xform, int32_t *err, void *stream) {
+  return mi_dual_gather_fwd_off(idx, nullptr, nullptr, T1, T2, S1, S2, M1, M2, out, n, F, De, n1, n2, mod1, div2, op, xform, err,
+                                stream);
+}
+
+int mi_dual_gather_fwd_off(const int64_t *idx, const int64_t *offsets, int64_t *rows_out, const float *T1, const float *T2,
+                           const float *S1, const float *S2, const uint8_t *M1, const uint8_t *M2, float *out, int64_t n,
+                           int32_t F, int32_t De, int64_t n1, int64_t n2, int64_t mod1, int64_t div2, int32_t op,
+                           int32_t xform, int32_t *err, void *stream) {
   if (n < 0 || F <= 0 || De <= 0 || n1 <= 0 || n2 <= 0 || mod1 <= 0 || div2 <= 0) return MI_ERR_INVALID_ARG;
   if (op < OP_MULT || op > OP_CAT || xform < XF_NONE || xform > XF_MASK) return MI_ERR_INVALID_ARG;
   if (n == 0) return MI_OK;
@@ -727,6 +742,7 @@ int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2, con
   if (xform == XF_SOFT && (!S1 || !S2)) return MI_ERR_INVALID_ARG;
   if (xform == XF_MASK && (!M1 || !M2)) return MI_ERR_INVALID_ARG;
   if (op == OP_CAT && n % F != 0) return MI_ERR_INVALID_ARG;
+  if (offsets && (n % F != 0 || !rows_out)) return MI_ERR_INVALID_ARG;
   DualTables t{T1, T2, S1, S2, M1, M2, n1, n2, mod1, div2};
   const bool al = aligned16(T1) && aligned16(T2) && aligned16(out) && (xform != XF_SOFT || (aligned16(S1) && aligned16(S2))) &&
                   (xform != XF_MASK || (((uintptr_t)M1 & 3) == 0 && ((uintptr_t)M2 & 3) == 0));
@@ -736,9 +752,9 @@ int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2, con
     const int grid = grid_for_waves(tiles);
 #define CALL(LPR)                                                                                            \
   do {                                                                                                       \
-    if (xform == XF_NONE) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_NONE>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
-    else if (xform == XF_SOFT) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_SOFT>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
-    else MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_MASK>), grid, kBlock, stream, idx, t, out, n, F, op, err); \
+    if (xform == XF_NONE) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_NONE>), grid, kBlock, stream, idx, t, out, n, F, op, err, offsets, rows_out); \
+    else if (xform == XF_SOFT) MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_SOFT>), grid, kBlock, stream, idx, t, out, n, F, op, err, offsets, rows_out); \
+    else MI_LAUNCH("dual_gather_fwd", (k_dual_fwd<LPR, XF_MASK>), grid, kBlock, stream, idx, t, out, n, F, op, err, offsets, rows_out); \
   } while (0)
     switch (lpr) {
       case 1: CALL(1); break;
@@ -752,6 +768,7 @@ int mi_dual_gather_fwd(const int64_t *idx, const float *T1, const float *T2, con
     }
 #undef CALL
   } else {
+    if (offsets) return MI_ERR_UNSUPPORTED;      // (the element-per-thread form takes finished row ids)
     MI_LAUNCH("dual_gather_fwd", k_dual_fwd_anyD, grid_for_elems(n * De), kBlock, stream, idx, t, out, n, F,
               De, op, xform, err);
   }
@@ -764,6 +781,11 @@ int mi_dual_gather_bwd(const int64_t *idx, const float *g_out, const float *T1, 
                        int64_t n2, int64_t mod1, int64_t div2, int32_t op, int32_t xform, void *stream) {
   return mi_dual_gather_bwd_fields(idx, g_out, T1, T2, S1, S2, M1, M2, gT1, gT2, gS1, gS2, n, F, De, n1, n2, mod1, div2, op, xform,
                                    nullptr, 0, nullptr, nullptr, stream);
+}
+
+int32_t mi_dual_gather_bwd_rows_overwrites(int32_t De, int64_t n1) {
+  return n1 >= 1 && n1 <= 4 && De > 0 && De % 4 == 0 && De <= 256 && ((De / 4) & (De / 4 - 1)) == 0 && n1 * De <= kBlock &&
+         kBlock % (n1 * De) == 0;
 }
 
 int64_t mi_dual_gather_bwd_rows_workspace_elems(int32_t De, int64_t n1) {

@@ -95,29 +95,30 @@ struct BnFwd {           // device view of mi_tail_bn_fwd
   int64_t *nbt, *seed_bump;
   float *mu, *sc, *be, *rstd;
   float momentum, eps;
-  int nrep;              // > 0: `part` holds SHIFTED SUMS [nrep][2][N] accumulated by float atomics (below), not tile statistics
+  int nrep;              // > 0: `part` holds SHIFTED SUMS double[nrep][2][N] accumulated by f64 atomics (below), not tile statistics
   const float *shift;    // [N] the shift they were taken around
 };
 // ---- statistics as shifted sums (round 4) ----------------------------------------------------------------------------
-// A product's epilogue adds, per column c, t1 = sum_m (z - s_c) and t2 = sum_m (z - s_c)^2 of its 64-row tile into
-// sums[r][0][c] / sums[r][1][c] with float atomics (r = row tile % nrep: replicas spread the same-address traffic; each
+// A product's epilogue adds, per column c, t1 = sum_m (z - s_c) and t2 = sum_m (z - s_c)^2 of its 64-row tile (formed from
+// the tile's exact (n, mean, M2)) into sums[r][0][c] / sums[r][1][c] — DOUBLES — with f64 atomics (r = row tile % nrep: replicas spread the same-address traffic; each
 // atomic wave-instruction covers 64 consecutive floats), s_c = the layer's running mean minus the Linear bias the product
 // left out — a value near the batch mean after a few steps, and any value is algebraically exact:
 //   mean = s + t1 / M,   M2 = t2 - t1^2 / M
 // (the cancellation in M2 is of relative size (mean - s)^2 / var, which is O(1) for a BatchNorm pre-activation).  The
-// CONSUMING kernel derives mu / gamma rstd / beta from (2 nrep + 3) N floats in its prologue — 8 to 20 KB, one round trip,
+// CONSUMING kernel derives mu / gamma rstd / beta from (4 nrep + 3) N floats in its prologue — 14 to 30 KB, one round trip,
 // against the 205 KB of tile statistics round 3's joined form pulled through every CU — and no finalize launch exists.
 // Float-atomic order makes the statistics vary in the last bits between runs: deterministic mode keeps the tile
 // statistics and the finalize launches.
 template <int NT>
 __device__ __forceinline__ void bn_derive_fwd(const BnFwd &b, int M, int N, float *cst, bool writer, int tid) {
-  const float inv_m = 1.f / (float)M;
+  const double inv_m = 1.0 / (double)M;
+  const double *P = reinterpret_cast<const double *>(b.part);
   for (int n = tid * 2; n < N; n += NT * 2) {
-    float2 t1 = make_float2(0.f, 0.f), t2 = t1;
+    double t1x = 0.0, t1y = 0.0, t2x = 0.0, t2y = 0.0;
     for (int r = 0; r < b.nrep; ++r) {
-      const float2 a = *reinterpret_cast<const float2 *>(b.part + (int64_t)(2 * r) * N + n);
-      const float2 q = *reinterpret_cast<const float2 *>(b.part + (int64_t)(2 * r + 1) * N + n);
-      t1.x += a.x; t1.y += a.y; t2.x += q.x; t2.y += q.y;
+      const double2 a = *reinterpret_cast<const double2 *>(P + (int64_t)(2 * r) * N + n);
+      const double2 q = *reinterpret_cast<const double2 *>(P + (int64_t)(2 * r + 1) * N + n);
+      t1x += a.x; t1y += a.y; t2x += q.x; t2y += q.y;
     }
     const float2 sh = *reinterpret_cast<const float2 *>(b.shift + n);
     const float2 gm2 = b.gamma ? *reinterpret_cast<const float2 *>(b.gamma + n) : make_float2(1.f, 1.f);
@@ -131,11 +132,11 @@ __device__ __forceinline__ void bn_derive_fwd(const BnFwd &b, int M, int N, floa
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n + j;
-      const float s1 = j ? t1.y : t1.x, s2 = j ? t2.y : t2.x;
-      const float d = s1 * inv_m;
-      const float mean = (j ? sh.y : sh.x) + d;
-      const float m2 = fmaxf(s2 - s1 * d, 0.f);
-      const float var = m2 * inv_m;
+      const double s1 = j ? t1y : t1x, s2 = j ? t2y : t2x;
+      const double dm = s1 * inv_m;
+      const float mean = (float)((double)(j ? sh.y : sh.x) + dm);
+      const float m2 = fmaxf((float)(s2 - s1 * dm), 0.f);
+      const float var = m2 * (float)inv_m;
       const float rstd = rsqrtf(var + b.eps);
       const float gm = j ? gm2.y : gm2.x, bt = j ? bt2.y : bt2.x;
       cst[col] = mean;
@@ -429,10 +430,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
       n_a = n;
     }
     if (a.stat_rep > 0) {
-      const float d = mean_a - stat_s;
-      float *o = a.part + (int64_t)((mt % a.stat_rep) * 2) * a.N + n0 + t;
-      atomicAdd(o, n_a * d);
-      atomicAdd(o + a.N, fmaf(n_a * d, d, m2_a));
+      // the tile's (n, mean, M2) are exact to fp32 around the tile's own values; what meets the other tiles' is kept in
+      // DOUBLE (global_atomic_add_f64): sum n d and sum (n d^2 + M2) with d = mean - shift cancel against each other by
+      // (mean - shift)^2 / var when the batch variance is derived, and a first layer fed by freshly initialised (tiny)
+      // embeddings has that ratio in the hundreds (fp32 sums: logits off by 9e-5 against the oracle at step 1)
+      const double d = (double)mean_a - (double)stat_s;
+      double *o = reinterpret_cast<double *>(a.part) + (int64_t)((mt % a.stat_rep) * 2) * a.N + n0 + t;
+      atomicAdd(o, (double)n_a * d);
+      atomicAdd(o + a.N, (double)n_a * d * d + (double)m2_a);
       if (mt == 0) a.stat_shift[n0 + t] = stat_s;
     } else {
       float *o = a.part + ((int64_t)mt * a.N + n0 + t) * 2;
@@ -1207,7 +1212,7 @@ int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const flo
                        int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
                        const float *shift_running_mean, const float *shift_mean_offset, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
-  if (sum_reps < 0 || sum_reps > 64 || (sum_reps > 0 && (!part || !shift_out))) return MI_ERR_INVALID_ARG;
+  if (sum_reps < 0 || sum_reps > 64 || (sum_reps > 0 && (!part || !shift_out || ((uintptr_t)part & 7)))) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!X || !W || !Z) return MI_ERR_INVALID_ARG;
   if (!vec_ok(X, ldx) || !vec_ok(W, ldw) || !vec_ok(Z, ldz) || N % 4 || K % 4) return MI_ERR_UNSUPPORTED;

@@ -48,9 +48,14 @@ class _FieldModel(nn.Module):
 
     def _lookup(self, x: torch.Tensor):
         """raw per-field ids [B, F] -> (row ids [B, F], field vectors flattened to [B, F*D])"""
-        rows = x + self.offsets
+        emb_mod = self.embedding
+        if getattr(emb_mod, "takes_offsets", None) is not None and emb_mod.takes_offsets(x):
+            fields, rows = emb_mod(x, offsets=self.offsets)        # x + offsets inside the lookup kernel
+        else:
+            rows = x + self.offsets
+            fields = emb_mod(rows)
         _kernels.note_field_layout(rows, self.offsets, self._num_rows)   # lets the sparse optimizer sort field by field
-        return rows, self.embedding(rows).reshape(rows.shape[0], -1)
+        return rows, fields.reshape(rows.shape[0], -1)
 
     @classmethod
     def load(cls, checkpoint: Union[str, Dict[str, Any]], strict=True, *, empty_embedding=False):
@@ -74,11 +79,13 @@ class DCN_Mix(_FieldModel):
         self._dnn = nn.Sequential(*stack, nn.Linear(top, 1))
         self._register_offsets(field_dims)
 
-    def forward(self, x):
-        """x: int [B, F] -> logits [B]: the MLP runs on the cross network's output (stacked)."""
+    def forward(self, x, labels=None):
+        """x: int [B, F] -> logits [B]: the MLP runs on the cross network's output (stacked).
+        labels (optional extension, [B]): as DeepFM.forward's — the step's targets, for a caller about to evaluate
+        BCEWithLogitsLoss on the result."""
         _no_atomics_promised(self)
         _, fields = self._lookup(x)
-        return run_tail(self._dnn, self.cross_head(fields)).squeeze(-1)
+        return run_tail(self._dnn, self.cross_head(fields), labels=labels).squeeze(-1)
 
 
 class DCNv2(_FieldModel):
@@ -96,7 +103,7 @@ class DCNv2(_FieldModel):
         self._dnn = nn.Sequential(*stack)
         self._register_offsets(field_dims)
 
-    def forward(self, x):
+    def forward(self, x, labels=None):
         _no_atomics_promised(self)
         rows, fields = self._lookup(x)
         crossed = self.cross_head(fields)
@@ -109,6 +116,6 @@ class DCNv2(_FieldModel):
             if tail is None or len(tail) != len(self._dnn) + 1 or tail[-1] is not self._last_fc:
                 tail = nn.Sequential(*self._dnn, self._last_fc)
                 self.__dict__["_stacked_tail"] = tail          # (not a registered submodule: state_dict keys unchanged)
-            return run_tail(tail, crossed, last_add=first_order).squeeze(-1)
+            return run_tail(tail, crossed, last_add=first_order, labels=labels).squeeze(-1)
         features = torch.concat([crossed, run_tail(self._dnn, fields)], dim=1)
         return (self._last_fc(features) + first_order).squeeze(-1)

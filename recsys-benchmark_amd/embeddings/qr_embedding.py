@@ -75,9 +75,16 @@ class QRHashingEmbedding(IEmbedding):
         for w in self._tables():
             nn.init.normal_(w, std=std)
 
-    def forward(self, tensor: torch.Tensor):
+    def forward(self, tensor: torch.Tensor, offsets: Optional[torch.Tensor] = None):
+        """offsets (optional extension, [F]): `tensor` then holds the model's raw per-field ids [B, F] and the per-field
+        row offsets are added inside the lookup; returns (embeddings, row ids) — the reference's callers pass x + offsets
+        (src/models/dcn.py:204), an elementwise launch of its own on the GPU."""
         w1, w2 = self._tables()
         d = self._divider
+        if offsets is not None:
+            if not self.takes_offsets(tensor):
+                rows = tensor + offsets
+                return self.forward(rows), rows
         if self._mode is None:
             fields = None
             if self._field_dims is not None and tensor.dim() == 2 and tensor.shape[1] == len(self._field_dims):
@@ -87,13 +94,19 @@ class QRHashingEmbedding(IEmbedding):
                     self._hint = (tensor.device, _kernels.small_field_hint(self._field_dims, d, tensor.device))
                 fields = self._hint[1]
             return _kernels.dual_gather(tensor, w1, w2, mod1=d, div2=d, op=self._operation, fields=fields,
-                                        sparse2=self._sparse2)
+                                        sparse2=self._sparse2, offsets=offsets)
         # EmbeddingBag modes reduce each table's rows BEFORE the combine (two bags in the reference)
         bag1 = _kernels.bag_reduce(_kernels.gather_rows(tensor % d, w1), self._mode)
         bag2 = _kernels.bag_reduce(_kernels.gather_rows(tensor // d, w2), self._mode)
         if self._operation == "mult":
             return bag1 * bag2
         return bag1 + bag2 if self._operation == "add" else torch.cat([bag1, bag2], dim=1)
+
+    def takes_offsets(self, tensor: torch.Tensor) -> bool:
+        """Whether forward(tensor, offsets=...) folds the addition into the lookup kernel (float4 rows, [B, F] ids on the GPU)."""
+        De = self.emb1.weight.shape[1]
+        return bool(self._mode is None and tensor.is_cuda and tensor.dim() == 2 and 4 <= De <= 256 and De % 4 == 0
+                    and (De // 4) & (De // 4 - 1) == 0)
 
     def get_weight(self):
         return self(torch.arange(self._num_item, device=self.emb1.weight.device))

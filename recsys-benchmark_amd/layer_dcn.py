@@ -191,7 +191,10 @@ class _DCNMixFn(torch.autograd.Function):
             return flat[l * per + off: l * per + off + n].view(shape)
 
         later = []
-        dGs = [part(l, Er * d + E * r * r + E * d * r + d, (E, d)) for l in range(L)]
+        # the layers' shares of dG (one gate matrix serves every layer): all added into layer 0's slot by the split-K atomics
+        # of the one launch below — or, in deterministic mode, kept apart and summed in a fixed order afterwards
+        shared_dG = not _kernels.DETERMINISTIC
+        dGs = [part(0 if shared_dG else l, Er * d + E * r * r + E * d * r + d, (E, d)) for l in range(L)]
         for l in range(L - 1, -1, -1):
             gate, H1, H2, H2g, T = sv[5 * l: 5 * l + 5]
             xl = xs[l]
@@ -224,12 +227,16 @@ class _DCNMixFn(torch.autograd.Function):
                                        R2=dx0 if l == 0 else None, rowscale=dgate, nrs=E, bias=G):
                 gemm(dZ1, Vs[l], gn, M, d, r, Er, r, d, transB=True, kgroups=E, gA=r, gB=d * r,
                      epi="add", R1=g, ldr1=d, R2=dx0 if l == 0 else None, ldr2=d, rowscale=dgate, nrs=E, bias=G)
-            later.append(dict(A=dgate, B=xl, C=dGs[l], M=E, N=d, K=M, lda=E, ldb=d, ldc=d))     # layer l's share of dG
+            later.append(dict(A=dgate, B=xl, C=dGs[l], M=E, N=d, K=M, lda=E, ldb=d, ldc=d,         # layer l's share of dG
+                              **({"splitk": 8} if shared_dG else {})))                           # (>= 2 slices: atomic adds)
             grads[4 * l: 4 * l + 4] = [dU, dC, dV, db]
             g = gn
         _kernels.gemm_multi(later, transA=True)
         # the layers' shares, summed in a fixed order (one strided view of the flat buffer: a single reduction launch)
-        dG = torch.as_strided(flat, (L, E, d), (per, d, 1), Er * d + E * r * r + E * d * r + d).sum(0)
+        if shared_dG:
+            dG = dGs[0]
+        else:
+            dG = torch.as_strided(flat, (L, E, d), (per, d, 1), Er * d + E * r * r + E * d * r + d).sum(0)
         return (g, dG.view(E, d, 1), *grads)
 
 

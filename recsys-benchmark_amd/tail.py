@@ -268,9 +268,9 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
         zsize = (zsize + 3) // 4 * 4
     foff, boff, hoff, loff = {}, {}, None, None
     for i, L in enumerate(plan):
-        if stat_f[i]:
+        if stat_f[i]:                      # (fp64 sums: 4 R N floats, 8-byte aligned — zsize is a multiple of 4 floats here)
             foff[i] = zsize
-            zsize += R * 2 * L.lin.out_features
+            zsize += (R * 4 * L.lin.out_features + 3) // 4 * 4
     if stat_b:
         for i in range(k - 1):
             boff[i] = zsize
@@ -319,7 +319,7 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
         else:
             c = torch.empty((4, N), dtype=torch.float32, device=dev)          # mu, sc, be, rstd
             if stat_f[i]:
-                part = zeros[foff[i]: foff[i] + R * 2 * N]
+                part = zeros[foff[i]: foff[i] + R * 4 * N]
                 shift = torch.empty((N,), dtype=torch.float32, device=dev)
             else:
                 part = torch.empty(int(lib.mi_tail_part_elems(M, N)), dtype=torch.float32, device=dev)
@@ -553,21 +553,21 @@ class FusedTailFn(torch.autograd.Function):
     exactly zero gradient."""
 
     @staticmethod
-    def forward(ctx, plan, head, seed, x, last_add, *params):
+    def forward(ctx, plan, head, seed, x, last_add, labels, *params):
         k = len(plan)
         x = _kernels._f32c(x)
         Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
         w_head = _kernels._f32c(params[4 * k]).view(-1)
-        out, saved, st = _tail_forward(plan, seed, x, last_add, Ws, w_head, params[4 * k + 1])
+        out, saved, st = _tail_forward(plan, seed, x, last_add, Ws, w_head, params[4 * k + 1], labels=labels)
         ctx.st = st
         ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, *params)
-        dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[5:], need[4])
-        return (None, None, None, dx, dadd, *grads)
+        need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, labels, *params)
+        dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[6:], need[4])
+        return (None, None, None, dx, dadd, None, *grads)
 
 
 # The NEXT batch's ids, when the caller knows them (a DataLoader is one batch ahead of the step: DeepFM.prefetch_next(x)):
@@ -682,8 +682,8 @@ def _plan_params(plan, head):
 
 
 def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
-                   last_add: Optional[torch.Tensor]) -> torch.Tensor:
-    return FusedTailFn.apply(plan, head, seed, x, last_add, *_plan_params(plan, head))
+                   last_add: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return FusedTailFn.apply(plan, head, seed, x, last_add, labels, *_plan_params(plan, head))
 
 
 # DeepFM's lookup backward in the epilogue of the tail's first input-gradient product (MI_FUSED_FM_EPILOGUE=0: two nodes,
