@@ -645,7 +645,10 @@ def bench_c5(args, real_stdout):
         else:                      # what trainer.GraphedCFTrainStep runs: both as one autograd node, the last layer at the
             au, ai, reg = model.forward_with_reg_loss(adj, users, pos, neg,          # rows the losses read
                                                       batch_rows_only=not args.full_last_layer)
-        (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * reg).backward(one)
+        if args.separate_reg:
+            (bpr_loss_rows(au, ai, users, pos, neg) + 1e-4 * reg).backward(one)
+        else:                      # ... and loss = bpr + weight_decay * reg out of the BPR launch itself
+            bpr_loss_rows(au, ai, users, pos, neg, plus=reg, plus_weight=1e-4).backward(one)
 
     elapsed = time_graphed(step, args, world, dev)
     pkg.check_index_errors()

@@ -700,6 +700,14 @@ MI_API int mi_bpr_fwd(const float *U, const int64_t *ui, const float *P, const i
 MI_API int mi_bpr_fwd_armed(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                             const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                             int64_t nN, int32_t *err, float *sig, float *workspace, float *loss, void *stream);
+/* ... with another scalar term of the step's objective joined in: loss = BPR + plus_weight * plus[0] (plus nullable; the
+ * reference trainer's `loss = bpr + reg_weight * reg`, src/trainer/lightgcn.py:401-404, without a scale and an add launch).
+ * With plus, `loss` has TWO words: loss[0] the sum, loss[1] the bare BPR term (what a trainer logs); without, one.
+ * armed != 0: mi_bpr_fwd_armed's promise about the ticket word. */
+MI_API int mi_bpr_fwd_plus(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                           const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+                           float *sig, float *workspace, int32_t armed, const float *plus, float plus_weight,
+                           float *loss, void *stream);
 MI_API int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi,
                       const float *Nn, const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP,
                       int64_t nN, const float *sig, const float *g, float *dU, float *dP, float *dN,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mi_bpr_workspace_elems": [_i64],
     "mi_bpr_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _p, _p],
     "mi_bpr_fwd_armed": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _p, _p],
+    "mi_bpr_fwd_plus": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _i32, _p, ctypes.c_float, _p, _p],
     "mi_bpr_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p],
     "mi_mask_topk_rows": [_p, _i64, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p],
     "mi_rownorm_fwd": [_p, _i64, _i32, ctypes.c_float, _p, _p, _p],

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_bpr_fwd(
     const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
     const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
     int64_t B, int D, RowBounds nb, float *__restrict__ sig, float *__restrict__ part, unsigned *ticket,
-    float *__restrict__ loss) {
+    float *__restrict__ loss, const float *__restrict__ plus, float plus_w) {
   __shared__ float red[kWavesPerBlock];
   __shared__ bool last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(kBlock) void k_bpr_fwd(
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int j = 0; j < kWavesPerBlock; ++j) t += red[j];
-      loss[0] = t / (float)B;
+      // plus (nullable): another term of the step's objective (the trainer's reg_weight * get_reg_loss, a scalar an earlier
+      // launch wrote) joins here instead of through a scale launch and an add launch
+      loss[0] = t / (float)B + (plus ? plus_w * plus[0] : 0.f);
+      if (plus) loss[1] = t / (float)B;      // (the bare BPR term beside the sum: what a trainer logs)
       *ticket = 0;                         // re-armed for the next launch
     }
   }
@@ -333,7 +336,7 @@ int64_t mi_bpr_workspace_elems(int64_t B) {
 
 static int bpr_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
                const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
-               float *sig, float *workspace, float *loss, void *stream) {
+               float *sig, float *workspace, float *loss, void *stream, const float *plus = nullptr, float plus_w = 0.f) {
   if (B <= 0 || D <= 0) return MI_ERR_INVALID_ARG;
   if ((!ui && nU < B) || (!pi && nP < B) || (!ni && nN < B)) return MI_ERR_INVALID_ARG;
   const RowBounds nb{nU, nP, nN, err};
@@ -343,7 +346,7 @@ static int bpr_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, con
   if (zero_ticket && hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
   MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace,
-            reinterpret_cast<unsigned *>(workspace + grid), loss);
+            reinterpret_cast<unsigned *>(workspace + grid), loss, plus, plus_w);
   return launch_status();
 }
 
@@ -359,6 +362,13 @@ int mi_bpr_fwd_armed(const float *U, const int64_t *ui, const float *P, const in
                const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
                float *sig, float *workspace, float *loss, void *stream) {
   return bpr_fwd_impl(false, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, sig, workspace, loss, stream);
+}
+
+int mi_bpr_fwd_plus(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,
+                    const int64_t *ni, int64_t B, int32_t D, int64_t nU, int64_t nP, int64_t nN, int32_t *err,
+                    float *sig, float *workspace, int32_t armed, const float *plus, float plus_weight, float *loss,
+                    void *stream) {
+  return bpr_fwd_impl(!armed, U, ui, P, pi, Nn, ni, B, D, nU, nP, nN, err, sig, workspace, loss, stream, plus, plus_weight);
 }
 
 int mi_bpr_bwd(const float *U, const int64_t *ui, const float *P, const int64_t *pi, const float *Nn,

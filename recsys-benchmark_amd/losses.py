@@ -124,7 +124,9 @@ class _BPRFn(torch.autograd.Function):
     """-logsigmoid(u.p - u.n).mean() with u = U[ui], p = P[pi], n = Nn[ni] (None index = row b)."""
 
     @staticmethod
-    def forward(ctx, U, P, Nn, ui, pi, ni):
+    def forward(ctx, U, P, Nn, ui, pi, ni, plus=None, plus_weight: float = 1.0):
+        """plus (0-dim tensor, optional): loss = BPR + plus_weight * plus — another term of the objective joined in the
+        kernel's last workgroup instead of by a scale launch and an add launch."""
         dev = _lib.require_gpu(U, P, Nn)
         lib = _lib.load()
         U, P, Nn = _kernels._f32c(U), _kernels._f32c(P), _kernels._f32c(Nn)
@@ -138,18 +140,25 @@ class _BPRFn(torch.autograd.Function):
             raise ValueError("bpr_loss of an empty batch")
         sig = torch.empty(B, dtype=torch.float32, device=dev)
         ws, armed = _ticket_workspace("bpr", dev, lib.mi_bpr_workspace_elems(B))
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check((lib.mi_bpr_fwd_armed if armed else lib.mi_bpr_fwd)(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
-                                  _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
-                                  _lib.err_word(dev).data_ptr(), sig.data_ptr(), ws.data_ptr(), loss.data_ptr(),
-                                  _lib.stream_ptr(dev)), "mi_bpr_fwd")
+        loss = torch.empty(2 if plus is not None else 1, dtype=torch.float32, device=dev)
+        if plus is not None:
+            plus = _kernels._f32c(plus).view(1)
+        _lib.check(lib.mi_bpr_fwd_plus(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
+                                       _lib.ptr(idx[2]), B, D, U.shape[0], P.shape[0], Nn.shape[0],
+                                       _lib.err_word(dev).data_ptr(), sig.data_ptr(), ws.data_ptr(), int(armed),
+                                       _lib.ptr(plus), float(plus_weight), loss.data_ptr(), _lib.stream_ptr(dev)), "mi_bpr_fwd_plus")
         ctx.save_for_backward(U, P, Nn, sig, *[i for i in idx if i is not None])
         ctx.has_idx = [i is not None for i in idx]
         ctx.meta = (B, D)
+        ctx.plus_weight = float(plus_weight) if plus is not None else None
+        if plus is not None:          # (sum, bare BPR term): the second is for logging only
+            bare = loss[1]
+            ctx.mark_non_differentiable(bare)
+            return loss[0], bare
         return loss.view(())
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_bare=None):
         U, P, Nn, sig, *rest = ctx.saved_tensors
         it = iter(rest)
         idx = [next(it) if h else None for h in ctx.has_idx]
@@ -161,11 +170,20 @@ class _BPRFn(torch.autograd.Function):
         same = (idx[1] is not None and idx[2] is not None and need[1] and need[2]
                 and P.data_ptr() == Nn.data_ptr() and P.shape == Nn.shape)
         grads = []
+        # user and item tables that are the two row segments of ONE matrix (LightGCN's propagation returns them that way):
+        # their zero-filled gradients are two views of one buffer — one fill launch instead of two
+        joint = None
+        if (need[0] and need[1] and idx[0] is not None and idx[1] is not None and U.dim() == 2 and U.shape[1:] == P.shape[1:]
+                and U.is_contiguous() and P.is_contiguous() and P.data_ptr() == U.data_ptr() + U.numel() * 4
+                and U.untyped_storage().data_ptr() == P.untyped_storage().data_ptr()):
+            joint = torch.zeros((U.shape[0] + P.shape[0],) + tuple(U.shape[1:]), dtype=torch.float32, device=U.device)
         for k, (t, i) in enumerate(zip((U, P, Nn), idx)):
             if not need[k]:
                 grads.append(None)
             elif k == 2 and same:
                 grads.append(grads[1])
+            elif joint is not None and k < 2:
+                grads.append(joint[: U.shape[0]] if k == 0 else joint[U.shape[0]:])
             else:   # rows repeat under an index array: the kernel accumulates with atomics into zeros
                 grads.append(torch.zeros_like(t) if i is not None else torch.empty_like(t))
         _lib.check(_lib.load().mi_bpr_bwd(U.data_ptr(), _lib.ptr(idx[0]), P.data_ptr(), _lib.ptr(idx[1]), Nn.data_ptr(),
@@ -173,7 +191,23 @@ class _BPRFn(torch.autograd.Function):
                                           sig.data_ptr(), g.data_ptr(), _lib.ptr(grads[0]),
                                           _lib.ptr(grads[1]), _lib.ptr(grads[2]), _lib.stream_ptr(U.device)),
                    "mi_bpr_bwd")
-        return grads[0], grads[1], (None if same else grads[2]), None, None, None
+        gplus = None
+        if ctx.plus_weight is not None and need[6]:
+            # d loss / d plus = plus_weight * g: for the resident unit seed that is a constant, kept per (device, weight)
+            if g.data_ptr() == unit_scalar(g.device).data_ptr():
+                key = (str(g.device), ctx.plus_weight)
+                gplus = _weights.get(key)
+                if gplus is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        gplus = torch.full((), ctx.plus_weight, dtype=torch.float32, device=g.device)
+                    else:
+                        gplus = _weights[key] = torch.full((), ctx.plus_weight, dtype=torch.float32, device=g.device)
+            else:
+                gplus = (g * ctx.plus_weight).view(())
+        return grads[0], grads[1], (None if same else grads[2]), None, None, None, gplus, None
+
+
+_weights: dict = {}
 
 
 def bpr_loss(user_embs, pos_embs, neg_embs):
@@ -181,11 +215,17 @@ def bpr_loss(user_embs, pos_embs, neg_embs):
     return _BPRFn.apply(user_embs, pos_embs, neg_embs, None, None, None)
 
 
-def bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items):
+def bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items, plus=None, plus_weight: float = 1.0,
+                  return_parts: bool = False):
     """bpr_loss(index_select(all_user_emb, users), index_select(all_item_emb, pos), index_select(all_item_emb, neg))
     (src/trainer/lightgcn.py:395-399) without materialising the three gathered matrices; the gradients land in
-    dense table gradients like index_select's backward."""
-    return _BPRFn.apply(all_user_emb, all_item_emb, all_item_emb, users, pos_items, neg_items)
+    dense table gradients like index_select's backward.
+    plus / plus_weight (optional): returns BPR + plus_weight * plus — the trainer's `loss = loss + reg_weight * reg_loss`
+    (src/trainer/lightgcn.py:401-404) inside the same launch; return_parts: (that sum, the bare BPR term for the log)."""
+    if plus is None:
+        return _BPRFn.apply(all_user_emb, all_item_emb, all_item_emb, users, pos_items, neg_items)
+    total, bare = _BPRFn.apply(all_user_emb, all_item_emb, all_item_emb, users, pos_items, neg_items, plus, plus_weight)
+    return (total, bare) if return_parts else total
 
 
 class _RowSqFn(torch.autograd.Function):

@@ -338,7 +338,11 @@ class GraphedCFTrainStep:
                                                                                     batch_rows_only=True)
         else:
             all_user_emb, all_item_emb = self.model(self.adj)
-        rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items)
+        if fused:      # rec_loss + weight_decay * reg_loss out of the BPR launch itself (no scale / add launches)
+            rec_plus_reg, rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items,
+                                                          plus=reg_loss, plus_weight=self.weight_decay, return_parts=True)
+        else:
+            rec_loss = losses.bpr_loss_rows(all_user_emb, all_item_emb, users, pos_items, neg_items)
         zero = torch.zeros((), device=rec_loss.device)
         if not fused:
             reg_loss = self.model.get_reg_loss(users, pos_items, neg_items) if self.weight_decay > 0 else zero
@@ -350,7 +354,10 @@ class GraphedCFTrainStep:
             valid = torch.cat([losses.first_occurrence(users, all_user_emb.shape[0]),
                                losses.first_occurrence(pos_items, all_item_emb.shape[0])])
             cl_loss = losses.info_nce(view, view, 0.2, valid=valid) * self.info_nce_weight
-        loss = rec_loss + self.weight_decay * reg_loss + cl_loss
+        if fused:
+            loss = rec_plus_reg + cl_loss if self.info_nce_weight > 0 else rec_plus_reg
+        else:
+            loss = rec_loss + self.weight_decay * reg_loss + cl_loss
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward(self._one)
         self.optimizer.step()

@@ -126,6 +126,21 @@ def test_dcn_models_match_reference_golden(name):
     for k, ref in g.group("grad/").items():
         assert_close(named[k].grad, ref, 5e-4, 2e-5, k)
     pkg.check_index_errors()
+    if bool(g["training"]):
+        # the same step with the labels handed to the forward and the package's criterion: where the model's tail ends in the
+        # fused head (DCN-Mix, stacked DCNv2) head + criterion + head backward are one launch; same logits, same gradients
+        from recsys_benchmark_amd.losses import BCEWithLogitsLoss, unit_scalar
+
+        model.zero_grad(set_to_none=True)
+        logits2 = model(x, labels=y)
+        assert_close(logits2, g.t("logits"), 1e-4, 1e-5, "logits (labels in forward)")
+        loss = BCEWithLogitsLoss()(logits2, y)
+        want = torch.nn.functional.binary_cross_entropy_with_logits(g.t("logits"), g.t("y"))
+        assert abs(float(loss) - float(want)) <= 1e-5
+        loss.backward(unit_scalar(DEV))
+        for k, ref in g.group("grad/").items():
+            assert_close(named[k].grad, ref, 5e-4, 2e-5, k + " (labels in forward)")
+        pkg.check_index_errors()
 
 
 @pytest.mark.parametrize("M,N,E", [(4096, 352, 4), (37, 8, 1), (130, 416, 8), (5, 1024, 3)])

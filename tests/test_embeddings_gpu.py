@@ -97,6 +97,40 @@ def test_qr_row_form_gradient_of_the_quotient_table_is_the_dense_one(op):
         assert torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("op", ["mult", "add", "cat"])
+@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("D", [16, 12])
+def test_qr_lookup_that_adds_the_field_offsets_itself(op, sparse, D):
+    """QRHashingEmbedding(x, offsets=o) = (QRHashingEmbedding(x + o), x + o) — the model's `x + offsets`
+    (src/models/dcn.py:204) inside the lookup kernel (mi_dual_gather_fwd_off); D = 12 (three float4 per row: no vector
+    form) takes the fallback that adds first.  Same values and, on integer data, the same gradients bit for bit."""
+    gen = torch.Generator().manual_seed(21)
+    dims = [241, 8, 3697, 5, 31]
+    B = 300
+    off = torch.tensor([0] + dims[:-1]).cumsum(0)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+    res = {}
+    for inside in (False, True):
+        gen = torch.Generator().manual_seed(22)
+        emb = QRHashingEmbedding(dims, D, None, 2, op, sparse=sparse).to(DEV)
+        with torch.no_grad():
+            for w in (emb.emb1.weight, emb.emb2.weight):
+                w.copy_(torch.randint(-3, 4, w.shape, generator=gen).float())
+        if inside:
+            assert emb.takes_offsets(x.to(DEV)) == (D == 16)
+            out, rows = emb(x.to(DEV), offsets=off.to(DEV))
+            assert torch.equal(rows.cpu(), x + off) and not rows.requires_grad
+        else:
+            out = emb((x + off).to(DEV))
+        G = torch.randint(-2, 3, out.shape, generator=torch.Generator().manual_seed(5)).float()
+        (out * G.to(DEV)).sum().backward()
+        g2 = emb.emb2.weight.grad
+        res[inside] = (out.detach(), emb.emb1.weight.grad.clone(), g2.to_dense() if g2.is_sparse else g2.clone())
+    for a, b, what in zip(res[False], res[True], ("out", "g emb1", "g emb2")):
+        assert torch.equal(a, b), what
+    _lib.check_index_errors()
+
+
 def test_qr_bag_modes():
     gen = torch.Generator().manual_seed(1)
     for mode in ("sum", "mean"):

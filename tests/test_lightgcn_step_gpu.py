@@ -58,6 +58,41 @@ def test_bpr_loss_rows_equals_index_select_path():
     assert_close(hI.grad, I.grad, 1e-4, 1e-7, "dI")
 
 
+@pytest.mark.parametrize("seed_kind", ["unit", "scaled"])
+def test_bpr_loss_rows_with_the_regulariser_joined_in_and_the_tables_as_one_matrix(seed_kind):
+    """bpr_loss_rows(..., plus=reg, plus_weight=w) = bpr + w * reg (src/trainer/lightgcn.py:401-404) out of the BPR launch, the
+    bare BPR term beside it; user and item tables given as the two row segments of ONE matrix (what LightGCN's propagation
+    returns) get their gradients as views of one zero-filled buffer.  Seeded with the resident unit scalar (the trainer's
+    way: d loss / d reg is then a kept constant) and with an ordinary upstream gradient."""
+    from recsys_benchmark_amd.losses import unit_scalar
+
+    g = torch.Generator().manual_seed(11)
+    nu, ni, D, B, w = 300, 500, 64, 2048, 1e-2
+    both = torch.randn(nu + ni, D, generator=g)
+    users = torch.randint(0, nu, (B,), generator=g)
+    pos, neg = torch.randint(0, ni, (B,), generator=g), torch.randint(0, ni, (B,), generator=g)
+    r = torch.tensor(3.25, requires_grad=True)
+    cb = both.clone().requires_grad_(True)
+    U, I = cb[:nu], cb[nu:]
+    bare_ref = ro.bpr_loss(torch.index_select(U, 0, users), torch.index_select(I, 0, pos), torch.index_select(I, 0, neg))
+    ref = bare_ref + w * (r * r)
+    up = 1.0 if seed_kind == "unit" else 0.37
+    (ref * up).backward()
+    hb = both.to(DEV).requires_grad_(True)
+    hr = r.detach().to(DEV).requires_grad_(True)
+    hU, hI = hb[:nu], hb[nu:]
+    total, bare = bpr_loss_rows(hU, hI, users.to(DEV), pos.to(DEV), neg.to(DEV), plus=hr * hr, plus_weight=w, return_parts=True)
+    assert not bare.requires_grad
+    if seed_kind == "unit":
+        total.backward(unit_scalar(DEV))
+    else:
+        (total * up).backward()
+    assert_close(total, ref, 1e-5, 1e-6, "bpr + w reg")
+    assert_close(bare, bare_ref, 1e-5, 1e-6, "bare bpr")
+    assert_close(hb.grad, cb.grad, 1e-4, 1e-7, "d tables")
+    assert_close(hr.grad, r.grad, 1e-6, 1e-9, "d reg")
+
+
 def test_bpr_and_reg_rows_out_of_range_ids_touch_no_memory_and_are_flagged():
     """index_select raises in the reference (src/trainer/lightgcn.py:395-397); here a bad triple reads and adds nothing,
     counts as zero rows, and the sticky word turns into IndexError at the next check."""
