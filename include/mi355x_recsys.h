@@ -924,14 +924,15 @@ MI_API int mi_tail_head_bwd_s(const float *Z, int32_t ldz, const float *mu, cons
  * src/models/deepfm.py:100-105).  Per row m: out[m] = the logit (mi_tail_head_fwd_m), its loss term, g[m] =
  * (sigmoid(out[m]) - y[m]) / M (mi_bce_logits_fwd's dx_unit), DY / part / wpart as mi_tail_head_bwd_s(g) writes them
  * (sum_reps > 0 rows, zeroed by the caller).  loss_ws: fp32[mi_tail_head_bce_ws_elems(sum_reps)], ZEROED by the caller;
- * loss_ws[0] is the loss afterwards (the rest are per-replica partial sums and arrival counts).  The sums are those of an
- * upstream gradient of exactly 1: a backward that arrives with another gradient calls mi_tail_head_bwd_s (after zeroing
- * part / wpart again).  N <= 512.  stats as in mi_tail_head_fwd_m (NULL: mu / sc / be are read). */
+ * loss_ws[0] is the loss afterwards (the rest are per-replica partial sums and arrival counts).  g and the sums are those
+ * of the upstream gradient upstream[0] — a device scalar, the one the caller seeds the backward with (NULL: exactly 1; a
+ * table-sharded step seeds 1 / world) — a backward that arrives with another gradient calls mi_tail_head_bwd_s (after
+ * zeroing part / wpart again).  N <= 512.  stats as in mi_tail_head_fwd_m (NULL: mu / sc / be are read). */
 MI_API int32_t mi_tail_head_bce_ws_elems(int32_t sum_reps);
 MI_API int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                             const uint8_t *keep, const float *w, const float *b, const float *add, const float *y,
                             float *out, float *g, float *DY, float *part, float *wpart, int32_t sum_reps, float *loss_ws,
-                            int32_t M, int32_t N, const mi_tail_bn_fwd *stats, void *stream);
+                            int32_t M, int32_t N, const mi_tail_bn_fwd *stats, const float *upstream, void *stream);
 MI_API int mi_tail_bn_finalize_bwd(const float *part, int32_t nblk, int32_t M, int32_t N, const float *gamma,
                                    const float *rstd, float *dgamma, float *dbeta, float *al, float *bz, float *de,
                                    const float *wpart, int32_t nwblk, float *dw, float *db, void *stream);

@@ -145,7 +145,7 @@ SIGNATURES = {
     "mi_tail_head_bwd": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     "mi_tail_head_bwd_s": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_head_bce_ws_elems": [_i32],
-    "mi_tail_head_bce": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p],
+    "mi_tail_head_bce": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _p, _p],
     "mi_tail_bn_finalize_bwd": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "mi_tail_affine_consts": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "mi_tail_bn_finalize_bwd_a": [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _p, _p],

@@ -710,8 +710,8 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
 //   loss_ws: [0] the loss (mean), [4 .. 4 + reps) per-replica partial sums, [4 + reps .. 4 + 2 reps) arrival counts
 //   (uint32) — all zero at launch.  The workgroups of a replica add their partial, the last of them (ticket) moves the
 //   replica's sum into [0]: <= gridDim / reps adders per address at each level, no single word that every workgroup hits.
-// The sums assume an upstream gradient of exactly 1 (the criterion is the last op of a step); tail.py falls back to
-// k_tail_head_bwd when the backward arrives with anything else.
+// The sums are those of the upstream gradient upstream[0] (a device scalar the caller will seed the backward with; NULL: 1 —
+// the criterion is the last op of a step); tail.py falls back to k_tail_head_bwd when the backward arrives with anything else.
 constexpr int kHeadLossCols = 512;
 constexpr int kHeadLossRed = 3 * kHeadLossCols + 4;
 template <bool MERGE>
@@ -720,7 +720,8 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
                                                           float *__restrict__ out, float *__restrict__ gout,
                                                           float *__restrict__ DY, float *__restrict__ part,
                                                           float *__restrict__ wpart, float *__restrict__ loss_ws, int M,
-                                                          int N, BnFwd bn, int reps, int64_t *bump) {
+                                                          int N, BnFwd bn, int reps, int64_t *bump,
+                                                          const float *__restrict__ upstream) {
   __shared__ __attribute__((aligned(16))) float cst[MERGE ? 3 * kCstPitch : 4];
   __shared__ __attribute__((aligned(16))) float red[kWavesPerBlock][kHeadLossRed];
   if (bump && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
@@ -729,6 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
   const Drop drop = make_drop(x.keep, x.p, x.ld);
   const float bv = b ? b[0] : 0.f;
   const float inv_m = 1.f / (float)M;
+  const float gsc = upstream ? upstream[0] * inv_m : inv_m;      // d objective / d loss (a device scalar), over the mean's M
   const int c0 = lane * 4, c1 = lane * 4 + 256;
   const bool v0 = c0 < N, v1 = c1 < N;
   const float4 w0 = v0 ? ld4(w + c0) : zero4(), w1 = v1 ? ld4(w + c1) : zero4();
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
       s = wave_sum(s);
       const float xl = s + bv + av[u];
       // the criterion's own arithmetic (k_bce_logits_fwd / _bwd, cross.hip)
-      const float gm = inv_m * (1.f / (1.f + expf(-xl)) - yv[u]);
+      const float gm = gsc * (1.f / (1.f + expf(-xl)) - yv[u]);
       s_loss += fmaxf(xl, 0.f) - xl * yv[u] + log1pf(expf(-fabsf(xl)));
       s_g += gm;
       if (lane == 0) { out[m] = xl; gout[m] = gm; }
@@ -1376,7 +1378,7 @@ int32_t mi_tail_head_bce_ws_elems(int32_t sum_reps) { return sum_reps > 0 ? (4 +
 int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *sc, const float *be, float p,
                      const uint8_t *keep, const float *w, const float *b, const float *add, const float *y, float *out,
                      float *g, float *DY, float *part, float *wpart, int32_t sum_reps, float *loss_ws, int32_t M, int32_t N,
-                     const mi_tail_bn_fwd *stats, void *stream) {
+                     const mi_tail_bn_fwd *stats, const float *upstream, void *stream) {
   if (M <= 0 || N <= 0 || sum_reps <= 0 || sum_reps > 64) return MI_ERR_INVALID_ARG;
   BnFwd bn{};
   int64_t *bump = nullptr;
@@ -1397,10 +1399,10 @@ int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *
   const int grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (waves + kWavesPerBlock - 1) / kWavesPerBlock : 256;
   if (stats)
     MI_LAUNCH("tail_head_bce", (k_tail_head_bce<true>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws, M,
-              N, bn, sum_reps, (int64_t *)nullptr);
+              N, bn, sum_reps, (int64_t *)nullptr, upstream);
   else
     MI_LAUNCH("tail_head_bce", (k_tail_head_bce<false>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws,
-              M, N, bn, sum_reps, bump);
+              M, N, bn, sum_reps, bump, upstream);
   return launch_status();
 }
 

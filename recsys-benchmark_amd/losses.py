@@ -55,7 +55,8 @@ class _BCEFn(torch.autograd.Function):
 
 class _HeadBCEFn(torch.autograd.Function):
     """The criterion as the model's head launch already evaluated it (tail.mi_tail_head_bce: DeepFM.forward(x, labels=y)):
-    the loss and the gradient for an upstream 1 exist, nothing is launched either way.  Any other upstream gradient takes
+    the loss and the gradient for the upstream seed (the resident 1, or the scalar the caller named) exist, nothing is
+    launched either way.  Any other upstream gradient takes
     mi_bce_logits_bwd like _BCEFn (and the model's backward then runs its own head backward)."""
 
     @staticmethod
@@ -69,7 +70,7 @@ class _HeadBCEFn(torch.autograd.Function):
     def backward(ctx, g):
         head = ctx.head
         (x,) = ctx.saved_tensors
-        if g.data_ptr() == unit_scalar(x.device).data_ptr():
+        if g.data_ptr() == head.seed.data_ptr():       # the very scalar the head launch scaled its gradient by
             return head.gvec.view(ctx.shape), None
         g = _kernels._f32c(g).view(1)
         x = x.reshape(-1)

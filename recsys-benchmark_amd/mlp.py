@@ -291,12 +291,13 @@ def _groups(seq: nn.Sequential) -> List[List]:
 
 
 def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tensor] = None,
-             labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+             labels: Optional[torch.Tensor] = None, loss_seed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """last_add ([B], optional): added to the tail's [B,1] output inside its last kernel when that layer is a
     1-output Linear (DeepFM: scores = y_fm + deep(emb)); otherwise added with a plain op.
     labels ([B], optional): the step's targets when the caller goes on to BCEWithLogitsLoss(out.squeeze(-1), labels) — the
     fused tail's head launch then evaluates that criterion and the head's backward as well (tail.mi_tail_head_bce); ignored
-    everywhere else."""
+    everywhere else.  loss_seed (device scalar, optional): the gradient the caller will seed that criterion's backward with
+    (default: losses.unit_scalar — `loss.backward(unit_scalar(dev))`)."""
     dev = x.device
     groups = _groups(seq)
     if FUSED_TAIL and x.is_cuda:
@@ -305,7 +306,7 @@ def run_tail(seq: nn.Sequential, x: torch.Tensor, last_add: Optional[torch.Tenso
         plan = _tail.fused_tail_plan(seq, x, groups)
         if plan is not None:       # training-mode BatchNorm tail ending in Linear(., 1): one node over csrc/tail.hip
             return _tail.run_fused_tail(plan, groups[-1][1], _seed_word(dev), x, last_add,
-                                        labels if seq.training else None)
+                                        labels if seq.training else None, loss_seed)
     seed = _seed_word(dev)
     # one zero-filled workspace for every reduction target of this pass (forward statistics,
     # backward dgamma/dbeta, bias gradients): a single fill launch instead of one per buffer

@@ -50,8 +50,8 @@ class HipOps:
     slot_fm = staticmethod(_kernels.slot_fm)
 
     @staticmethod
-    def tail(deep_branch: nn.Sequential, x: torch.Tensor, y_fm: torch.Tensor) -> torch.Tensor:
-        return run_tail(deep_branch, x, last_add=y_fm).squeeze(-1)
+    def tail(deep_branch: nn.Sequential, x: torch.Tensor, y_fm: torch.Tensor, labels=None, loss_seed=None) -> torch.Tensor:
+        return run_tail(deep_branch, x, last_add=y_fm, labels=labels, loss_seed=loss_seed).squeeze(-1)
 
 
 def bucket_capacity(n: int, world: int, slack: float) -> int:
@@ -505,10 +505,14 @@ class ShardedDeepFM(nn.Module):
         self.fc_shard[n].zero_()
 
     # ---- the compute between the collectives ------------------------------------------------
-    def _local_compute(self, recv, slot):
-        """received packed rows + slots -> logits [B]: slot gather, FM, first-order term, MLP tail."""
+    def _local_compute(self, recv, slot, labels=None, loss_seed=None):
+        """received packed rows + slots -> logits [B]: slot gather, FM, first-order term, MLP tail.
+        labels / loss_seed (the graphed step): the targets and the scalar its backward is seeded with (1 / world) — the
+        tail's head launch then evaluates the BCE criterion and the head's backward as well (mlp.run_tail)."""
         emb, y_fm = self.ops.slot_fm(recv, slot, self._bias)
-        return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm)
+        if labels is None:
+            return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm)
+        return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm, labels, loss_seed)
 
     def enable_graphs(self, batch_size: int):
         """Capture the local compute (forward AND backward) for a fixed batch size as hipGraphs
@@ -570,8 +574,12 @@ class ShardedDeepFM(nn.Module):
         # gradients arrive already averaged and the dense ones only need a SUM all-reduce
         seed_grad = torch.full((), 1.0 / self.world, device=dev)
 
+        from . import losses as _losses
+        in_head = isinstance(criterion, _losses.BCEWithLogitsLoss) and self.ops is HipOps      # (the gloo tests' CPU ops take no labels)
+
         def local():
-            loss = criterion(self._local_compute(recv, slot), ys)
+            logits = self._local_compute(recv, slot, ys, seed_grad) if in_head else self._local_compute(recv, slot)
+            loss = criterion(logits, ys)
             grads = torch.autograd.grad(loss, [recv] + dense, grad_outputs=seed_grad)
             return loss, grads[0], torch.cat([g.reshape(-1) for g in grads[1:]])
 

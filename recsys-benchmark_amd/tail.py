@@ -218,7 +218,7 @@ class _Lead:
 class _HeadLoss:
     """What mi_tail_head_bce left for the criterion: losses.BCEWithLogitsLoss(logits, labels) picks it up when it is handed
     exactly these logits and labels (take_head_loss), otherwise computes the loss itself."""
-    __slots__ = ("out", "y", "y_key", "loss", "gvec")
+    __slots__ = ("out", "y", "y_key", "loss", "gvec", "seed")
 
 
 _HEAD_LOSS = {}
@@ -240,10 +240,11 @@ def take_head_loss(logits: torch.Tensor, target: torch.Tensor):
     return None
 
 
-def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_Lead] = None, labels=None):
+def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_Lead] = None, labels=None, loss_seed=None):
     """The forward kernels of the tail; returns (out[M, 1], tensors to save, state).  lead (instead of x / last_add): the
     launch that produces them, run here once the mask job it carries is known.  labels ([M] fp32, optional): the head
-    launch also evaluates BCE-with-logits against them and the head's backward sums (state.head)."""
+    launch also evaluates BCE-with-logits against them and the head's backward sums (state.head) for the upstream gradient
+    loss_seed (a device scalar: what the caller will seed the criterion's backward with; None: losses.unit_scalar)."""
     lib = _lib.load()
     dev = lead.dev if lead is not None else _lib.require_gpu(x)
     s = _lib.stream_ptr(dev)
@@ -374,12 +375,20 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
         head.out, head.y, head.y_key = out, y, _label_key(labels)
         head.gvec = torch.empty((M,), dtype=torch.float32, device=dev)
         head.loss = zeros[loff: loff + 1]
+        if loss_seed is None:
+            from .losses import unit_scalar
+
+            head.seed = unit_scalar(dev)
+        else:
+            if loss_seed.numel() != 1 or loss_seed.dtype != torch.float32 or loss_seed.device != dev:
+                raise ValueError("loss_seed must be a float32 device scalar")
+            head.seed = loss_seed
         DY = torch.empty((M, N), dtype=torch.float32, device=dev)
         _lib.check(lib.mi_tail_head_bce(
             prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(), float(prev_p), _lib.ptr(prev_bits),
             w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add), y.data_ptr(), out.data_ptr(), head.gvec.data_ptr(), DY.data_ptr(),
             zeros[hoff:].data_ptr(), zeros[hoff + Rh * 2 * N:].data_ptr(), Rh, zeros[loff:].data_ptr(), M, N,
-            ctypes.byref(stats) if stats is not None else None, s), "mi_tail_head_bce")
+            ctypes.byref(stats) if stats is not None else None, _lib.ptr(loss_seed), s), "mi_tail_head_bce")
         _HEAD_LOSS[str(dev)] = head
     else:
         _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
@@ -553,21 +562,21 @@ class FusedTailFn(torch.autograd.Function):
     exactly zero gradient."""
 
     @staticmethod
-    def forward(ctx, plan, head, seed, x, last_add, labels, *params):
+    def forward(ctx, plan, head, seed, x, last_add, labels, loss_seed, *params):
         k = len(plan)
         x = _kernels._f32c(x)
         Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
         w_head = _kernels._f32c(params[4 * k]).view(-1)
-        out, saved, st = _tail_forward(plan, seed, x, last_add, Ws, w_head, params[4 * k + 1], labels=labels)
+        out, saved, st = _tail_forward(plan, seed, x, last_add, Ws, w_head, params[4 * k + 1], labels=labels, loss_seed=loss_seed)
         ctx.st = st
         ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, labels, *params)
-        dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[6:], need[4])
-        return (None, None, None, dx, dadd, None, *grads)
+        need = ctx.needs_input_grad           # (plan, head, seed, x, last_add, labels, loss_seed, *params)
+        dx, dadd, grads, _ = _tail_backward(ctx.st, ctx.saved_tensors, g, need[3], need[7:], need[4])
+        return (None, None, None, dx, dadd, None, None, *grads)
 
 
 # The NEXT batch's ids, when the caller knows them (a DataLoader is one batch ahead of the step: DeepFM.prefetch_next(x)):
@@ -682,8 +691,9 @@ def _plan_params(plan, head):
 
 
 def run_fused_tail(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, x: torch.Tensor,
-                   last_add: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return FusedTailFn.apply(plan, head, seed, x, last_add, labels, *_plan_params(plan, head))
+                   last_add: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None,
+                   loss_seed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return FusedTailFn.apply(plan, head, seed, x, last_add, labels, loss_seed, *_plan_params(plan, head))
 
 
 # DeepFM's lookup backward in the epilogue of the tail's first input-gradient product (MI_FUSED_FM_EPILOGUE=0: two nodes,
