@@ -12,6 +12,7 @@ import pytest
 import torch
 from torch import nn
 
+from conftest import assert_close
 from tail_helpers import tail_keep_scale
 
 from recsys_benchmark_amd import mlp as _mlp
@@ -247,6 +248,41 @@ def test_fused_tail_is_bit_reproducible_and_graph_capturable(monkeypatch):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, a[0]) and torch.equal(xs.grad, a[1])
+
+
+@pytest.mark.parametrize("seed_value", [None, 0.25])
+@pytest.mark.parametrize("M,K,hidden,p", [(4096, 416, [400, 400, 400], 0.5), (300, 64, [96], 0.0), (64, 32, [512, 32], 0.3)])
+def test_head_launch_with_the_criterion_and_a_named_upstream_seed(M, K, hidden, p, seed_value):
+    """run_tail(..., labels=y, loss_seed=s): the head launch evaluates BCE-with-logits and the head's backward for an
+    upstream gradient s (a device scalar; None = the resident 1) — the table-sharded step seeds 1 / world.  Against the same
+    step with the labels withheld, the criterion as its own launch and the same seed, on the same dropout seed."""
+    from recsys_benchmark_amd.losses import BCEWithLogitsLoss, unit_scalar
+
+    torch.manual_seed(M + K)
+    seq0 = _seq(K, hidden, p).train()
+    x = torch.randn(M, K)
+    add = torch.randn(M)
+    y = (torch.rand(M) < 0.4).float()
+    dev = torch.device(DEV, 0)
+    up = unit_scalar(dev) if seed_value is None else torch.full((), seed_value, device=dev)
+    res = {}
+    for fused in (True, False):
+        seq = copy.deepcopy(seq0).to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        yd, ad = y.to(DEV), add.to(DEV).requires_grad_(True)
+        _mlp._seed_word(dev).fill_(1234)
+        out = run_tail(seq, xd, last_add=ad, labels=yd if fused else None, loss_seed=up if (fused and seed_value is not None) else None)
+        loss = BCEWithLogitsLoss()(out.squeeze(-1), yd)
+        assert (type(loss.grad_fn).__name__ == "_HeadBCEFnBackward") == fused
+        loss.backward(up)
+        res[fused] = (out.detach(), loss.detach(), xd.grad, ad.grad, [q.grad for q in seq.parameters()])
+    a, b = res[True], res[False]
+    assert_close(a[0], b[0], 1e-5, 1e-6, "logits")
+    assert_close(a[1], b[1], 1e-5, 1e-6, "loss")
+    assert_close(a[2], b[2], 2e-4, 1e-7, "dx")
+    assert_close(a[3], b[3], 1e-5, 1e-9, "d last_add")
+    for u, v, (name, _) in zip(a[4], b[4], copy.deepcopy(seq0).named_parameters()):
+        assert_close(u, v, 2e-4, 1e-6 + 2e-8 * M, name)
 
 
 def test_fused_tail_default_and_deterministic_weight_gradients_agree():
