@@ -18,6 +18,8 @@
 // float4; a wave-instruction covers RS = 64/LPR lookups.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -804,7 +806,8 @@ int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float 
       aligned16(g2vals)) {
     const int lpr = De / 4;
     int64_t fg = (n * lpr / 2 + kBlock - 1) / kBlock;          // two lookups per thread and trip
-    if (fg > 512) fg = 512;
+    static const int cap = [] { const char *e = getenv("MI_DUAL_ROWS_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 512; }();
+    if (fg > cap) fg = cap;
     if (fg < 1) fg = 1;
     float *ws = (workspace && n1 * De <= kBlock && kBlock % (n1 * De) == 0) ? workspace : nullptr;
 #define CALL(LPR) MI_LAUNCH("dual_gather_bwd_rows", (k_dual_bwd_rows4<LPR>), (int)fg, kBlock, stream, idx, t, g_out, gT1, g2vals, rows2, n, F, op, ws)

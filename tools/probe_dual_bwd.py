@@ -21,11 +21,12 @@ T2 = torch.randn((N + 1) // 2, D, device=dev, requires_grad=True)
 G = torch.randn(B, len(AVAZU), D, device=dev)
 hint = _kernels.small_field_hint(AVAZU, 2, dev)
 cases["avazu fields + the small-field hint"] = ids_f
+cases["avazu fields, quotient table's gradient in row form (MI_DUAL_ROWS_GRID=%s)" % os.environ.get("MI_DUAL_ROWS_GRID", "512")] = ids_f
 for name, ids in cases.items():
     ids = ids.to(dev)
     fields = hint if "hint" in name else None
     def run():
-        out = _kernels.dual_gather(ids, T1, T2, mod1=2, div2=2, op="mult", fields=fields)
+        out = _kernels.dual_gather(ids, T1, T2, mod1=2, div2=2, op="mult", fields=fields, sparse2="row form" in name)
         out.backward(G)
         T1.grad = None; T2.grad = None
     for _ in range(3):
