@@ -44,5 +44,6 @@ else
   python3 $R/tools/pmc_pair_summarise.py $O/pair > $O/${tag}_pair_traffic.txt 2>&1; cat $O/${tag}_pair_traffic.txt
   rm -rf $O/pair
   bash $R/tools/pmc_c5.sh $tag/spmm > $O/pmc_c5.log 2>&1; cp $O/spmm/spmm_counters.txt $O/${tag}_spmm_counters.txt 2>/dev/null
+  cd $R && bash $R/tools/pmc_tail.sh $tag > $O/pmc_tail.log 2>&1; cp $R/gpurun_out/pmc/$tag.summary.csv $O/${tag}_tail_sq_counters.csv 2>/dev/null
 fi
 echo done

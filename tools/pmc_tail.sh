@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$R/gpurun_out/pmc/_$tag.*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "k_tail_fwd" in n or "k_tail_dgrad" in n or "k_gemm_f32_multi" in n or "k_gemm_tn_multi" in n:
+        if "k_tail_fwd" in n or "k_tail_dgrad" in n or "k_tail_head" in n or "k_gemm_f32_multi" in n or "k_gemm_tn_multi" in n:
             acc[re.search(r"(k_\\w+(<[^>]*>)?)", n).group(1).replace(",", ";")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$R/gpurun_out/pmc/$tag.summary.csv", "w") as out:
     names = sorted({c for k in acc.values() for c in k})
