@@ -863,6 +863,15 @@ MI_API int mi_tail_dgrad_gemm_fm(const float *DY, const float *Zl, int32_t ld, c
                                  float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
                                  const float *emb, const float *emb_sum, const float *g_y, float *g1vals, int32_t D,
                                  void *stream);
+/* ... for the table-sharded lookup (mi_slot_fm_fwd's operands: rows gathered out of a receive buffer of packed
+ * {D embedding floats, first-order weight, 3 pad} rows at row slot[m, f]): gbuf fp32[nrows, D + 4] is that buffer's gradient,
+ * row slot[m, f] receives the embedding part and g_y[m] at column D — mi_slot_fm_bwd in the epilogue.  Rows no sample
+ * points at keep what the caller put there (zeros: they travel back to owners as padding). */
+MI_API int mi_tail_dgrad_gemm_fm_slot(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
+                                      const float *bz, const float *de, const float *W, int32_t ldw, float *gbuf,
+                                      float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
+                                      const float *emb, const float *emb_sum, const float *g_y, const int64_t *slot,
+                                      int32_t D, void *stream);
 MI_API int mi_tail_dropout_masks(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps,
                                  const int32_t *lds, uint8_t *const *bits, int32_t M, void *stream);
 /* the same launch also zero-fills zero_buf[0 .. zero_floats) (a multiple of 4 floats, 16-byte aligned): the backward pass's
@@ -900,7 +909,8 @@ MI_API int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, co
 /* The gather + FM forward (mi_gather_fm_fwd_sum) carrying the same job in extra workgroups at the end of its grid: in
  * DeepFM's fused step (src/models/deepfm.py:79-105) it is the first kernel of the step — every reader of the keep bits
  * and every adder into zero_buf is launched later — so the tail needs no mask launch and no finalize launch to carry one.
- * ride == NULL: mi_gather_fm_fwd_sum.  A gather form without the extra workgroups (D % 4, F > 64, unaligned) runs the job
+ * ride == NULL: mi_gather_fm_fwd_sum.  offsets may be NULL (ids used as they are: the sharded step's slot lookup, W / w1 the
+ * receive buffer and its column D, ldw = ldw1 = D + 4).  A gather form without the extra workgroups (D % 4, F > 64, unaligned) runs the job
  * as a launch of its own first.  The seed must be advanced by a LATER kernel. */
 MI_API int mi_gather_fm_fwd_ride(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
                                  int64_t ldw1, const float *bias, float *emb_out, float *yfm_out, int64_t *rows_out,

@@ -135,6 +135,7 @@ SIGNATURES = {
     "mi_tail_dgrad_gemm_m": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
                              _i32, _p, _p, _i32, _i32, _i32, _p, _p],
     "mi_tail_dgrad_gemm_fm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p],
+    "mi_tail_dgrad_gemm_fm_slot": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p],
     "mi_tail_part_elems": [_i32, _i32],
     "mi_tail_bn_finalize_fwd": [_p, _i32, _i32, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p,
                                 _p, _p],

@@ -665,8 +665,8 @@ int mi_gather_fm_fwd_ride(const int64_t *idx, const int64_t *offsets, const floa
   r.zero4 = reinterpret_cast<float4 *>(ride->zero_buf);
   r.nzero4 = ride->zero_floats / 4;
   const int lpr = D / 4, nit = vec_ok(D) ? nit_for(F, lpr) : 0;
-  const bool fits = B > 0 && idx && offsets && W && w1 && emb_out && yfm_out && vec_ok(D) && aligned16(W) && (ldw & 3) == 0 &&
-                    aligned16(emb_out) && nit > 0 && F <= kWave;
+  const bool fits = B > 0 && idx && W && w1 && emb_out && yfm_out && vec_ok(D) && aligned16(W) && (ldw & 3) == 0 &&
+                    aligned16(emb_out) && nit > 0 && F <= kWave;      // (offsets may be NULL: slot lookups, mi_slot_fm_fwd's operands)
   if (extra == 0 || !fits) {      // nothing to carry, or a gather form without the extra workgroups: two launches
     if (extra > 0) {
       MI_LAUNCH("tail_dropout_masks", k_mask_job, (int)extra, kBlock, stream, r);

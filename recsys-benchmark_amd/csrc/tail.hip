@@ -978,6 +978,12 @@ struct DgradArgs {
   const float *fm_gy;    // [M] dL/d y_fm
   float *fm_g1;          // [M, K / fm_D] first-order gradient values (nullable)
   int fm_D;
+  // ... and for the table-sharded lookup (sharded.py): the rows came out of a receive buffer of packed rows
+  // {fm_D embedding floats, first-order weight, pad} at row slot[m, f]; the gradient goes back the same way — OUT is that
+  // buffer's gradient (pitch fm_pitch), row slot[m, f] gets the embedding part at [0, fm_D) and gy[m] at [fm_D]
+  // (mi_slot_fm_bwd in this epilogue; slots no sample points at are left as the caller zeroed them)
+  const int64_t *fm_slot;   // [M, K / fm_D], nullable
+  int fm_pitch;
 };
 
 template <bool DZ, bool MID, bool MERGE, bool FM = false>
@@ -1021,6 +1027,7 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
     // arithmetic: one round trip for the epilogue
     float4 e[4], sm[4], da[4];
     float gy[4];
+    int64_t sl[4] = {0, 0, 0, 0};
     bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1031,6 +1038,7 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
       sm[k] = ld4(a.fm_sum + (int64_t)m * a.fm_D + kc % a.fm_D);
       gy[k] = a.fm_gy[m];
       da[k] = ld4(T + (ok[k] ? row : 0) * kTilePitch + (ok[k] ? c : 0));
+      if (a.fm_slot) sl[k] = a.fm_slot[(int64_t)m * (a.K / a.fm_D) + kc / a.fm_D];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1041,7 +1049,14 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
         o.y = da[k].y + gy[k] * (sm[k].y - e[k].y);
         o.z = da[k].z + gy[k] * (sm[k].z - e[k].z);
         o.w = da[k].w + gy[k] * (sm[k].w - e[k].w);
-        st4(a.OUT + (int64_t)(m0 + row) * a.ldo + k0 + c, o);
+        if (a.fm_slot) {
+          float *dst = a.OUT + sl[k] * a.fm_pitch;
+          const int d = (k0 + c) % a.fm_D;
+          st4(dst + d, o);
+          if (d == 0) dst[a.fm_D] = gy[k];          // (the chunk that opens a field also writes its first-order value)
+        } else {
+          st4(a.OUT + (int64_t)(m0 + row) * a.ldo + k0 + c, o);
+        }
       }
     }
     if (a.fm_g1 && nt == 0) {      // the first-order table's gradient values of this row tile: gy[m] for every field
@@ -1458,7 +1473,7 @@ static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const floa
                         const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
                         float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
                         const float *fm_emb, const float *fm_sum, const float *fm_gy, float *fm_g1, int32_t fm_D,
-                        int32_t part_reps, void *stream);
+                        int32_t part_reps, void *stream, const int64_t *fm_slot = nullptr);
 
 int mi_tail_dgrad_gemm_m(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
                          const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
@@ -1489,18 +1504,29 @@ int mi_tail_dgrad_gemm_fm(const float *DY, const float *Zl, int32_t ld, const fl
                       nullptr, dz_out, M, N, K, sums, emb, emb_sum, g_y, g1vals, D, 0, stream);
 }
 
+int mi_tail_dgrad_gemm_fm_slot(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
+                               const float *de, const float *W, int32_t ldw, float *gbuf, float *dz_out, int32_t M, int32_t N,
+                               int32_t K, const mi_tail_bn_bwd *sums, const float *emb, const float *emb_sum, const float *g_y,
+                               const int64_t *slot, int32_t D, void *stream) {
+  if (!emb || !emb_sum || !g_y || !slot || !gbuf || D <= 0 || D % 4 || K % D) return MI_ERR_INVALID_ARG;
+  if (!aligned16(emb) || !aligned16(emb_sum) || !aligned16(gbuf)) return MI_ERR_UNSUPPORTED;
+  return dgrad_launch(DY, Zl, ld, mu, al, bz, de, W, ldw, nullptr, K, nullptr, nullptr, nullptr, 0.f, nullptr, gbuf, D + 4,
+                      nullptr, dz_out, M, N, K, sums, emb, emb_sum, g_y, nullptr, D, 0, stream, slot);
+}
+
 static int dgrad_launch(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al, const float *bz,
                         const float *de, const float *W, int32_t ldw, const float *pZ, int32_t pld, const float *p_mu,
                         const float *p_sc, const float *p_be, float p_p, const uint8_t *p_keep, float *OUT, int32_t ldo,
                         float *part, float *dz_out, int32_t M, int32_t N, int32_t K, const mi_tail_bn_bwd *sums,
                         const float *fm_emb, const float *fm_sum, const float *fm_gy, float *fm_g1, int32_t fm_D,
-                        int32_t part_reps, void *stream) {
+                        int32_t part_reps, void *stream, const int64_t *fm_slot) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
   if (!DY || !W || !OUT) return MI_ERR_INVALID_ARG;
   DgradArgs a;
   a.part_rep = part_reps;
   a.fm_emb = fm_emb; a.fm_sum = fm_sum; a.fm_gy = fm_gy; a.fm_g1 = fm_g1; a.fm_D = fm_D;
+  a.fm_slot = fm_slot; a.fm_pitch = fm_D + 4;
   a.bn = BnBwd{};
   if (sums) {               // al / bz / de are joined from the column sums in the kernel's prologue and written to sums->al ...
     if (N > kCstPitch) return MI_ERR_UNSUPPORTED;

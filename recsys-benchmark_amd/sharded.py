@@ -509,10 +509,30 @@ class ShardedDeepFM(nn.Module):
         """received packed rows + slots -> logits [B]: slot gather, FM, first-order term, MLP tail.
         labels / loss_seed (the graphed step): the targets and the scalar its backward is seeded with (1 / world) — the
         tail's head launch then evaluates the BCE criterion and the head's backward as well (mlp.run_tail)."""
+        fused = self._fused_local(recv, slot, labels, loss_seed)
+        if fused is not None:
+            return fused
         emb, y_fm = self.ops.slot_fm(recv, slot, self._bias)
         if labels is None:
             return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm)
         return self.ops.tail(self._deep_branch, emb.reshape(slot.shape[0], -1), y_fm, labels, loss_seed)
+
+    def _fused_local(self, recv, slot, labels, loss_seed):
+        """The local compute as ONE autograd node (tail.SlotDeepFMFusedFn) when the fused tail takes the MLP: the slot lookup
+        carries the tail's dropout bits and zero fill, the lookup's backward runs in the epilogue of the tail's first
+        input-gradient product and writes straight into the receive buffer's gradient.  None: the two-node path."""
+        from . import mlp as _mlp, tail as _tail
+
+        D = recv.shape[1] - 4
+        if not (self.ops is HipOps and _mlp.FUSED_TAIL and _tail.FM_EPILOGUE and torch.is_grad_enabled() and recv.is_cuda
+                and recv.requires_grad and slot.dim() == 2 and D >= 4 and D % 4 == 0 and (D // 4) & (D // 4 - 1) == 0 and D <= 256):
+            return None
+        groups = _mlp._groups(self._deep_branch)
+        plan = _tail.fused_tail_plan(self._deep_branch, _tail._InputSpec(slot.shape[0], slot.shape[1] * D, recv.device), groups)
+        if plan is None:
+            return None
+        return _tail.run_fused_slot_deepfm(plan, groups[-1][1], _mlp._seed_word(recv.device), recv, slot, self._bias,
+                                           labels if self.training else None, loss_seed).squeeze(-1)
 
     def enable_graphs(self, batch_size: int):
         """Capture the local compute (forward AND backward) for a fixed batch size as hipGraphs

@@ -194,7 +194,8 @@ def _fixed_constants(plan: List[_Layer], dev, stream):
 
 class _State:
     """What the forward leaves for the backward: tensors (flattened for ctx.save_for_backward) + plain metadata."""
-    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat_b", "zsize", "boff", "hoff", "head")
+    __slots__ = ("k", "ps", "has_head_bias", "add_shape", "zeros", "plan", "n_saved", "stat_b", "zsize", "boff", "hoff", "head",
+                 "extra")
 
 
 # The gather + FM forward in front of DeepFM's tail carries the keep bits and the zero fill (mi_gather_fm_fwd_ride): the
@@ -208,11 +209,12 @@ HEAD_LOSS = os.environ.get("MI_TAIL_HEAD_LOSS", "1") == "1"
 
 class _Lead:
     """The kernel in front of the tail that produces its input (DeepFM: gather + FM): `launch(job)` runs it — carrying the
-    mask job (a mi_tail_mask_ride or None) — and returns (x[M, K], last_add or None)."""
-    __slots__ = ("M", "dev", "launch")
+    mask job (a mi_tail_mask_ride or None) — and returns (x[M, K], last_add or None).  extra_zero: floats the step's
+    zero-filled buffer should hold for the caller besides the tail's own accumulators (state.extra)."""
+    __slots__ = ("M", "dev", "launch", "extra_zero")
 
-    def __init__(self, M, dev, launch):
-        self.M, self.dev, self.launch = M, dev, launch
+    def __init__(self, M, dev, launch, extra_zero: int = 0):
+        self.M, self.dev, self.launch, self.extra_zero = M, dev, launch, int(extra_zero)
 
 
 class _HeadLoss:
@@ -282,6 +284,10 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
         if head_loss:
             loff = zsize
             zsize += int(lib.mi_tail_head_bce_ws_elems(Rh))
+    eoff = None
+    if lead is not None and lead.extra_zero > 0 and grad:
+        eoff = zsize
+        zsize += (lead.extra_zero + 3) // 4 * 4
     zeros = torch.empty((zsize,), dtype=torch.float32, device=dev) if zsize else None
     # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that launch
     # exists (a training-mode BatchNorm on the first layer) and a LATER kernel can advance the seed
@@ -398,6 +404,7 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
     st = _State()
     st.k, st.plan, st.zeros = k, plan, zeros
     st.head = (head.gvec, DY) if head is not None else None
+    st.extra = zeros[eoff: eoff + lead.extra_zero] if eoff is not None else None
     st.stat_b, st.zsize, st.boff, st.hoff = stat_b, zsize, boff, hoff
     st.ps = [L.p for L in plan]
     st.has_head_bias = b_head is not None
@@ -508,7 +515,15 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
                 npart = zeros[st.boff[i - 1]: st.boff[i - 1] + R * 2 * K]
             else:
                 npart = torch.empty(int(lib.mi_tail_part_elems(M, K)), dtype=torch.float32, device=dev) if i > 0 else None
-            if i == 0 and fm is not None:
+            if i == 0 and fm is not None and len(fm) == 5:      # the sharded step: rows go back into the receive buffer's gradient
+                emb_sum, _, D, slot, gbuf = fm
+                OUT = gbuf
+                _lib.check(lib.mi_tail_dgrad_gemm_fm_slot(
+                    DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
+                    Ws[i].data_ptr(), K, gbuf.data_ptr(), _lib.ptr(dz_keep), M, N, K,
+                    ctypes.byref(sums) if sums is not None else None, x.data_ptr(), emb_sum.data_ptr(), gvec.data_ptr(),
+                    slot.data_ptr(), D, s), "mi_tail_dgrad_gemm_fm_slot")
+            elif i == 0 and fm is not None:
                 emb_sum, g1vals, D = fm
                 _lib.check(lib.mi_tail_dgrad_gemm_fm(
                     DY.data_ptr(), Zs[i].data_ptr(), N, c[0].data_ptr(), dzc[0].data_ptr(), dzc[1].data_ptr(), dzc[2].data_ptr(),
@@ -683,6 +698,60 @@ class DeepFMFusedFn(torch.autograd.Function):
         return (None, None, None, None, None, gW, gw1, gb, None, None, None, *grads)
 
 
+class SlotDeepFMFusedFn(torch.autograd.Function):
+    """DeepFMFusedFn for the table-sharded step (sharded.ShardedDeepFM._local_compute): the rows come out of the receive
+    buffer `recv` fp32[S + 1, D + 4] of packed {D embedding floats, first-order weight, pad} rows at row slot[b, f]
+    (mi_slot_fm_fwd's operands) and their gradient goes back as that buffer's gradient — written by the epilogue of the
+    tail's first input-gradient product (mi_tail_dgrad_gemm_fm_slot) into a buffer the step's one zero fill has cleared
+    (padding slots travel back to their owners as zeros).  The lookup launch carries the tail's dropout bits and zero fill."""
+
+    @staticmethod
+    def forward(ctx, plan, head, seed, recv, slot, bias, labels, loss_seed, *params):
+        dev = _lib.require_gpu(recv, slot)
+        lib = _lib.load()
+        if recv.dtype != torch.float32 or not recv.is_contiguous() or recv.dim() != 2:
+            raise ValueError("recv must be a contiguous fp32 [rows, D + 4] buffer")
+        slot = _kernels._i64c(slot)
+        B, F = slot.shape
+        rows, D = recv.shape[0], recv.shape[1] - 4
+        emb = torch.empty((B, F * D), dtype=torch.float32, device=dev)
+        yfm = torch.empty((B,), dtype=torch.float32, device=dev)
+        esum = torch.empty((B, D), dtype=torch.float32, device=dev)
+
+        def gather(job):
+            _lib.check(lib.mi_gather_fm_fwd_ride(slot.data_ptr(), None, recv.data_ptr(), D + 4, recv.data_ptr() + 4 * D, D + 4,
+                                                 _lib.ptr(bias), emb.data_ptr(), yfm.data_ptr(), None, esum.data_ptr(),
+                                                 B, F, D, rows, _lib.err_word(dev).data_ptr(),
+                                                 ctypes.byref(job) if job is not None else None, _lib.stream_ptr(dev)),
+                       "mi_gather_fm_fwd_ride")
+            return emb, yfm
+
+        k = len(plan)
+        Ws = [_kernels._f32c(params[4 * i]) for i in range(k)]
+        w_head = _kernels._f32c(params[4 * k]).view(-1)
+        out, saved, st = _tail_forward(plan, seed, None, None, Ws, w_head, params[4 * k + 1],
+                                       lead=_Lead(B, dev, gather, extra_zero=rows * (D + 4)), labels=labels, loss_seed=loss_seed)
+        ctx.st = st
+        ctx.meta = (B, F, D, rows, bias is not None)
+        ctx.save_for_backward(*saved, slot, esum)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, F, D, rows, has_bias = ctx.meta
+        saved = ctx.saved_tensors
+        slot, esum = saved[-2], saved[-1]
+        need = ctx.needs_input_grad       # (plan, head, seed, recv, slot, bias, labels, loss_seed, *params)
+        st = ctx.st
+        gbuf, st.extra = st.extra, None
+        if gbuf is None:                   # a second backward through the same graph: a fresh zero fill
+            gbuf = torch.zeros((rows * (D + 4),), dtype=torch.float32, device=slot.device)
+        gbuf = gbuf.view(rows, D + 4)
+        _, _, grads, db_head = _tail_backward(st, saved[:st.n_saved], g, True, need[8:], False, fm=(esum, None, D, slot, gbuf))
+        gb = db_head if (has_bias and need[5]) else None
+        return (None, None, None, gbuf if need[3] else None, None, gb, None, None, *grads)
+
+
 def _plan_params(plan, head):
     params = []
     for L in plan:
@@ -707,3 +776,8 @@ def run_fused_deepfm(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, id
     the head's backward (losses.BCEWithLogitsLoss finds both when it is called with these logits and labels)."""
     return DeepFMFusedFn.apply(plan, head, seed, idx, offsets, W, w1, bias, sparse_W, sparse_w1, labels,
                                *_plan_params(plan, head))
+
+
+def run_fused_slot_deepfm(plan: List[_Layer], head: nn.Linear, seed: torch.Tensor, recv, slot, bias,
+                          labels: Optional[torch.Tensor] = None, loss_seed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return SlotDeepFMFusedFn.apply(plan, head, seed, recv, slot, bias, labels, loss_seed, *_plan_params(plan, head))
