@@ -284,7 +284,8 @@ def test_criterion_in_the_head_launch_vs_the_three_launch_form_and_the_oracle(B,
     one = run(True, None)
     three = run(False, None)
     atol = 1e-5 + 2e-7 * B
-    assert_close(one[0], three[0], 1e-5, 1e-6, "logits")
+    # (two runs of one step differ by the order of the float atomics behind the BatchNorm statistics: a few 1e-6 on O(1) logits)
+    assert_close(one[0], three[0], 1e-5, 1e-5, "logits")
     assert abs(one[1] - three[1]) <= 1e-6 + 1e-5 * abs(three[1]), (one[1], three[1])
     assert set(one[2]) == set(three[2])
     for k in three[2]:
