@@ -806,7 +806,9 @@ int mi_dual_gather_bwd_rows(const int64_t *idx, const float *g_out, const float 
       aligned16(g2vals)) {
     const int lpr = De / 4;
     int64_t fg = (n * lpr / 2 + kBlock - 1) / kBlock;          // two lookups per thread and trip
-    static const int cap = [] { const char *e = getenv("MI_DUAL_ROWS_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 512; }();
+    // workgroups: one per CU.  Each adds a partial to the last workgroup's join (profiles/r04_dual_rows_grid_sweep.txt: 512
+    // workgroups 15.7 us, 384 14.6, 256 12.6, 192 13.0, 128 13.1 at the C3 shape); MI_DUAL_ROWS_GRID overrides for a sweep
+    static const int cap = [] { const char *e = getenv("MI_DUAL_ROWS_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 512 ? v : 256; }();
     if (fg > cap) fg = cap;
     if (fg < 1) fg = 1;
     float *ws = (workspace && n1 * De <= kBlock && kBlock % (n1 * De) == 0) ? workspace : nullptr;
