@@ -10,6 +10,7 @@ from .embeddings import IEmbedding, NAME_TO_CLS, VanillaEmbedding, get_embedding
 from .factory import (get_ctr_model, get_graph_model, load_ctr_model, load_graph_model, save_cf_emb_checkpoint,
                       save_ctr_checkpoint)
 from .lightgcn import LightGCN, SingleLightGCN
+from .losses import BCEWithLogitsLoss
 
 
 
@@ -45,4 +46,5 @@ __all__ = [
     "DeepFM", "IEmbedding", "VanillaEmbedding", "NAME_TO_CLS", "get_embedding",
     "LightGCN", "SingleLightGCN", "get_ctr_model", "get_graph_model", "load_ctr_model", "load_graph_model",
     "save_cf_emb_checkpoint", "save_ctr_checkpoint", "MI355XLibraryError", "check_index_errors", "use_deterministic_algorithms",
+    "BCEWithLogitsLoss",
 ]

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_ride(
     mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, (int)blockIdx.x - ngather, (int)gridDim.x - ngather);
     return;
   }
+  // every workgroup of the launch is resident at once (1 024 + ~200 of the chip's 2 048 slots): the gather's waves wait on
+  // memory most of the time and should win the issue slot against the mask work's 64-bit multiplies whenever they are ready
+  __builtin_amdgcn_s_setprio(2);
   gather_fm_fwd_blocks<LPR, NIT, true>(idx, offsets, W, w1, bias, emb, yfm, rows_out, B, F, N, ldw, ldw1, err, sum_out,
                                        (int)blockIdx.x, ngather);
 }

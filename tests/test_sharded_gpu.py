@@ -57,9 +57,11 @@ def test_sharded_world1_equals_unsharded(one_rank_group):
     pkg.check_index_errors()
 
 
-@pytest.mark.parametrize("graphed", [False, True])
-def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphed):
-    """Same batches, same optimizers: after several steps the shards hold the unsharded model's tables."""
+@pytest.mark.parametrize("graphed,criterion", [(False, "torch"), (True, "torch"), (True, "package")])
+def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphed, criterion):
+    """Same batches, same optimizers: after several steps the shards hold the unsharded model's tables.  criterion "package":
+    recsys_benchmark_amd.BCEWithLogitsLoss — the graphed step then hands labels and its 1 / world seed to the local compute and
+    the criterion is evaluated inside the tail's head launch."""
     from recsys_benchmark_amd.optim import get_optimizers
 
     torch.manual_seed(4)
@@ -72,7 +74,7 @@ def test_sharded_training_steps_track_the_unsharded_model(one_rank_group, graphe
     sh._deep_branch.load_state_dict(ref._deep_branch.state_dict())
     cfg = {"sparse": True, "optimizer": "adam", "learning_rate": 1e-2, "weight_decay": 1e-6}
     ropts, sopts = get_optimizers(ref, cfg), sh.get_optimizers(cfg)
-    lossf = torch.nn.BCEWithLogitsLoss()
+    lossf = torch.nn.BCEWithLogitsLoss() if criterion == "torch" else pkg.BCEWithLogitsLoss()
     gstep = sh.make_graphed_step(lossf, B) if graphed else None
     gen = torch.Generator().manual_seed(5)
     for _ in range(6):
