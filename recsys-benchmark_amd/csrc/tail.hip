@@ -835,14 +835,18 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
   if (lane == 0) { rp[3 * kHeadLossCols] = s_g; rp[3 * kHeadLossCols + 1] = s_loss; }
   __syncthreads();
   const int rr = blockIdx.x % reps;
-  float *o = part + (int64_t)rr * N * 2;
-  for (int i = threadIdx.x; i < 2 * N; i += kBlock) atomicAdd(o + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
-  float *q = wpart + (int64_t)rr * (N + 4);
-  for (int i = threadIdx.x; i <= N; i += kBlock) {
-    const int j = i < N ? 2 * kHeadLossCols + i : 3 * kHeadLossCols;
-    atomicAdd(q + i, (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
-  }
-  if (threadIdx.x == 0) {
+  // the last wave takes the loss (a chain of dependent round trips: add, fence, ticket), the other three the column sums
+  // (fire and forget): the two run side by side instead of one after the other
+  constexpr int kSumThreads = kBlock - kWave;
+  if (wv < kWavesPerBlock - 1) {
+    float *o = part + (int64_t)rr * N * 2;
+    for (int i = threadIdx.x; i < 2 * N; i += kSumThreads) atomicAdd(o + i, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+    float *q = wpart + (int64_t)rr * (N + 4);
+    for (int i = threadIdx.x; i <= N; i += kSumThreads) {
+      const int j = i < N ? 2 * kHeadLossCols + i : 3 * kHeadLossCols;
+      atomicAdd(q + i, (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
+    }
+  } else if (lane == 0) {
     const int j = 3 * kHeadLossCols + 1;
     const float lp = ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j])) * inv_m;
     atomicAdd(loss_ws + 4 + rr, lp);

@@ -22,6 +22,7 @@ elif [ $what = bench2 ]; then
   timeout -k 10 400 python $R/bench.py --c4 --no-cpu-baseline > $O/${tag}_bench_c4_1e9rows_world1.json 2> $O/bench_c4.err || tail -5 $O/bench_c4.err
   timeout -k 10 300 python $R/bench.py --ids zipf --no-cpu-baseline --no-train-step > $O/${tag}_bench_c2_zipf.json 2> $O/bench_zipf.err || tail -5 $O/bench_zipf.err
   timeout -k 10 300 python $R/bench.py --fields 39 --no-cpu-baseline --no-train-step > $O/${tag}_bench_c2_fields39.json 2> $O/bench_f39.err || tail -5 $O/bench_f39.err
+  timeout -k 10 300 python $R/bench.py --no-head-loss --no-cpu-baseline --no-train-step --no-sweep > $O/${tag}_bench_c2_labels_withheld.json 2> $O/bench_nohl.err || tail -5 $O/bench_nohl.err
   echo "benches done"
   timeout -k 10 500 python -m pytest $R/tests -q -m gpu > $O/${tag}_pytest_gpu.log 2>&1; tail -3 $O/${tag}_pytest_gpu.log
 elif [ $what = pair ]; then
