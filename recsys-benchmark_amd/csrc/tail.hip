@@ -714,7 +714,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bwd(ActDesc x, const float
 // the criterion is the last op of a step); tail.py falls back to k_tail_head_bwd when the backward arrives with anything else.
 constexpr int kHeadLossCols = 512;
 constexpr int kHeadLossRed = 3 * kHeadLossCols + 4;
-template <bool MERGE>
+// (MERGE: 0 constants read from memory, 1 joined from tile statistics, 2 derived from shifted sums — apart so that the
+//  sums form does not carry the tile join's 32-deep load chunks in its register budget: 359 VGPRs + scratch with both)
+template <int MERGE>
 __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float *__restrict__ w, const float *__restrict__ b,
                                                           const float *__restrict__ add, const float *__restrict__ y,
                                                           float *__restrict__ out, float *__restrict__ gout,
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
                                                           float *__restrict__ wpart, float *__restrict__ loss_ws, int M,
                                                           int N, BnFwd bn, int reps, int64_t *bump,
                                                           const float *__restrict__ upstream) {
-  __shared__ __attribute__((aligned(16))) float cst[MERGE ? 3 * kCstPitch : 4];
+  __shared__ __attribute__((aligned(16))) float cst[MERGE != 0 ? 3 * kCstPitch : 4];
   __shared__ __attribute__((aligned(16))) float red[kWavesPerBlock][kHeadLossRed];
   if (bump && blockIdx.x == 0 && threadIdx.x == 0) bump[0] += 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -753,8 +755,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
       }
     }
     if (first) {      // the constants are not needed to ISSUE the row loads: their join runs under the rows' round trip
-      if constexpr (MERGE) {
-        bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
+      if constexpr (MERGE != 0) {
+        if constexpr (MERGE == 2) bn_derive_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
+        else bn_merge_fwd<kBlock>(bn, M, N, cst, blockIdx.x == 0, (int)threadIdx.x);
         __syncthreads();
         const lds_cfp c = as_lds(cst);
         if (v0) { mu0 = vld4(c + c0); sc0 = vld4(c + kCstPitch + c0); be0 = vld4(c + 2 * kCstPitch + c0); }
@@ -766,27 +769,49 @@ __global__ __launch_bounds__(kBlock) void k_tail_head_bce(ActDesc x, const float
     }
     first = false;
     if (m0 >= M) break;
+    // the four rows' dots first, then ONE butterfly over the four sums side by side (a row at a time is four dependent chains
+    // of six lane exchanges, ~1 us of a kernel that is all latency), then the rows' remaining arithmetic
+    float sa[4];
+    auto row0 = [&](int u, float4 &zc, float4 &pre, float4 &kk) {
+      kk = drop.scale4(k0[u], c0);
+      zc = make_float4(z0[u].x - mu0.x, z0[u].y - mu0.y, z0[u].z - mu0.z, z0[u].w - mu0.w);
+      pre = make_float4(fmaf(zc.x, sc0.x, be0.x), fmaf(zc.y, sc0.y, be0.y), fmaf(zc.z, sc0.z, be0.z), fmaf(zc.w, sc0.w, be0.w));
+    };
+    auto row1 = [&](int u, float4 &zc, float4 &pre, float4 &kk) {
+      kk = drop.scale4(k1[u], c1);
+      zc = make_float4(z1[u].x - mu1.x, z1[u].y - mu1.y, z1[u].z - mu1.z, z1[u].w - mu1.w);
+      pre = make_float4(fmaf(zc.x, sc1.x, be1.x), fmaf(zc.y, sc1.y, be1.y), fmaf(zc.z, sc1.z, be1.z), fmaf(zc.w, sc1.w, be1.w));
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 zc, pre, kk;
+      float s = 0.f;
+      if (v0) {
+        row0(u, zc, pre, kk);
+        s += fmaxf(pre.x, 0.f) * kk.x * w0.x + fmaxf(pre.y, 0.f) * kk.y * w0.y + fmaxf(pre.z, 0.f) * kk.z * w0.z +
+             fmaxf(pre.w, 0.f) * kk.w * w0.w;
+      }
+      if (v1) {
+        row1(u, zc, pre, kk);
+        s += fmaxf(pre.x, 0.f) * kk.x * w1.x + fmaxf(pre.y, 0.f) * kk.y * w1.y + fmaxf(pre.z, 0.f) * kk.z * w1.z +
+             fmaxf(pre.w, 0.f) * kk.w * w1.w;
+      }
+      sa[u] = s;
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sa[u] += __shfl_xor(sa[u], msk);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int m = m0 + u * nw;
       if (m >= M) break;
+      // (the row's pre-activations again from its loaded values: a few instructions, against 24 registers per row kept alive)
       float4 zc0 = zero4(), zc1 = zero4(), pre0 = zero4(), pre1 = zero4(), kk0 = zero4(), kk1 = zero4();
-      float s = 0.f;
-      if (v0) {
-        kk0 = drop.scale4(k0[u], c0);
-        zc0 = make_float4(z0[u].x - mu0.x, z0[u].y - mu0.y, z0[u].z - mu0.z, z0[u].w - mu0.w);
-        pre0 = make_float4(fmaf(zc0.x, sc0.x, be0.x), fmaf(zc0.y, sc0.y, be0.y), fmaf(zc0.z, sc0.z, be0.z), fmaf(zc0.w, sc0.w, be0.w));
-        s += fmaxf(pre0.x, 0.f) * kk0.x * w0.x + fmaxf(pre0.y, 0.f) * kk0.y * w0.y + fmaxf(pre0.z, 0.f) * kk0.z * w0.z +
-             fmaxf(pre0.w, 0.f) * kk0.w * w0.w;
-      }
-      if (v1) {
-        kk1 = drop.scale4(k1[u], c1);
-        zc1 = make_float4(z1[u].x - mu1.x, z1[u].y - mu1.y, z1[u].z - mu1.z, z1[u].w - mu1.w);
-        pre1 = make_float4(fmaf(zc1.x, sc1.x, be1.x), fmaf(zc1.y, sc1.y, be1.y), fmaf(zc1.z, sc1.z, be1.z), fmaf(zc1.w, sc1.w, be1.w));
-        s += fmaxf(pre1.x, 0.f) * kk1.x * w1.x + fmaxf(pre1.y, 0.f) * kk1.y * w1.y + fmaxf(pre1.z, 0.f) * kk1.z * w1.z +
-             fmaxf(pre1.w, 0.f) * kk1.w * w1.w;
-      }
-      s = wave_sum(s);
+      if (v0) row0(u, zc0, pre0, kk0);
+      if (v1) row1(u, zc1, pre1, kk1);
+      const float s = sa[u];
       const float xl = s + bv + av[u];
       // the criterion's own arithmetic (k_bce_logits_fwd / _bwd, cross.hip)
       const float gm = gsc * (1.f / (1.f + expf(-xl)) - yv[u]);
@@ -1416,11 +1441,14 @@ int mi_tail_head_bce(const float *Z, int32_t ldz, const float *mu, const float *
   // one workgroup per CU, 16 rows each at M = 4096 (a single trip of 4 rows per wave)
   const int waves = (M + 3) / 4;
   const int grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock < 256 ? (waves + kWavesPerBlock - 1) / kWavesPerBlock : 256;
-  if (stats)
-    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<true>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws, M,
+  if (stats && bn.nrep > 0)
+    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<2>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws, M,
+              N, bn, sum_reps, (int64_t *)nullptr, upstream);
+  else if (stats)
+    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<1>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws, M,
               N, bn, sum_reps, (int64_t *)nullptr, upstream);
   else
-    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<false>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws,
+    MI_LAUNCH("tail_head_bce", (k_tail_head_bce<0>), grid, kBlock, stream, x, w, b, add, y, out, g, DY, part, wpart, loss_ws,
               M, N, bn, sum_reps, bump, upstream);
   return launch_status();
 }
