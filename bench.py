@@ -294,12 +294,18 @@ def dgrad_epilogue_us(B, F, D, H, dev, copies=32, reps=20):
 def graph_wall_us(enqueue, copies, reps, dev):
     """WALL microseconds per enqueue(i) inside a replayed hipGraph holding `copies` of them back to back (HIP events on the
     stream the graph is launched on, around `reps` replays)."""
+    from recsys_benchmark_amd import sharded as _sh
+
     enqueue(0)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for i in range(copies):
-            enqueue(i)
+    _sh.note_capture(+1)          # (a sharded run's communicator watchdog skips its event polls while a capture is open)
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for i in range(copies):
+                enqueue(i)
+    finally:
+        _sh.note_capture(-1)
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
@@ -1285,6 +1291,7 @@ def main():
         ingraph["dgrad"] = dgrad_epilogue_us(B, F, D, hidden[0], dev)
         if not args.no_sweep and rank == 0:
             sweep = batch_sweep(model, dims, F, D, dev, args.ids)
+    sharded_dgrad = dgrad_epilogue_us(B, F, D, hidden[0], dev) if (sharded and rank == 0 and not args.no_gather_leg) else None
     sharded_phases = None
     if sharded and graphed_local:
         sharded_phases = timed_phases()          # every rank runs them (collectives inside); rank 0 reports its own
@@ -1355,6 +1362,25 @@ def main():
                     **{k: kernels[k]["avg_us"] for k in ("gather_fm_fwd", "gather_fm_bwd_rows", "gather_fm_bwd_dense", "empty") if k in kernels}}
             if sweep is not None:
                 roofline["batch_sweep"] = sweep
+        elif sharded and "gather_fm_fwd_ride" in kernels and sharded_dgrad is not None:
+            # the sharded step's local compute is the one-node form too: the slot lookup (same kernel, rows addressed by slot in
+            # the receive buffer, the tail's mask riders in its launch) + the lookup backward in the epilogue of the tail's first
+            # input-gradient product.  The lookup's time here is its EAGER dispatch-event time (reads ~1-2 us above the in-graph
+            # wall the unsharded line quotes, and includes the riders); the epilogue's is the in-graph difference as above.
+            fwd_us = kernels["gather_fm_fwd_ride"]["avg_us"]
+            epi_us = max(sharded_dgrad["fm"] - sharded_dgrad["plain"], 0.0)
+            pair_bytes = (fb + bb) * B
+            roofline = {"bound": "hbm",
+                        "kernel": "gather+FM fwd+bwd PAIR of the sharded step's local compute: the slot lookup (k_gather_fm_fwd_ride) + "
+                                  "the lookup backward in the epilogue of the tail's first input-gradient product",
+                        "achieved": round(pair_bytes / (fwd_us + epi_us) / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(pair_bytes / (fwd_us + epi_us) / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_us": round(fwd_us + epi_us, 3), "alg_bytes": pair_bytes,
+                        "attribution": {"slot_lookup_eager_dispatch_us": round(fwd_us, 3),
+                                        "tail_dgrad_gemm_plain_us": round(sharded_dgrad["plain"], 3),
+                                        "tail_dgrad_gemm_fm_us": round(sharded_dgrad["fm"], 3), "epilogue_us": round(epi_us, 3)},
+                        "clock": "lookup: dispatch begin/end events of an eager pass (incl. the mask riders of its launch); epilogue: "
+                                 "in-graph wall per launch, product with the epilogue minus without"}
         else:
             cand = [k for k in kernels if k in alg]
             dom = max(cand, key=lambda k: kernels[k]["avg_us"]) if cand else None
