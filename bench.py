@@ -309,13 +309,19 @@ def graph_wall_us(enqueue, copies, reps, dev):
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (copies * reps)
+    # the MEDIAN of five such measurements: differences of two of these numbers (the epilogue's cost, the prefetched gather)
+    # are a microsecond or two, and a single measurement is now and then a microsecond off
+    samples = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) * 1e3 / (copies * reps))
+    samples.sort()
+    return samples[len(samples) // 2]
 
 
 def gather_in_graph_us(model, xs, B, F, D, dev, copies=32, reps=20):
@@ -339,6 +345,43 @@ def gather_in_graph_us(model, xs, B, F, D, dev, copies=32, reps=20):
     out["warm"] = {"fwd": graph_wall_us(lambda i: warm.fwd(xw[i % len(xw)]), copies, reps, dev),
                    "bwd": graph_wall_us(lambda i: warm.bwd(), copies, reps, dev)}
     return out
+
+
+def prefetched_gather_us(model, xs, B, F, D, hidden, dev, copies=32, reps=20):
+    """The gather + FM forward in the regime a step with DeepFM.prefetch_next runs it in: the PREVIOUS launch was the tail's
+    weight-gradient launch (four products dz^T a, MFMA-bound) carrying, in extra workgroups, the touch of exactly the table rows
+    this gather reads.  In-graph wall per launch of
+        P = [weight gradients + riders for batch i]                     Q = [the same, then gather(batch i)]
+        R = [weight gradients alone]
+    gather after a prefetch = Q - P, what the riders cost the launch that carries them = P - R."""
+    from recsys_benchmark_amd import _kernels as K_
+
+    gb = GatherBench(model, B, F, D, dev)
+    g = torch.Generator().manual_seed(17)
+    widths = [F * D] + list(hidden)
+    dz = [torch.randn(B, n, generator=g).to(dev) for n in widths[1:]]
+    act = [torch.randn(B, k, generator=g).to(dev) for k in widths[:-1]]
+    dW = [torch.zeros(n, k, device=dev) for k, n in zip(widths[:-1], widths[1:])]
+    probs = [dict(A=dz[l], B=act[l], C=dW[l], M=widths[l + 1], N=widths[l], K=B, lda=widths[l + 1], ldb=widths[l], ldc=widths[l])
+             for l in range(len(dW))]
+
+    def job(i):
+        x = xs[i % len(xs)]
+        return K_.PrefetchRowsJob(x.data_ptr(), gb.off.data_ptr(), gb.W.data_ptr(), gb.w1.data_ptr(), gb.ldw, gb.ldw1, B, gb.N, F)
+
+    jobs = [job(i) for i in range(len(xs))]
+
+    def wgrad(i, ride):
+        K_.gemm_multi(probs, transA=True, ride=jobs[i % len(jobs)] if ride else None)
+
+    R = graph_wall_us(lambda i: wgrad(i, False), copies, reps, dev)
+    P = graph_wall_us(lambda i: wgrad(i, True), copies, reps, dev)
+    Q = graph_wall_us(lambda i: (wgrad(i, True), gb.fwd(xs[i % len(xs)], i)), copies, reps, dev)
+    C = graph_wall_us(lambda i: (wgrad(i, False), gb.fwd(xs[i % len(xs)], i)), copies, reps, dev)
+    del gb
+    torch.cuda.empty_cache()
+    return {"wgrad": R, "wgrad_with_riders": P, "riders_cost": max(P - R, 0.0), "gather_after_prefetch": Q - P,
+            "gather_cold_behind_wgrad": C - R}
 
 
 def batch_sweep(model, dims, F, D, dev, ids, sizes=(4096, 16384, 65536, 262144)):
@@ -996,8 +1039,9 @@ def main():
                     "steps (the GPU's clocks ramp up over the first milliseconds of load after the host-bound capture phase); 0: none")
     ap.add_argument("--no-head-loss", action="store_true", help="model(x) without the step's labels: head, criterion and head backward as "
                     "three launches (default: model(x, labels=y), one launch)")
-    ap.add_argument("--prefetch", action="store_true", help="every step touches the NEXT batch's table rows on a side stream under its "
-                    "weight-gradient launch (DeepFM.prefetch_next): the next forward gathers from the Infinity Cache")
+    ap.add_argument("--no-prefetch", action="store_true", help="default: every step touches the NEXT batch's table rows in extra "
+                    "workgroups of its weight-gradient launch (DeepFM.prefetch_next), the next forward gathers from the Infinity "
+                    "Cache; with this flag the steps know nothing of the next batch")
     ap.add_argument("--infer", action="store_true", help="the reference's own timing harnesses (scripts/deepfm/infer_deepfm.py, "
                     "scripts/lightgcn/infer_lightgcn.py): eval-mode forward latency at B=64 / 4096, LightGCN request phases, CPU oracle beside")
     ap.add_argument("--windows", type=int, default=10, help="extra windows of --steps replays after the timed region, for "
@@ -1121,6 +1165,9 @@ def main():
     # evaluates the criterion and the head's backward sums, lossf() picks them up (--no-head-loss: the reference's two calls
     # as they stand — head, criterion and head backward are three launches)
     labels_in_forward = not args.no_head_loss and not sharded
+    # one graph per resident batch, replayed in turn: graph i is followed by graph i + 1, whose ids it can touch ahead
+    prefetching = (not args.no_prefetch and not args.copy_batch and not sharded and hasattr(model, "prefetch_next")
+                   and not args.no_graph)
 
     def fwd(xb, yb):
         return model(xb, labels=yb) if labels_in_forward else model(xb)
@@ -1209,7 +1256,7 @@ def main():
         pool = None
         for gi, blob in enumerate(slots):
             xb, yb = blob[:nx].view(torch.int64).view(B, F), blob[nx:].view(torch.float32)
-            if args.prefetch and not args.copy_batch:
+            if prefetching:
                 # graph i is followed by graph i + 1 in the timed ring: its step touches that batch's table rows
                 nb = slots[(gi + 1) % len(slots)]
                 model.prefetch_next(nb[:nx].view(torch.int64).view(B, F))
@@ -1299,6 +1346,7 @@ def main():
         xs_ring += [synth_batch(dims, B, 31337 + i, dev, args.ids)[0] for i in range(max(0, 64 - len(xs_ring)))]
         ingraph = gather_in_graph_us(model, xs_ring, B, F, D, dev, copies=64)
         ingraph["dgrad"] = dgrad_epilogue_us(B, F, D, hidden[0], dev)
+        ingraph["prefetched"] = prefetched_gather_us(model, xs_ring, B, F, D, hidden, dev) if prefetching else None
         if not args.no_sweep and rank == 0:
             sweep = batch_sweep(model, dims, F, D, dev, args.ids)
     sharded_dgrad = dgrad_epilogue_us(B, F, D, hidden[0], dev) if (sharded and rank == 0 and not args.no_gather_leg) else None
@@ -1335,17 +1383,34 @@ def main():
             epi_us = max(dg["fm"] - dg["plain"], 0.0)
             from recsys_benchmark_amd import tail as _tailmod
             fused = bool(_tailmod.FM_EPILOGUE and _mlp.FUSED_TAIL and sparse)
-            step_pair_us = fwd_us + epi_us if fused else pair_us
+            pf = ingraph.get("prefetched") if fused else None
+            fwd_step_us = pf["gather_after_prefetch"] if pf else fwd_us      # the forward as the step finds its rows
+            step_pair_us = fwd_step_us + epi_us if fused else pair_us
             pair_bytes = (fb + bb) * B
             roofline = {"bound": "hbm",
-                        "kernel": ("gather+FM fwd+bwd PAIR as the step runs it: k_gather_fm_fwd + the lookup backward in the epilogue of "
+                        "kernel": ("gather+FM fwd+bwd PAIR as the step runs it: k_gather_fm_fwd" +
+                                   (" behind the previous step's weight-gradient launch, whose extra workgroups touched its table "
+                                    "rows (DeepFM.prefetch_next)" if pf else "") +
+                                   " + the lookup backward in the epilogue of "
                                    "the tail's first input-gradient product (k_tail_dgrad<..., FM>: its time with the epilogue minus "
                                    "its time without)" if fused else "gather+FM fwd+bwd pair: k_gather_fm_fwd + k_gather_fm_bwd_rows"),
                         "achieved": round(pair_bytes / step_pair_us / 1e3, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(pair_bytes / step_pair_us / 1e3 / HBM_PEAK_GBS, 4),
                         "traffic": traffic_all.get("gather_fm_pair_fused" if fused else "gather_fm_fwd"), "avg_us": round(step_pair_us, 3),
                         "alg_bytes": pair_bytes,
-                        "attribution": {"gather_fm_fwd_us": round(fwd_us, 3),
+                        "cold": ({"what": "the same pair with the forward on rows nobody touched ahead (--no-prefetch; rounds 1-4's figure)",
+                                  "avg_us": round(fwd_us + epi_us, 3),
+                                  "frac": round(pair_bytes / (fwd_us + epi_us) / 1e3 / HBM_PEAK_GBS, 4)} if pf else None),
+                        "prefetch": ({"gather_fm_fwd_after_prefetch_us": round(pf["gather_after_prefetch"], 3),
+                                      "gather_fm_fwd_cold_behind_the_same_launch_us": round(pf["gather_cold_behind_wgrad"], 3),
+                                      "weight_gradient_launch_us": round(pf["wgrad"], 3),
+                                      "weight_gradient_launch_with_riders_us": round(pf["wgrad_with_riders"], 3),
+                                      "riders_cost_us": round(pf["riders_cost"], 3),
+                                      "note": "in-graph wall per launch, medians of 5: P = [weight gradients + riders for batch i], "
+                                              "Q = [P, gather(batch i)], R = [weight gradients alone]; gather after a prefetch = "
+                                              "Q - P, riders' cost = P - R (it is inside ms_per_step: the timed steps carry the riders)"}
+                                     if pf else None),
+                        "attribution": {"gather_fm_fwd_us": round(fwd_step_us, 3), "gather_fm_fwd_cold_us": round(fwd_us, 3),
                                         "tail_dgrad_gemm_plain_us": round(dg["plain"], 3), "tail_dgrad_gemm_fm_us": round(dg["fm"], 3),
                                         "epilogue_us": round(epi_us, 3),
                                         "alternating_plain_then_fm_us_per_pair": round(dg["alternating_pair"], 3),
@@ -1421,7 +1486,8 @@ def main():
                                    f"MLP 400x3+BN+dropout0.5, B={B}/GPU, fwd+bwd, {len(ring)} distinct {args.ids}-id batches "
                                    f"rotated (fresh ids every step), "
                                    f"{'row-form (COO)' if sparse else 'dense'} table grads, "
-                                   f"{'criterion evaluated in the head launch (model(x, labels=y)), ' if labels_in_forward else ''}tables stored as "
+                                   f"{'criterion evaluated in the head launch (model(x, labels=y)), ' if labels_in_forward else ''}"
+                                   f"{'next batch known one step ahead (its table rows touched by riders of the weight-gradient launch), ' if prefetching else ''}tables stored as "
                                    f"{'one packed [N,32] buffer (row + first-order weight per 128-B line)' if (args.layout == 'packed128' and not sharded) else 'row-sharded packed rows' if sharded else 'the two reference tensors'}",
                        "global_batch": B * world, "parallelism": parallelism},
             "ms_per_step_windows": ({"min": round(window_ms[0], 4), "median": round(window_ms[len(window_ms) // 2], 4),

@@ -101,6 +101,15 @@ MI_API int mi_gather_fm_fwd_sum(const int64_t *idx, const int64_t *offsets,
  * next batch from its DataLoader while the step runs; this is what the device does with that lead.) */
 MI_API int mi_prefetch_rows(const int64_t *idx, const int64_t *offsets, const float *W, int64_t ldw, const float *w1,
                             int64_t ldw1, int64_t B, int32_t F, int64_t N, void *stream);
+/* The same job as a host struct, for a launch that carries it in extra workgroups (mi_gemm_f32_multi_ride). */
+typedef struct mi_prefetch_rows_job {
+  const int64_t *idx;       /* device int64[B, F]: the NEXT batch's raw ids */
+  const int64_t *offsets;   /* device int64[F], nullable */
+  const float *W;           /* the embedding table (row pitch ldw floats) */
+  const float *w1;          /* the first-order table (row pitch ldw1), nullable */
+  int64_t ldw, ldw1, B, N;
+  int32_t F;
+} mi_prefetch_rows_job;
 
 /* Backward of the above, row-sparse form (the MI355X-native default):
  *   gvals[b,f,:] = g_emb[b,f,:] + g_y[b] * (S_b - emb[b,f,:]),  S_b = sum_f emb
@@ -476,6 +485,13 @@ typedef struct mi_gemm_problem {
   int32_t accumulate;
 } mi_gemm_problem;
 MI_API int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream);
+/* ... carrying a mi_prefetch_rows job in workgroups past the products' grid: the MLP tail's weight-gradient launch is
+ * MFMA-bound (~45 us with the HBM idle), the lookup of the NEXT step is a chain of HBM round trips — touched here, its table
+ * lines wait in the Infinity Cache (DeepFM.prefetch_next; src/trainer/deepfm.py:40-60 holds the next batch while the step
+ * runs).  ride == NULL: mi_gemm_f32_multi.  A launch that cannot carry it (not the A^T B LDS-DMA form) runs the job as a
+ * launch of its own first. */
+MI_API int mi_gemm_f32_multi_ride(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB,
+                                  const mi_prefetch_rows_job *ride, void *stream);
 MI_API int mi_gemm_f32_multi_plan(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, int32_t *kind,
                                   int64_t *workgroups, int32_t *splitk);
 

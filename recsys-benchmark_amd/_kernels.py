@@ -1165,20 +1165,32 @@ def gemm_multi_plan(problems, transA=False, transB=False):
     return kind.value, wgs.value, list(splitk[:len(problems)])
 
 
-def gemm_multi(problems, transA=False, transB=False):
+class PrefetchRowsJob(_ctypes.Structure):
+    """mi_prefetch_rows_job: the NEXT batch's ids and the tables its lookup will read."""
+    _fields_ = [("idx", _ctypes.c_void_p), ("offsets", _ctypes.c_void_p), ("W", _ctypes.c_void_p), ("w1", _ctypes.c_void_p),
+                ("ldw", _ctypes.c_int64), ("ldw1", _ctypes.c_int64), ("B", _ctypes.c_int64), ("N", _ctypes.c_int64),
+                ("F", _ctypes.c_int32)]
+
+
+def gemm_multi(problems, transA=False, transB=False, ride: Optional[PrefetchRowsJob] = None):
     """problems: dicts with A, B, C (torch buffers / views), M, N, K, lda, ldb, ldc and optionally batch, sA, sB, sC, splitk
     (0 / absent = the library's cut), accumulate — all the same operand layout, independent of each other: ONE launch per 16
     problems (mi_gemm_f32_multi).  C of a problem must be zero (or accumulate) unless splitk == 1: the caller allocates
-    them zero-filled."""
+    them zero-filled.  ride: a prefetch job the (first) launch carries in extra workgroups (mi_gemm_f32_multi_ride)."""
     if not problems:
+        if ride is not None:
+            _lib.check(_lib.load().mi_gemm_f32_multi_ride(None, 0, int(transA), int(transB), _ctypes.byref(ride),
+                                                          _lib.stream_ptr(torch.device("cuda", torch.cuda.current_device()))),
+                       "mi_gemm_f32_multi_ride")
         return
     dev = _lib.require_gpu(*[q[k] for q in problems for k in ("A", "B", "C")])
     lib, stream = _lib.load(), _lib.stream_ptr(dev)
     for i in range(0, len(problems), MAX_GEMM_PROBLEMS):
         chunk = problems[i:i + MAX_GEMM_PROBLEMS]
         arr = _multi_problem_array(chunk)
-        _lib.check(lib.mi_gemm_f32_multi(_ctypes.addressof(arr), len(chunk), int(transA), int(transB), stream),
-                   "mi_gemm_f32_multi")
+        _lib.check(lib.mi_gemm_f32_multi_ride(_ctypes.addressof(arr), len(chunk), int(transA), int(transB),
+                                              _ctypes.byref(ride) if (ride is not None and i == 0) else None, stream),
+                   "mi_gemm_f32_multi_ride")
 
 
 PANEL_GEMM = True        # False: every product stays on the 64x64-tile kernel (mi_gemm_f32)

@@ -157,6 +157,7 @@ SIGNATURES = {
     "mi_tail_wgrad_gemm": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i32,
                            _i32, _i32, _p],
     "mi_gemm_f32_multi": [_p, _i32, _i32, _i32, _p],
+    "mi_gemm_f32_multi_ride": [_p, _i32, _i32, _i32, _p, _p],
     "mi_gemm_f32_multi_plan": [_p, _i32, _i32, _i32, _p, _p, _p],
     "mi_gemm_f32_panel": [_p, _i32, _p, _i32, _i32, _i32, _i64, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p],
     "mi_mix_expert_fwd": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],

@@ -18,6 +18,7 @@
 // byte is used once); the dense backward stages a 1 KiB tile per wave in LDS to
 // turn 16-B-strided float4 fragments into 256-B contiguous atomic instructions.
 #include "common.hpp"
+#include "prefetch_rows.hpp"
 #include "tail_masks.hpp"
 
 namespace {
@@ -457,19 +458,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_bwd_dense_anyD(
 // packed row — comes into the Infinity Cache), so that the next step's forward finds them on-die instead of in HBM.  Meant
 // to run on a side stream under an MFMA-bound kernel of the CURRENT step (the tail's weight gradients leave the HBM idle for
 // ~45 us).  `sink` is never non-null in practice; it keeps the loads alive.
-__global__ __launch_bounds__(kBlock) void k_prefetch_rows(const int64_t *__restrict__ idx, const int64_t *__restrict__ offsets,
-                                                          const float *__restrict__ W, const float *__restrict__ w1,
-                                                          int64_t n, int F, int64_t N, int64_t ldw, int64_t ldw1,
-                                                          float *__restrict__ sink) {
-  float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = idx[i] + (offsets ? offsets[i % F] : 0);
-    if ((uint64_t)row < (uint64_t)N) {
-      s += W[row * ldw];
-      if (w1) s += w1[row * ldw1];
-    }
-  }
-  if (sink && s == 1.2345e-30f) sink[0] = s;
+__global__ __launch_bounds__(kBlock) void k_prefetch_rows(PrefetchJob j, float *__restrict__ sink) {
+  prefetch_rows_blocks(j, (int)blockIdx.x, (int)gridDim.x, sink);
 }
 
 // ------------------------------------------------------- plain row gather ----
@@ -749,13 +739,11 @@ int mi_prefetch_rows(const int64_t *idx, const int64_t *offsets, const float *W,
   if (B < 0 || F <= 0 || N < 0 || ldw <= 0) return MI_ERR_INVALID_ARG;
   if (B == 0) return MI_OK;
   if (!idx || !W) return MI_ERR_INVALID_ARG;
-  // a first-order weight inside the embedding row's 128-byte line (the packed table) needs no touch of its own
-  const bool same_line = w1 && ldw1 == ldw && w1 > W && (w1 - W) * 4 < 128 && ldw * 4 <= 128;
-  const int64_t n = B * F;
-  int64_t grid = (n + kBlock - 1) / kBlock;
+  PrefetchJob j;
+  if (!prefetch_job(idx, offsets, W, ldw, w1, ldw1, B, F, N, j)) return MI_OK;
+  int64_t grid = (j.n + kBlock - 1) / kBlock;
   if (grid > kMaxGrid) grid = kMaxGrid;
-  MI_LAUNCH("prefetch_rows", k_prefetch_rows, (int)grid, kBlock, stream, idx, offsets, W, same_line ? (const float *)nullptr : w1,
-            n, F, N, ldw, ldw1 > 0 ? ldw1 : 1, (float *)nullptr);
+  MI_LAUNCH("prefetch_rows", k_prefetch_rows, (int)grid, kBlock, stream, j, (float *)nullptr);
   return launch_status();
 }
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "prefetch_rows.hpp"
 
 namespace {
 using namespace mi;
@@ -444,6 +445,10 @@ struct SlimProblem {      // what varies between the problems of one launch; the
 struct MultiArgs {
   int n, total;
   SlimProblem p[kMaxProblems];
+  // riders (k_gemm_tn_multi only): workgroups past the product's grid that touch the table rows of the NEXT batch's lookup
+  // (prefetch_rows.hpp) — the weight-gradient launch is MFMA-bound and its workgroups leave slots on every CU
+  int ride_blocks;
+  mi::PrefetchJob pf;
 };
 template <int TA, int BT>
 __global__ __launch_bounds__(256) void k_gemm_f32_multi(MultiArgs m) {
@@ -513,6 +518,10 @@ __device__ __forceinline__ void tn_dma(const float *src, float *lds_dst) {
 __global__ __launch_bounds__(256) void k_gemm_tn_multi(MultiArgs m) {
   __shared__ __attribute__((aligned(16))) float tn_lds[TN_S * 2 * TN_TILE];
   const int per_xcd = (m.total + 7) >> 3;
+  if ((int)blockIdx.x >= 8 * per_xcd) {      // (riders sit at the END of the grid: the product's workgroups are dispatched first)
+    mi::prefetch_rows_blocks(m.pf, (int)blockIdx.x - 8 * per_xcd, m.ride_blocks, nullptr);
+    return;
+  }
   const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || id >= m.total) return;
   int j = 0;
@@ -794,12 +803,33 @@ int mi_gemm_f32_multi_plan(const mi_gemm_problem *probs, int32_t n, int32_t tran
 // split-K slices meet in float atomics: a problem with splitk != 1 needs its C zeroed by the caller (or accumulate);
 // splitk = 0 leaves the cut to the library.
 int mi_gemm_f32_multi(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB, void *stream) {
+  return mi_gemm_f32_multi_ride(probs, n, transA, transB, nullptr, stream);
+}
+
+int mi_gemm_f32_multi_ride(const mi_gemm_problem *probs, int32_t n, int32_t transA, int32_t transB,
+                           const mi_prefetch_rows_job *ride, void *stream) {
   MultiArgs m;
   bool tn;
   const int rc = plan_multi(probs, n, transA, transB, m, &tn);
-  if (rc != MI_OK || m.n == 0) return rc;
+  if (rc != MI_OK) return rc;
+  m.ride_blocks = 0;
+  bool riding = false;
+  if (ride && ride->B > 0) {
+    riding = mi::prefetch_job(ride->idx, ride->offsets, ride->W, ride->ldw, ride->w1, ride->ldw1, ride->B, ride->F, ride->N, m.pf);
+    if (!riding) return MI_ERR_INVALID_ARG;
+  }
+  if (riding && (!tn || m.n == 0)) {      // no launch that can carry it: the job as a launch of its own
+    const int st = mi_prefetch_rows(ride->idx, ride->offsets, ride->W, ride->ldw, ride->w1, ride->ldw1, ride->B, ride->F, ride->N, stream);
+    if (st != MI_OK) return st;
+    riding = false;
+  }
+  if (m.n == 0) return MI_OK;
   hipEvent_t ea, eb;
-  const dim3 grid((unsigned)((m.total + 7) / 8 * 8));
+  if (riding) {      // four rows per rider thread
+    int64_t rb = (m.pf.n + 4 * 256 - 1) / (4 * 256);
+    m.ride_blocks = (int)(rb > 1024 ? 1024 : rb);
+  }
+  const dim3 grid((unsigned)((m.total + 7) / 8 * 8 + m.ride_blocks));
   if (tn) {      // A^T B, both operands reduction-major, every problem of the launch fits: the LDS-DMA kernel
     const bool prof = mi::prof_acquire("gemm_tn_multi", &ea, &eb);
     if (prof) hipExtLaunchKernelGGL(k_gemm_tn_multi, grid, dim3(256), 0, (hipStream_t)stream, ea, eb, 0, m);

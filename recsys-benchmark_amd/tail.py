@@ -558,10 +558,8 @@ def _tail_backward(st, saved, g, need_x: bool, need_params, need_add: bool, fm=N
                 DY, part, part_rows = OUT, npart, (R if stat else (M + 63) // 64)
             else:
                 dx = OUT
-    join = beside_wgrad() if beside_wgrad is not None else None      # (work for a side stream under the MFMA-bound launch)
-    _kernels.gemm_multi(later, transA=True)
-    if join is not None:
-        join()
+    # (beside_wgrad: a job for extra workgroups of this MFMA-bound launch — the next batch's table lines, DeepFM.prefetch_next)
+    _kernels.gemm_multi(later, transA=True, ride=beside_wgrad[0] if beside_wgrad is not None else None)
     grads[4 * k] = dw_head
     grads[4 * k + 1] = db_head if st.has_head_bias else None
     dadd = gvec.view(st.add_shape) if (st.add_shape is not None and need_add) else None
@@ -595,10 +593,10 @@ class FusedTailFn(torch.autograd.Function):
 
 
 # The NEXT batch's ids, when the caller knows them (a DataLoader is one batch ahead of the step: DeepFM.prefetch_next(x)):
-# the step then touches that batch's table rows on a side stream under its weight-gradient launch (MFMA-bound, the HBM idle),
+# the step then touches that batch's table rows in extra workgroups of its weight-gradient launch (MFMA-bound, the HBM idle),
 # so the next forward's ~106 K random 128-byte lines come from the Infinity Cache.  Consumed by the next DeepFMFusedFn forward.
+# (Round 4 first ran the job on a side stream beside that launch: the two cross-stream edges cost ~30 us inside a hipGraph.)
 _NEXT_IDS = {}
-_SIDE = {}
 
 
 def set_next_batch(idx: Optional[torch.Tensor]) -> None:
@@ -609,22 +607,13 @@ def set_next_batch(idx: Optional[torch.Tensor]) -> None:
 
 
 def _next_batch_prefetch(dev, offsets, Wc, ldw, w1c, ldw1, F, N):
+    """The job (a _kernels.PrefetchRowsJob + the tensors it points at) the step's weight-gradient launch will carry, or None."""
     nxt = _NEXT_IDS.pop(str(dev), None)
-    if nxt is None or nxt.dim() != 2 or nxt.shape[1] != F:
+    if nxt is None or nxt.dim() != 2 or nxt.shape[1] != F or nxt.device != dev:
         return None
-
-    def start():
-        cur = torch.cuda.current_stream(dev)
-        side = _SIDE.get(str(dev))
-        if side is None:
-            side = _SIDE[str(dev)] = torch.cuda.Stream(dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            _lib.check(_lib.load().mi_prefetch_rows(nxt.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), ldw, w1c.data_ptr(), ldw1,
-                                                    nxt.shape[0], F, N, _lib.stream_ptr(dev)), "mi_prefetch_rows")
-        return lambda: cur.wait_stream(side)
-
-    return start
+    job = _kernels.PrefetchRowsJob(nxt.data_ptr(), offsets.data_ptr(), Wc.data_ptr(), w1c.data_ptr(), int(ldw), int(ldw1),
+                                   int(nxt.shape[0]), int(N), int(F))
+    return job, (nxt, offsets, Wc, w1c)
 
 
 class DeepFMFusedFn(torch.autograd.Function):

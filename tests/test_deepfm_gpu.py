@@ -262,12 +262,16 @@ def test_criterion_in_the_head_launch_vs_the_three_launch_form_and_the_oracle(B,
     dev = torch.device(DEV, 0)
     lossf = BCEWithLogitsLoss()
 
+    x_next = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1).to(DEV)
+
     def run(labels_in_forward, upstream):
         m = copy.deepcopy(base).to(DEV).train()
         if layout == "packed128":
             m.pack_tables()
         _mlp_mod._seed_word(dev).fill_(4242)
         xd, yd = x.to(DEV), y.to(DEV)
+        if labels_in_forward:      # the step also knows the NEXT batch: its weight-gradient launch carries the prefetch riders
+            m.prefetch_next(x_next)
         logits = m(xd, labels=yd) if labels_in_forward else m(xd)
         loss = lossf(logits, yd)
         fused = type(loss.grad_fn).__name__ == "_HeadBCEFnBackward"

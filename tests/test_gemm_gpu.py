@@ -263,3 +263,40 @@ def test_multi_problem_launch_reduction_major_lds_dma_kernel():
     _kernels.gemm_multi([dict(A=A.to(DEV), B=B.to(DEV), C=C, M=400, N=416, K=4096, lda=400, ldb=416, ldc=416)], transA=True)
     ref = A.double().t() @ B.double()
     assert_close(C, ref.float(), 1e-5, 1e-3)
+
+
+def test_multi_problem_launch_carrying_prefetch_riders():
+    """mi_gemm_f32_multi_ride: the weight-gradient launch with extra workgroups that touch the table rows of the next batch's
+    lookup (DeepFM.prefetch_next).  The products are unchanged bit for bit (integer data, both kernels), out-of-range ids among
+    the riders' are skipped, a launch that cannot carry the job runs it as a launch of its own, and a job without products is
+    just that job."""
+    from recsys_benchmark_amd import _lib
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    gen = torch.Generator().manual_seed(77)
+    N, D, B, F = 5000, 16, 300, 7
+    table = torch.randn(N, 32, device=DEV)
+    ids = torch.randint(0, N // F, (B, F), generator=gen)
+    ids[3, 2] = 10 ** 9                      # beyond the table: skipped
+    ids[5, 0] = -4
+    ids = ids.to(DEV)
+    off = (torch.arange(F) * (N // F)).to(DEV)
+    job = _kernels.PrefetchRowsJob(ids.data_ptr(), off.data_ptr(), table.data_ptr(), table.data_ptr() + 4 * D, 32, 32, B, N, F)
+    for shapes, kernel in (([(400, 416, 4096), (64, 64, 32), (132, 260, 2048)], "gemm_tn_multi"), ([(30, 50, 70)], "gemm_f32_multi")):
+        probs, refs = [], []
+        for (M, Nn, K) in shapes:
+            A, Bm = _mk((K, M), gen), _mk((K, Nn), gen)
+            probs.append(dict(A=A.to(DEV), B=Bm.to(DEV), C=torch.zeros(M, Nn, device=DEV), M=M, N=Nn, K=K, lda=M, ldb=Nn, ldc=Nn))
+            refs.append(A.t() @ Bm)
+        with KernelTimer(16) as kt:
+            _kernels.gemm_multi(probs, transA=True, ride=job)
+        names = [k for k, _ in kt.records]
+        if os.environ.get("MI_GEMM_TN_DMA") != "0":
+            assert names == ([kernel] if kernel == "gemm_tn_multi" else ["prefetch_rows", kernel]), names
+        for q, ref in zip(probs, refs):
+            assert torch.equal(q["C"].cpu(), ref)
+    with KernelTimer(16) as kt:
+        _kernels.gemm_multi([], transA=True, ride=job)
+    assert [k for k, _ in kt.records] == ["prefetch_rows"]
+    torch.cuda.synchronize()
+    _lib.check_index_errors()
