@@ -87,6 +87,8 @@ class GraphedTrainStep:
         self.criterion = criterion if criterion is not None else losses.BCEWithLogitsLoss()
         self._labels_in_forward = (isinstance(self.criterion, losses.BCEWithLogitsLoss)
                                    and "labels" in inspect.signature(model.forward).parameters)
+        self._prefetches = callable(getattr(model, "prefetch_next", None))
+        self._static_next = None
         self.warmup = warmup
         self.clip_grad = clip_grad
         # clip_grad_norm_ reads the norm back on some paths and row-form gradients have no dense norm: eager only
@@ -127,14 +129,21 @@ class GraphedTrainStep:
 
     def _capture(self, inputs, labels):
         static_in, static_lab = inputs.clone(), labels.clone()
+        # a model that can use the NEXT batch's ids (DeepFM.prefetch_next: the step's weight-gradient launch touches that
+        # batch's table rows in extra workgroups) reads them from a static buffer the caller refreshes per step
+        static_next = inputs.clone() if self._prefetches else None
         for opt in self.optimizers:
             opt.zero_grad(set_to_none=True)        # the captured backward allocates the gradients in the graph's pool
         graph = torch.cuda.CUDAGraph()
+        if static_next is not None:
+            self.model.prefetch_next(static_next)
         with _capture(graph):
             static_loss = self._body(static_in, static_lab)
-        self._graph, self._static = graph, (static_in, static_lab, static_loss)
+        self._graph, self._static, self._static_next = graph, (static_in, static_lab, static_loss), static_next
 
-    def __call__(self, inputs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    def __call__(self, inputs: torch.Tensor, labels: torch.Tensor, next_inputs: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """next_inputs (optional): the batch of the FOLLOWING step, already on the device — a loop that is one batch ahead of
+        the step (train_epoch is) lets the step pull that batch's table rows into the Infinity Cache."""
         if not inputs.is_cuda:
             raise RuntimeError("GraphedTrainStep runs on the GPU: move the batch to the model's device first")
         if self.loss_sum is None:
@@ -154,6 +163,8 @@ class GraphedTrainStep:
             static_in, static_lab, static_loss = self._static
             static_in.copy_(inputs, non_blocking=True)
             static_lab.copy_(labels, non_blocking=True)
+            if self._static_next is not None and next_inputs is not None and next_inputs.shape == self._static_next.shape:
+                self._static_next.copy_(next_inputs, non_blocking=True)
             self._graph.replay()
             self.last_loss = static_loss
             return static_loss
@@ -161,6 +172,8 @@ class GraphedTrainStep:
             if self._shape != shape:
                 self._shape, self._seen = shape, 0
             self._seen += 1
+        if self._prefetches and next_inputs is not None and next_inputs.shape == inputs.shape:
+            self.model.prefetch_next(next_inputs)
         self.last_loss = self._body(inputs, labels)
         return self.last_loss
 
@@ -179,10 +192,20 @@ def train_epoch(dataloader, model, optimizers: Union[List[torch.optim.Optimizer]
     load_data_time, train_time = datetime.timedelta(), datetime.timedelta()
     first_start = start = now()
     idx = -1
-    for idx, (inputs, labels) in enumerate(dataloader):
+    # one batch ahead of the step (the DataLoader's workers are anyway): the step is told the next batch's ids
+    batches = iter(dataloader)
+    ahead = next(batches, None)
+    if ahead is not None:
+        ahead = (ahead[0].to(device, non_blocking=True), ahead[1].to(device, non_blocking=True))
+    while ahead is not None:
+        idx += 1
+        inputs, labels = ahead
+        ahead = next(batches, None)
+        if ahead is not None:
+            ahead = (ahead[0].to(device, non_blocking=True), ahead[1].to(device, non_blocking=True))
         load_data_time += now() - start
         start_train = now()
-        step(inputs.to(device, non_blocking=True), labels.to(device, non_blocking=True))
+        step(inputs, labels, next_inputs=ahead[0] if ahead is not None else None)
         if log_step and idx % log_step == 0:
             logger.info("Idx: %d - loss: %.4g", idx, (float(step.loss_sum) - first_sum) / (idx + 1))
             _check_errors(model)             # the reference's nn.Embedding raises on the offending batch; here at the next sync
