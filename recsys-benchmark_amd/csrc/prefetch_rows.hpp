@@ -25,6 +25,9 @@ __device__ __forceinline__ void prefetch_rows_blocks(const PrefetchJob &j, int b
       if (j.w1) s += j.w1[row * j.ldw1];
     }
   }
+  // the sum is "used" by an empty asm: with a sink pointer the compiler can prove null (a rider's call) the loads would be
+  // dead code and vanish — measured: riders that cost nothing and bought nothing
+  asm volatile("" ::"v"(s));
   if (sink && s == 1.2345e-30f) sink[0] = s;
 }
 
