@@ -1030,44 +1030,6 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // The epilogue's global loads — the saved rows, sums and g_y of the FM form; the layer below's pre-activations, keep bits
-  // and constants of the MID form — do not depend on the product: they are ISSUED HERE, in front of the main loop, and
-  // waited for behind it (they used to be issued in the epilogue: one exposed round trip, ~1.5 us of a 25 us kernel; the
-  // registers that hold them, <= 44 per thread, are free — 151 of 256 in use).  Being the oldest loads of their waves they
-  // are long back by any later vmcnt wait of the producers.
-  const int t = threadIdx.x;
-  float4 h_e[4], h_sm[4];
-  float h_gy[4];
-  int64_t h_sl[4] = {0, 0, 0, 0};
-  bool h_ok[4];
-  float4 h_z[4], h_u = zero4(), h_sc = zero4(), h_be = zero4();
-  uint32_t h_kb[4];
-  if constexpr (FM) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
-      h_ok[k] = i < 64 * 28 && row < rows_valid && c < cols_valid;
-      const int m = m0 + (h_ok[k] ? row : 0), kc = k0 + (h_ok[k] ? c : 0);
-      h_e[k] = ld4(a.fm_emb + (int64_t)m * a.K + kc);
-      h_sm[k] = ld4(a.fm_sum + (int64_t)m * a.fm_D + kc % a.fm_D);
-      h_gy[k] = a.fm_gy[m];
-      if (a.fm_slot) h_sl[k] = a.fm_slot[(int64_t)m * (a.K / a.fm_D) + kc / a.fm_D];
-    }
-  } else if constexpr (MID) {
-    const Drop drop = make_drop(a.prev.keep, a.prev.p, a.prev.ld);
-    const int cg = t % 28, rl = t / 28, c = cg * 4, kc = k0 + c;
-    if (rl < 18 && c < cols_valid) {
-      h_u = ld4(a.prev.mu + kc); h_sc = ld4(a.prev.sc + kc); h_be = ld4(a.prev.be + kc);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int row = rl + 18 * k;
-        const int rc = row < rows_valid ? row : rows_valid - 1;
-        h_z[k] = ld4(a.prev.Z + (int64_t)(m0 + rc) * a.prev.ld + kc);
-        h_kb[k] = drop.fetch(m0 + rc, kc);
-      }
-    }
-  }
-
   const LoadDz dzl = make_dz(a.dz);
   const LoadPlain dyp{a.dz.DY, a.dz.ld};
   const LoadPlain wp{a.W, a.ldw};     // [red = n][out = k]
@@ -1087,25 +1049,40 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
   float *T = lds;
   acc_to_lds(acc, T, wave, lane);
   __syncthreads();
+  const int t = threadIdx.x;
   if constexpr (FM) {
     static_assert(!MID, "the FM epilogue belongs to the product whose output is the tail's input gradient");
-    // (the saved rows, sums, g_y and slots were loaded in front of the main loop: h_*)
+    // all loads of the thread's four chunks first (saved rows from HBM / Infinity Cache, sums and gy from L2), then the
+    // arithmetic: one round trip for the epilogue
+    float4 e[4], sm[4], da[4];
+    float gy[4];
+    int64_t sl[4] = {0, 0, 0, 0};
+    bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
-      if (h_ok[k]) {
-        const float4 da = ld4(T + row * kTilePitch + c);
-        const float gy = h_gy[k];
+      ok[k] = i < 64 * 28 && row < rows_valid && c < cols_valid;
+      const int m = m0 + (ok[k] ? row : 0), kc = k0 + (ok[k] ? c : 0);
+      e[k] = ld4(a.fm_emb + (int64_t)m * a.K + kc);
+      sm[k] = ld4(a.fm_sum + (int64_t)m * a.fm_D + kc % a.fm_D);
+      gy[k] = a.fm_gy[m];
+      da[k] = ld4(T + (ok[k] ? row : 0) * kTilePitch + (ok[k] ? c : 0));
+      if (a.fm_slot) sl[k] = a.fm_slot[(int64_t)m * (a.K / a.fm_D) + kc / a.fm_D];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
+      if (ok[k]) {
         float4 o;
-        o.x = da.x + gy * (h_sm[k].x - h_e[k].x);
-        o.y = da.y + gy * (h_sm[k].y - h_e[k].y);
-        o.z = da.z + gy * (h_sm[k].z - h_e[k].z);
-        o.w = da.w + gy * (h_sm[k].w - h_e[k].w);
+        o.x = da[k].x + gy[k] * (sm[k].x - e[k].x);
+        o.y = da[k].y + gy[k] * (sm[k].y - e[k].y);
+        o.z = da[k].z + gy[k] * (sm[k].z - e[k].z);
+        o.w = da[k].w + gy[k] * (sm[k].w - e[k].w);
         if (a.fm_slot) {
-          float *dst = a.OUT + h_sl[k] * a.fm_pitch;
+          float *dst = a.OUT + sl[k] * a.fm_pitch;
           const int d = (k0 + c) % a.fm_D;
           st4(dst + d, o);
-          if (d == 0) dst[a.fm_D] = gy;             // (the chunk that opens a field also writes its first-order value)
+          if (d == 0) dst[a.fm_D] = gy[k];          // (the chunk that opens a field also writes its first-order value)
         } else {
           st4(a.OUT + (int64_t)(m0 + row) * a.ldo + k0 + c, o);
         }
@@ -1130,20 +1107,23 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
     const bool cv = rl < 18 && c < cols_valid;
     float4 s_dy = zero4(), s_dyz = zero4();
     if (cv) {
-      // (z, the keep bits and the constants of the layer below were loaded in front of the main loop: h_*)
-      const float4 u = h_u, sc = h_sc, be = h_be;
-      float4 da[4];
+      const float4 u = ld4(a.prev.mu + kc), sc = ld4(a.prev.sc + kc), be = ld4(a.prev.be + kc);
+      float4 z[4], da[4];
+      uint32_t kb[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = rl + 18 * k;
+        const int rc = row < rows_valid ? row : rows_valid - 1;
+        z[k] = ld4(a.prev.Z + (int64_t)(m0 + rc) * a.prev.ld + kc);
+        kb[k] = drop.fetch(m0 + rc, kc);
         da[k] = ld4(T + (row < 64 ? row : 63) * kTilePitch + c);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = rl + 18 * k;
         if (row < rows_valid) {
-          const float4 kk = drop.scale4(h_kb[k], kc);
-          const float4 zc = make_float4(h_z[k].x - u.x, h_z[k].y - u.y, h_z[k].z - u.z, h_z[k].w - u.w);
+          const float4 kk = drop.scale4(kb[k], kc);
+          const float4 zc = make_float4(z[k].x - u.x, z[k].y - u.y, z[k].z - u.z, z[k].w - u.w);
           float4 dy;
           dy.x = fmaf(zc.x, sc.x, be.x) > 0.f ? da[k].x * kk.x : 0.f;
           dy.y = fmaf(zc.y, sc.y, be.y) > 0.f ? da[k].y * kk.y : 0.f;
