@@ -349,7 +349,7 @@ def gather_in_graph_us(model, xs, B, F, D, dev, copies=32, reps=20):
 
 def prefetched_gather_us(model, xs, B, F, D, hidden, dev, copies=32, reps=20):
     """The gather + FM forward in the regime a step with DeepFM.prefetch_next runs it in: the PREVIOUS launch was the tail's
-    weight-gradient launch (four products dz^T a, MFMA-bound) carrying, in extra workgroups, the touch of exactly the table rows
+    weight-gradient launch (three products dz^T a, MFMA-bound) carrying, in extra workgroups, the touch of exactly the table rows
     this gather reads.  In-graph wall per launch of
         P = [weight gradients + riders for batch i]                     Q = [the same, then gather(batch i)]
         R = [weight gradients alone]
