@@ -415,6 +415,9 @@ class DualGather(torch.autograd.Function):
         if rows is not None:
             idxc = rows              # the backward reads the finished row ids
             ctx.mark_non_differentiable(rows)
+            # (autograd would otherwise hand the backward a ZERO-FILLED int64 [B, F] "gradient" for the row ids: a fill launch
+            #  per step for a tensor nobody reads)
+            ctx.set_materialize_grads(False)
         ctx.save_for_backward(idxc, T1c, T2c, S1c, S2c, M1c, M2c)
         ctx.meta = (n, F, De, mod1, div2, op, xform)
         ctx.fields = fields if (fields is not None and idx.dim() == 2 and fields[3] == F) else None
@@ -425,6 +428,8 @@ class DualGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_rows=None):
+        if g is None:                # (materialisation is off when the row ids are a second output: nothing flowed back)
+            return (None,) * 14
         idxc, T1c, T2c, S1c, S2c, M1c, M2c = ctx.saved_tensors
         n, F, De, mod1, div2, op, xform = ctx.meta
         dev = g.device

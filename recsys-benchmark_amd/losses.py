@@ -155,11 +155,14 @@ class _BPRFn(torch.autograd.Function):
         if plus is not None:          # (sum, bare BPR term): the second is for logging only
             bare = loss[1]
             ctx.mark_non_differentiable(bare)
+            ctx.set_materialize_grads(False)      # (no zero-filled "gradient" of the bare term: a fill launch per step)
             return loss[0], bare
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g, _g_bare=None):
+        if g is None:
+            return (None,) * 8
         U, P, Nn, sig, *rest = ctx.saved_tensors
         it = iter(rest)
         idx = [next(it) if h else None for h in ctx.has_idx]
