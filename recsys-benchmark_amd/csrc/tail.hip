@@ -366,15 +366,15 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
     const LoadActL actl{a.x.Z, a.x.ld, c, c + kCstPitch, c + 2 * kCstPitch, act.drop};
     float *cst = lds + kLdsFloats;
     const bool writer = tile == 0;
-    main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadActL>>{Tee<LoadActL>{actl, a.a_out, a.x.ld, nt, a.ntn}, m0, rows_valid, a.K}, opC,
+    main_loop<true, true>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadActL>>{Tee<LoadActL>{actl, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC,
                           make_pre([&]() { bn_merge_fwd<kThreads - kProd>(a.bn, a.M, a.K, cst, writer, (int)threadIdx.x); }));
   } else if constexpr (DMA && ACT)      // the weights by LDS-DMA (two loader waves), the activation through two producer waves
-    main_loop_dma(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>, 128>{Tee<LoadAct>{act, a.a_out, a.x.ld, nt, a.ntn}, m0, rows_valid, a.K},
+    main_loop_dma(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>, 128>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K},
                   a.W, a.ldw, n0, cols_valid);
   else if constexpr (DMA)
     main_loop_dma(acc, lds, 0, a.K, KcOperand<64, LoadPlain, 128>{xp, m0, rows_valid, a.K}, a.W, a.ldw, n0, cols_valid);
   else if constexpr (ACT)
-    main_loop<true, true, NS>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, a.a_out, a.x.ld, nt, a.ntn}, m0, rows_valid, a.K}, opC);
+    main_loop<true, true, NS>(acc, lds, 0, a.K, KcOperand<64, Tee<LoadAct>>{Tee<LoadAct>{act, nt == 0 ? a.a_out : nullptr, a.x.ld}, m0, rows_valid, a.K}, opC);
   else main_loop<true, true, NS>(acc, lds, 0, a.K, KcOperand<64, LoadPlain>{xp, m0, rows_valid, a.K}, opC);
 
   // ---- epilogue.  A lane holds z[m0 + 16 wave + r][n0 + 16 s + 4 g + v] (waves 0-3); the tile goes through LDS once so
@@ -1039,10 +1039,10 @@ __global__ __launch_bounds__(kThreads) void k_tail_dgrad(DgradArgs a) {
     const LoadDzL dzm{a.dz.DY, a.dz.Z, a.dz.ld, c, c + kCstPitch, c + 2 * kCstPitch, c + 3 * kCstPitch};
     float *cst = lds + kLdsFloats;
     const bool writer = tile == 0, wwriter = tile == min(1, mt_total * a.ntn - 1);
-    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDzL>>{Tee<LoadDzL>{dzm, a.dz_out, a.dz.ld, nt, a.ntn}, m0, rows_valid, a.N}, opC,
+    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDzL>>{Tee<LoadDzL>{dzm, nt == 0 ? a.dz_out : nullptr, a.dz.ld}, m0, rows_valid, a.N}, opC,
                           make_pre([&]() { bn_merge_bwd<kThreads - kProd>(a.bn, a.M, a.N, cst, writer, wwriter, (int)threadIdx.x); }));
   } else if constexpr (DZ)
-    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDz>>{Tee<LoadDz>{dzl, a.dz_out, a.dz.ld, nt, a.ntn}, m0, rows_valid, a.N}, opC);
+    main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, Tee<LoadDz>>{Tee<LoadDz>{dzl, nt == 0 ? a.dz_out : nullptr, a.dz.ld}, m0, rows_valid, a.N}, opC);
   else main_loop<true, true>(acc, lds, 0, a.N, KcOperand<64, LoadPlain>{dyp, m0, rows_valid, a.N}, opC);
 
   // ---- epilogue through LDS (see k_tail_fwd): all 8 waves, whole row segments

@@ -229,17 +229,12 @@ struct Tee {
   L in;
   float *out;
   int ld;
-  // The column tiles of a row tile all load the same R operand: its copy to memory is SHARED between them, slice by slice —
-  // tile `own` of `nown` stores the BK-slices whose index is own modulo nown (one tile storing all of them made the 64
-  // workgroups that did the launch's stragglers).  nown = 1: this tile stores everything.
-  int own = 0, nown = 1;
   typedef typename L::Raw Raw;
   typedef typename L::Consts Consts;
   struct UBase { typename L::UBase in; float *out; };
   struct TC { typename L::TC in; uint32_t off; };
-  __device__ __forceinline__ bool mine(int col) const { return nown <= 1 || (col / BK) % nown == own; }
   __device__ __forceinline__ UBase ubase(int row, int col) const {
-    return UBase{in.ubase(row, col), (out && mine(col)) ? out + (int64_t)row * ld + col : nullptr};
+    return UBase{in.ubase(row, col), out ? out + (int64_t)row * ld + col : nullptr};
   }
   __device__ __forceinline__ TC tconst(int r, int c) const { return TC{in.tconst(r, c), (uint32_t)(r * ld + c) * 4u}; }
   __device__ __forceinline__ Raw fetch_u(const UBase &u, const TC &t) const { return in.fetch_u(u.in, t.in); }
@@ -253,7 +248,7 @@ struct Tee {
   __device__ __forceinline__ Consts consts(int c) const { return in.consts(c); }
   __device__ __forceinline__ float4 finish(const Raw &r, const Consts &k, int m, int c) const {
     const float4 v = in.finish(r, k, m, c);
-    if (out && mine(c)) vst4(out + (int64_t)m * ld + c, v);
+    if (out) vst4(out + (int64_t)m * ld + c, v);
     return v;
   }
 };
