@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 tag=$1; shift
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
   t=$(echo $set | tr ' ' '+')
   env "$@" timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc/_$tag.$t -- \
     python3 $R/bench.py --steps 5 --warmup 2 --windows 0 --no-cpu-baseline --no-graph --no-gather-leg --no-train-step --no-sweep --no-eager-leg > /dev/null 2> $R/gpurun_out/pmc/$tag.$t.err || echo "pass $t failed"
