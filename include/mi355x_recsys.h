@@ -907,6 +907,14 @@ MI_API int mi_tail_bn_finalize_fwd(const float *part, int32_t M, int32_t N, cons
  * (ride == NULL: the plain entry point).  The layer whose statistics are joined is the FIRST of the step, so every kernel
  * that reads keep bits comes later.  seed_bump must not point at ride->seed (MI_ERR_INVALID_ARG): a launch cannot both
  * draw from the seed and advance it; let a later finalize launch bump it.  Host struct, read at call time. */
+/* The arguments of mi_tail_affine_consts (below) as a host struct: a second job a carrying launch can take. */
+typedef struct mi_tail_affine_job {
+  int32_t nlayers;                          /* <= 8 */
+  const int32_t *widths;                    /* host [nlayers] */
+  const float *const *gamma, *const *beta, *const *running_mean, *const *running_var, *const *bias;   /* host arrays of device pointers */
+  const float *eps;                         /* host [nlayers] */
+  float *const *mu, *const *sc, *const *be, *const *rstd;                                             /* host arrays of device pointers */
+} mi_tail_affine_job;
 typedef struct mi_tail_mask_ride {
   const int64_t *seed;          /* device */
   int32_t nlayers;              /* <= 8 */
@@ -917,6 +925,9 @@ typedef struct mi_tail_mask_ride {
   uint8_t *const *bits;         /* host [nlayers] of device pointers (NULL where ps == 0) */
   float *zero_buf;              /* device, nullable */
   int64_t zero_floats;
+  const mi_tail_affine_job *affine;   /* nullable: the constants of the tail's fixed-statistics layers computed by further extra
+                                         workgroups (read by mi_gather_fm_fwd_ride only: an inference forward is the lookup, the
+                                         products and the head — no launch for the constants) */
 } mi_tail_mask_ride;
 MI_API int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, const float *gamma, const float *beta,
                                      const float *mean_offset, float *running_mean, float *running_var, float momentum,

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_ride(
     float *__restrict__ emb, float *__restrict__ yfm, int64_t *__restrict__ rows_out,
     int64_t B, int F, int64_t N, int64_t ldw, int64_t ldw1, int *err, float *__restrict__ sum_out, int ngather, MaskRide ride) {
   if ((int)blockIdx.x >= ngather) {
-    mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, (int)blockIdx.x - ngather, (int)gridDim.x - ngather);
+    const int rb = (int)blockIdx.x - ngather;
+    if (rb < ride.mask_blocks) mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, rb, ride.mask_blocks);
+    else affine_consts_blocks(ride.aff, rb - ride.mask_blocks, (int)gridDim.x - ngather - ride.mask_blocks);
     return;
   }
   // every workgroup of the launch is resident at once (1 024 + ~200 of the chip's 2 048 slots): the gather's waves wait on
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_fm_fwd_ride(
 }
 
 __global__ __launch_bounds__(kBlock) void k_mask_job(MaskRide ride) {
-  mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, (int)blockIdx.x, (int)gridDim.x);
+  const int rb = (int)blockIdx.x;
+  if (rb < ride.mask_blocks) mask_blocks(ride.j, ride.seed, ride.zero4, ride.nzero4, rb, ride.mask_blocks);
+  else affine_consts_blocks(ride.aff, rb - ride.mask_blocks, (int)gridDim.x - ride.mask_blocks);
 }
 
 // Any D (scalar accesses): wave per sample, lanes stride over d.
@@ -657,24 +661,33 @@ int mi_gather_fm_fwd_ride(const int64_t *idx, const int64_t *offsets, const floa
   r.seed = ride->seed;
   r.zero4 = reinterpret_cast<float4 *>(ride->zero_buf);
   r.nzero4 = ride->zero_floats / 4;
+  r.aff.nl = 0;
+  int aff_blocks = 0;
+  if (ride->affine) {
+    const mi_tail_affine_job *q = ride->affine;
+    const int rc2 = affine_job(q->nlayers, q->widths, q->gamma, q->beta, q->running_mean, q->running_var, q->bias, q->eps, q->mu,
+                               q->sc, q->be, q->rstd, r.aff, &aff_blocks);
+    if (rc2 != MI_OK) return rc2;
+  }
   const int lpr = D / 4, nit = vec_ok(D) ? nit_for(F, lpr) : 0;
   const bool fits = B > 0 && idx && W && w1 && emb_out && yfm_out && vec_ok(D) && aligned16(W) && (ldw & 3) == 0 &&
                     aligned16(emb_out) && nit > 0 && F <= kWave;      // (offsets may be NULL: slot lookups, mi_slot_fm_fwd's operands)
-  if (extra == 0 || !fits) {      // nothing to carry, or a gather form without the extra workgroups: two launches
-    if (extra > 0) {
-      MI_LAUNCH("tail_dropout_masks", k_mask_job, (int)extra, kBlock, stream, r);
+  // (mask workgroups: a quarter of what the job would take alone — each walks four strides — so the launch stays one wave
+  //  of workgroups over the chip's slots)
+  int nmask = (int)((extra + 3) / 4);
+  if (nmask > 1024) nmask = 1024;
+  r.mask_blocks = nmask;
+  if (nmask + aff_blocks == 0 || !fits) {      // nothing to carry, or a gather form without the extra workgroups: two launches
+    if (nmask + aff_blocks > 0) {
+      MI_LAUNCH("tail_dropout_masks", k_mask_job, nmask + aff_blocks, kBlock, stream, r);
       const int st = launch_status();
       if (st != MI_OK) return st;
     }
     return mi_gather_fm_fwd_sum(idx, offsets, W, ldw, w1, ldw1, bias, emb_out, yfm_out, rows_out, sum_out, B, F, D, N, err, stream);
   }
   const int ngather = grid_for_waves(B);
-  // (mask workgroups: a quarter of what the job would take alone — each walks four strides — so the launch stays one wave
-  //  of workgroups over the chip's slots)
-  int nmask = (int)((extra + 3) / 4);
-  if (nmask > 1024) nmask = 1024;
 #define CALL(LPR, NIT)                                                                                         \
-  MI_LAUNCH("gather_fm_fwd_ride", (k_gather_fm_fwd_ride<LPR, NIT>), ngather + nmask, kBlock, stream, idx, offsets, \
+  MI_LAUNCH("gather_fm_fwd_ride", (k_gather_fm_fwd_ride<LPR, NIT>), ngather + nmask + aff_blocks, kBlock, stream, idx, offsets, \
             W, w1, bias, emb_out, yfm_out, rows_out, B, F, N, ldw, ldw1, err, sum_out, ngather, r)
   MI_DISPATCH_LPR_NIT(lpr, nit, CALL)
 #undef CALL

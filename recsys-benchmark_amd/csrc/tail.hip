@@ -957,30 +957,8 @@ __global__ __launch_bounds__(kBlock) void k_bn_finalize_bwd(const float *__restr
 //   eval-mode BatchNorm (src/models/deepfm.py:57-58 under model.eval()): rstd = 1/sqrt(running_var + eps),
 //       mu = running_mean - b,  sc = gamma rstd,  be = beta
 //   no BatchNorm (DeepFM's default use_batchnorm=False):  mu = 0, sc = 1, be = b, rstd = 1
-struct AffineJob {
-  const float *gamma[8], *beta[8], *rmean[8], *rvar[8], *bias[8];
-  float *mu[8], *sc[8], *be[8], *rstd[8];
-  float eps[8];
-  int n[8];
-  int nl;
-};
 __global__ __launch_bounds__(kBlock) void k_tail_affine_consts(AffineJob j) {
-  const int l = blockIdx.y;
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (l >= j.nl || c >= j.n[l]) return;
-  const float b = j.bias[l] ? j.bias[l][c] : 0.f;
-  if (j.rvar[l]) {
-    const float r = rsqrtf(j.rvar[l][c] + j.eps[l]);
-    j.mu[l][c] = j.rmean[l][c] - b;
-    j.sc[l][c] = (j.gamma[l] ? j.gamma[l][c] : 1.f) * r;
-    j.be[l][c] = j.beta[l] ? j.beta[l][c] : 0.f;
-    j.rstd[l][c] = r;
-  } else {
-    j.mu[l][c] = 0.f;
-    j.sc[l][c] = 1.f;
-    j.be[l][c] = b;
-    j.rstd[l][c] = 1.f;
-  }
+  affine_consts_blocks(j, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ============================================================================================== dgrad GEMM ====
@@ -1340,6 +1318,7 @@ int mi_tail_bn_finalize_fwd_r(const float *part, int32_t M, int32_t N, const flo
   const int nfin = (N + kFinCols - 1) / kFinCols;
   MaskRide r;
   r.j.n = 0; r.seed = nullptr; r.zero4 = nullptr; r.nzero4 = 0;
+  r.mask_blocks = 0; r.aff.nl = 0;      // (this launch carries the keep bits / zero fill only: ride->affine is not read here)
   int64_t extra = 0;
   if (ride) {
     if (seed_bump && seed_bump == ride->seed) return MI_ERR_INVALID_ARG;      // the bits are drawn from it in this launch
@@ -1481,22 +1460,11 @@ int mi_tail_affine_consts(int32_t nlayers, const int32_t *widths, const float *c
                           const float *const *running_mean, const float *const *running_var, const float *const *bias,
                           const float *eps, float *const *mu, float *const *sc, float *const *be, float *const *rstd,
                           void *stream) {
-  if (nlayers < 0 || nlayers > 8) return MI_ERR_INVALID_ARG;
-  if (nlayers == 0) return MI_OK;
-  if (!widths || !gamma || !beta || !running_mean || !running_var || !bias || !eps || !mu || !sc || !be || !rstd)
-    return MI_ERR_INVALID_ARG;
   AffineJob j;
-  j.nl = nlayers;
-  int widest = 0;
-  for (int l = 0; l < nlayers; ++l) {
-    if (widths[l] <= 0 || !mu[l] || !sc[l] || !be[l] || !rstd[l]) return MI_ERR_INVALID_ARG;
-    if ((running_mean[l] == nullptr) != (running_var[l] == nullptr)) return MI_ERR_INVALID_ARG;
-    j.gamma[l] = gamma[l]; j.beta[l] = beta[l]; j.rmean[l] = running_mean[l]; j.rvar[l] = running_var[l]; j.bias[l] = bias[l];
-    j.mu[l] = mu[l]; j.sc[l] = sc[l]; j.be[l] = be[l]; j.rstd[l] = rstd[l];
-    j.eps[l] = eps[l]; j.n[l] = widths[l];
-    widest = widths[l] > widest ? widths[l] : widest;
-  }
-  MI_LAUNCH("tail_affine_consts", k_tail_affine_consts, dim3((widest + kBlock - 1) / kBlock, nlayers), kBlock, stream, j);
+  int blocks = 0;
+  const int rc = affine_job(nlayers, widths, gamma, beta, running_mean, running_var, bias, eps, mu, sc, be, rstd, j, &blocks);
+  if (rc != MI_OK || blocks == 0) return rc;
+  MI_LAUNCH("tail_affine_consts", k_tail_affine_consts, blocks, kBlock, stream, j);
   return launch_status();
 }
 

@@ -39,12 +39,69 @@ __device__ __forceinline__ void mask_blocks(const MaskJob &j, const int64_t *see
     }
   }
 }
-// the job as a kernel argument
+// Per-column constants (mu, sc, be, rstd) of layers that normalise with FIXED statistics or not at all (eval-mode BatchNorm,
+// use_batchnorm=False: see k_tail_affine_consts, tail.hip) — up to 8 layers, a job like the keep bits: its own launch
+// (mi_tail_affine_consts) or extra workgroups of the lookup in front of the tail (an inference forward is six launches of a
+// few microseconds each: one fewer is 8 % of its latency at batch 64).
+struct AffineJob {
+  const float *gamma[8], *beta[8], *rmean[8], *rvar[8], *bias[8];
+  float *mu[8], *sc[8], *be[8], *rstd[8];
+  float eps[8];
+  int n[8];
+  int nl;
+};
+__device__ __forceinline__ void affine_consts_blocks(const AffineJob &j, int blk, int nblk) {
+  for (int l = 0; l < j.nl; ++l) {
+    for (int c = blk * kBlock + (int)threadIdx.x; c < j.n[l]; c += nblk * kBlock) {
+      const float b = j.bias[l] ? j.bias[l][c] : 0.f;
+      if (j.rvar[l]) {
+        const float r = rsqrtf(j.rvar[l][c] + j.eps[l]);
+        j.mu[l][c] = j.rmean[l][c] - b;
+        j.sc[l][c] = (j.gamma[l] ? j.gamma[l][c] : 1.f) * r;
+        j.be[l][c] = j.beta[l] ? j.beta[l][c] : 0.f;
+        j.rstd[l][c] = r;
+      } else {
+        j.mu[l][c] = 0.f;
+        j.sc[l][c] = 1.f;
+        j.be[l][c] = b;
+        j.rstd[l][c] = 1.f;
+      }
+    }
+  }
+}
+// host: builds the job from mi_tail_affine_consts' arguments; *blocks = workgroups that suit it (0: nothing to do)
+inline int affine_job(int32_t nlayers, const int32_t *widths, const float *const *gamma, const float *const *beta,
+                      const float *const *running_mean, const float *const *running_var, const float *const *bias,
+                      const float *eps, float *const *mu, float *const *sc, float *const *be, float *const *rstd, AffineJob &j,
+                      int *blocks) {
+  *blocks = 0;
+  j.nl = 0;
+  if (nlayers < 0 || nlayers > 8) return MI_ERR_INVALID_ARG;
+  if (nlayers == 0) return MI_OK;
+  if (!widths || !gamma || !beta || !running_mean || !running_var || !bias || !eps || !mu || !sc || !be || !rstd)
+    return MI_ERR_INVALID_ARG;
+  j.nl = nlayers;
+  int widest = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    if (widths[l] <= 0 || !mu[l] || !sc[l] || !be[l] || !rstd[l]) return MI_ERR_INVALID_ARG;
+    if ((running_mean[l] == nullptr) != (running_var[l] == nullptr)) return MI_ERR_INVALID_ARG;
+    j.gamma[l] = gamma[l]; j.beta[l] = beta[l]; j.rmean[l] = running_mean[l]; j.rvar[l] = running_var[l]; j.bias[l] = bias[l];
+    j.mu[l] = mu[l]; j.sc[l] = sc[l]; j.be[l] = be[l]; j.rstd[l] = rstd[l];
+    j.eps[l] = eps[l]; j.n[l] = widths[l];
+    widest = widths[l] > widest ? widths[l] : widest;
+  }
+  *blocks = (widest + kBlock - 1) / kBlock;
+  return MI_OK;
+}
+
+// the jobs as a kernel argument
 struct MaskRide {
   MaskJob j;
   const int64_t *seed;
   float4 *zero4;
   int64_t nzero4;
+  int mask_blocks;      // workgroups of the keep bits + zero fill (0: none); the affine job's follow them
+  AffineJob aff;        // aff.nl == 0: none
 };
 // builds the device job; *grid = workgroups that suit it (0: nothing to do)
 inline int mask_job(const int64_t *seed, int32_t nlayers, const int64_t *salts, const float *ps, const int32_t *lds,

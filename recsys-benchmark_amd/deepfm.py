@@ -122,7 +122,7 @@ class DeepFM(nn.Module):
         from . import mlp as _mlp, tail as _tail
 
         emb_mod = getattr(self, "embedding", None)
-        if not (_mlp.FUSED_TAIL and _tail.FM_EPILOGUE and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
+        if not (_mlp.FUSED_TAIL and _tail.FM_EPILOGUE and x.is_cuda and x.dim() == 2
                 and type(emb_mod) is VanillaEmbedding and emb_mod._mode is None):
             return None
         W, w1 = emb_mod.get_weight(), self.fc.weight
@@ -130,9 +130,11 @@ class DeepFM(nn.Module):
         if (not _kernels._float4_rows(W.shape[1]) or W.dtype != torch.float32 or W.device != x.device
                 or x.shape[1] != self.offsets.numel()):
             return None
-        wants = W.requires_grad or w1.requires_grad
-        if not ((sparse_W and W.requires_grad) or (sparse_w1 and w1.requires_grad) or (_kernels.DETERMINISTIC and wants)):
+        wants = (W.requires_grad or w1.requires_grad) and torch.is_grad_enabled()
+        if wants and not ((sparse_W and W.requires_grad) or (sparse_w1 and w1.requires_grad) or _kernels.DETERMINISTIC):
             return None              # dense weight.grad by float atomics: the scatter kernel of the two-node path
+        # (no gradient wanted — an inference forward, validation under no_grad: the same node, forward only; the lookup
+        #  launch then also computes the constants of the tail's fixed-statistics layers)
         groups = _mlp._groups(self._deep_branch)
         plan = _tail.fused_tail_plan(self._deep_branch, _tail._InputSpec(x.shape[0], x.shape[1] * W.shape[1], W.device), groups)
         if plan is None:

@@ -68,7 +68,14 @@ class _BnBwd(ctypes.Structure):          # mi_tail_bn_bwd
 class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
     _fields_ = [("seed", ctypes.c_void_p), ("nlayers", ctypes.c_int32), ("M", ctypes.c_int32), ("salts", ctypes.c_void_p),
                 ("ps", ctypes.c_void_p), ("lds", ctypes.c_void_p), ("bits", ctypes.c_void_p), ("zero_buf", ctypes.c_void_p),
-                ("zero_floats", ctypes.c_int64)]
+                ("zero_floats", ctypes.c_int64), ("affine", ctypes.c_void_p)]
+
+
+class _AffineJob(ctypes.Structure):      # mi_tail_affine_job
+    _fields_ = [("nlayers", ctypes.c_int32), ("widths", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("eps", ctypes.c_void_p), ("mu", ctypes.c_void_p), ("sc", ctypes.c_void_p), ("be", ctypes.c_void_p),
+                ("rstd", ctypes.c_void_p)]
 
 
 def _bn_fwd_struct(part, L, c, seed_bump, shift=None, nrep=0) -> "_BnFwd":
@@ -154,7 +161,7 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Option
     nzero = zero_buf.numel() if zero_buf is not None else 0
     if ride:
         job = _MaskRide(seed.data_ptr(), n, M, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
-                        ctypes.addressof(ptrs), _lib.ptr(zero_buf), nzero)
+                        ctypes.addressof(ptrs), _lib.ptr(zero_buf), nzero, None)
         return bits, (job, salts, ps, lds, ptrs)
     _lib.check(lib.mi_tail_dropout_masks_z(seed.data_ptr(), n, ctypes.addressof(salts), ctypes.addressof(ps), ctypes.addressof(lds),
                                            ctypes.addressof(ptrs), M, _lib.ptr(zero_buf), nzero, _lib.stream_ptr(dev)),
@@ -162,12 +169,13 @@ def _masks(seed: torch.Tensor, plan: List[_Layer], M: int, dev, zero_buf: Option
     return bits
 
 
-def _fixed_constants(plan: List[_Layer], dev, stream):
+def _fixed_constants(plan: List[_Layer], dev, stream, defer: bool = False):
     """(mu, sc, be, rstd) [4, N] of every layer that normalises with fixed statistics or not at all, ONE launch for all of
-    them (mi_tail_affine_consts); {layer index: tensor}."""
+    them (mi_tail_affine_consts); {layer index: tensor}.  defer: nothing is launched — returns (tensors, job) with job a
+    (mi_tail_affine_job, host arrays it points at) for a launch that carries it (the lookup in front of the tail), or None."""
     idx = [i for i, L in enumerate(plan) if L.fixed]
     if not idx:
-        return {}
+        return ({}, None) if defer else {}
     n = len(idx)
     out = {i: torch.empty((4, plan[i].lin.out_features), dtype=torch.float32, device=dev) for i in idx}
     P = ctypes.c_void_p * n
@@ -185,6 +193,11 @@ def _fixed_constants(plan: List[_Layer], dev, stream):
     rme, rva = arr(lambda L: bn_of(L, "running_mean")), arr(lambda L: bn_of(L, "running_var"))
     bia = arr(lambda L: _lib.ptr(L.lin.bias))
     outs = [P(*[out[i][r].data_ptr() for i in idx]) for r in range(4)]
+    if defer:
+        job = _AffineJob(n, ctypes.addressof(widths), ctypes.addressof(gam), ctypes.addressof(bet), ctypes.addressof(rme),
+                         ctypes.addressof(rva), ctypes.addressof(bia), ctypes.addressof(eps), ctypes.addressof(outs[0]),
+                         ctypes.addressof(outs[1]), ctypes.addressof(outs[2]), ctypes.addressof(outs[3]))
+        return out, (job, widths, eps, gam, bet, rme, rva, bia, outs)
     _lib.check(_lib.load().mi_tail_affine_consts(
         n, ctypes.addressof(widths), ctypes.addressof(gam), ctypes.addressof(bet), ctypes.addressof(rme), ctypes.addressof(rva),
         ctypes.addressof(bia), ctypes.addressof(eps), ctypes.addressof(outs[0]), ctypes.addressof(outs[1]),
@@ -293,15 +306,22 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
     # exists (a training-mode BatchNorm on the first layer) and a LATER kernel can advance the seed
     ride = RIDE_MASKS and not merge and k >= 2 and not plan[0].fixed and not lead_ride
     if lead_ride:
+        # the launch in front of the tail carries the keep bits, the zero fill AND the constants of the fixed-statistics layers
         bits, lead_job = _masks(seed, plan, M, dev, zeros, ride=True)
-        x, last_add = lead.launch(lead_job[0] if lead_job is not None else None)
+        fixed_c, aff = _fixed_constants(plan, dev, s, defer=True)
+        ride_struct = lead_job[0] if lead_job is not None else None
+        if aff is not None:
+            if ride_struct is None:
+                ride_struct = _MaskRide(None, 0, M, None, None, None, None, None, 0, None)
+            ride_struct.affine = ctypes.addressof(aff[0])
+        x, last_add = lead.launch(ride_struct)
         job = None
     else:
         if lead is not None:
             x, last_add = lead.launch(None)
         bits, job = _masks(seed, plan, M, dev, zeros, ride=True) if ride else (_masks(seed, plan, M, dev, zeros), None)
+        fixed_c = _fixed_constants(plan, dev, s)
     keep_inputs = grad and not _kernels.DETERMINISTIC
-    fixed_c = _fixed_constants(plan, dev, s)
     Zs, consts, acts = [], [], []
     prev, prev_c, prev_p, prev_bits = x, None, 0.0, None
     any_bits = any(b is not None for b in bits)
