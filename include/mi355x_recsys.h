@@ -852,6 +852,22 @@ MI_API int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, co
                               float *part, float *a_out, int32_t M, int32_t N, int32_t K,
                               const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
                               const float *shift_running_mean, const float *shift_mean_offset, void *stream);
+/* An INFERENCE forward's last hidden layer with the head in its epilogue (eval-mode BatchNorm or none on that layer, no
+ * dropout, nothing kept): z = a(X) W^T is not stored; every 64-row x <= 112-column tile adds
+ * sum_n relu((z - mu[n]) sc[n] + be[n]) w[n] into out[m] with a float atomic (out ZEROED by an earlier launch — the lookup's
+ * riders do it in DeepFM's forward; column tile 0 also adds b[0] and add[m]): src/models/deepfm.py:100-105 under
+ * model.eval() as one launch less. */
+typedef struct mi_tail_head_in_epilogue {
+  const float *w;            /* [N] the head Linear(N, 1)'s weight */
+  const float *b;            /* [1], nullable */
+  const float *add;          /* [M], nullable (DeepFM: y_fm) */
+  const float *mu, *sc, *be; /* [N] constants of THIS layer's activation (mi_tail_affine_consts) */
+  float *out;                /* [M] logits, zero on entry */
+} mi_tail_head_in_epilogue;
+MI_API int mi_tail_fwd_gemm_head(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be,
+                                 float x_p, const uint8_t *x_keep, const float *W, int32_t ldw, int32_t M, int32_t N,
+                                 int32_t K, const mi_tail_bn_fwd *x_stats, const mi_tail_head_in_epilogue *head,
+                                 void *stream);
 MI_API int mi_tail_dgrad_gemm_s(const float *DY, const float *Zl, int32_t ld, const float *mu, const float *al,
                                 const float *bz, const float *de, const float *W, int32_t ldw, const float *pZ,
                                 int32_t pld, const float *p_mu, const float *p_sc, const float *p_be, float p_p,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "mi_tail_dropout_masks_z": [_p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p],
     "mi_tail_fwd_gemm": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p],
     "mi_tail_fwd_gemm_m": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p],
+    "mi_tail_fwd_gemm_head": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "mi_tail_fwd_gemm_s": [_p, _i32, _p, _p, _p, ctypes.c_float, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p],
     "mi_tail_dgrad_gemm_s": [_p, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, ctypes.c_float, _p, _p,
                              _i32, _p, _i32, _p, _i32, _i32, _i32, _p, _p],

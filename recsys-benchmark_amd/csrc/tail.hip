@@ -336,6 +336,12 @@ struct FwdArgs {
   int stat_rep;
   float *stat_shift;
   const float *stat_rm, *stat_off;
+  // head_w != null (an INFERENCE forward's last hidden layer: fixed statistics, no dropout, nothing kept for a backward): the
+  // head Linear(., 1) runs in this epilogue — a tile's 64 x ncols values go through relu((z - mu) sc + be), are dotted with
+  // its slice of the head's weight and ADDED into head_out[m] (zeroed by an earlier launch; column tile 0 also adds the
+  // bias and head_add[m]); Z is not stored.  One launch less per forward, 4 float atomics per logit.
+  const float *head_w, *head_b, *head_add, *h_mu, *h_sc, *h_be;
+  float *head_out;
 };
 
 // NS: the 16-column sub-tiles a workgroup computes (7 = up to 112 columns: the training shapes, one workgroup per CU at
@@ -383,6 +389,30 @@ __global__ __launch_bounds__(kThreads) void k_tail_fwd(FwdArgs a) {
   acc_to_lds(acc, T, wave, lane);
   __syncthreads();
   const int t = threadIdx.x;
+  if (a.head_w) {      // thread (row = t / 8, part = t % 8): float4 chunks part, part + 8, part + 16, part + 24 of the row's tile
+    const int row = t >> 3, part = t & 7;
+    float sum = 0.f;
+    if (row < rows_valid) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (part + 8 * j) * 4;
+        if (c < cols_valid) {
+          const float4 z = ld4(T + row * kTilePitch + c);
+          const float4 u = ld4(a.h_mu + n0 + c), sc = ld4(a.h_sc + n0 + c), be = ld4(a.h_be + n0 + c), w = ld4(a.head_w + n0 + c);
+          sum += fmaxf(fmaf(z.x - u.x, sc.x, be.x), 0.f) * w.x + fmaxf(fmaf(z.y - u.y, sc.y, be.y), 0.f) * w.y +
+                 fmaxf(fmaf(z.z - u.z, sc.z, be.z), 0.f) * w.z + fmaxf(fmaf(z.w - u.w, sc.w, be.w), 0.f) * w.w;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    if (part == 0 && row < rows_valid) {
+      if (nt == 0) sum += (a.head_b ? a.head_b[0] : 0.f) + (a.head_add ? a.head_add[m0 + row] : 0.f);
+      atomicAdd(a.head_out + m0 + row, sum);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = t + k * kThreads, row = i / 28, c = (i % 28) * 4;
@@ -1231,15 +1261,38 @@ int mi_tail_fwd_gemm_m(const float *X, int32_t ldx, const float *x_mu, const flo
                             nullptr, nullptr, stream);
 }
 
+static int fwd_launch(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                      const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                      int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
+                      const float *shift_running_mean, const float *shift_mean_offset, const mi_tail_head_in_epilogue *head,
+                      void *stream);
+
 int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
                        const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
                        int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
                        const float *shift_running_mean, const float *shift_mean_offset, void *stream) {
+  return fwd_launch(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, Z, ldz, part, a_out, M, N, K, x_stats, sum_reps, shift_out,
+                    shift_running_mean, shift_mean_offset, nullptr, stream);
+}
+
+int mi_tail_fwd_gemm_head(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                          const uint8_t *x_keep, const float *W, int32_t ldw, int32_t M, int32_t N, int32_t K,
+                          const mi_tail_bn_fwd *x_stats, const mi_tail_head_in_epilogue *head, void *stream) {
+  if (!head) return MI_ERR_INVALID_ARG;
+  return fwd_launch(X, ldx, x_mu, x_sc, x_be, x_p, x_keep, W, ldw, nullptr, N, nullptr, nullptr, M, N, K, x_stats, 0, nullptr,
+                    nullptr, nullptr, head, stream);
+}
+
+static int fwd_launch(const float *X, int32_t ldx, const float *x_mu, const float *x_sc, const float *x_be, float x_p,
+                      const uint8_t *x_keep, const float *W, int32_t ldw, float *Z, int32_t ldz, float *part, float *a_out,
+                      int32_t M, int32_t N, int32_t K, const mi_tail_bn_fwd *x_stats, int32_t sum_reps, float *shift_out,
+                      const float *shift_running_mean, const float *shift_mean_offset, const mi_tail_head_in_epilogue *head,
+                      void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return MI_ERR_INVALID_ARG;
   if (sum_reps < 0 || sum_reps > 64 || (sum_reps > 0 && (!part || !shift_out || ((uintptr_t)part & 7)))) return MI_ERR_INVALID_ARG;
   if (M == 0) return MI_OK;
-  if (!X || !W || !Z) return MI_ERR_INVALID_ARG;
-  if (!vec_ok(X, ldx) || !vec_ok(W, ldw) || !vec_ok(Z, ldz) || N % 4 || K % 4) return MI_ERR_UNSUPPORTED;
+  if (!X || !W || (!Z && !head)) return MI_ERR_INVALID_ARG;
+  if (!vec_ok(X, ldx) || !vec_ok(W, ldw) || (Z && !vec_ok(Z, ldz)) || N % 4 || K % 4) return MI_ERR_UNSUPPORTED;
   FwdArgs a;
   a.bn = BnFwd{};
   if (x_stats) {            // the constants of X are joined in the kernel's prologue and written to x_stats->mu / sc / be
@@ -1252,6 +1305,12 @@ int mi_tail_fwd_gemm_s(const float *X, int32_t ldx, const float *x_mu, const flo
   a.x = ActDesc{X, ldx, x_mu, x_sc, x_be, x_p, x_keep};
   a.W = W; a.ldw = ldw; a.Z = Z; a.ldz = ldz; a.part = part;
   a.stat_rep = sum_reps; a.stat_shift = shift_out; a.stat_rm = shift_running_mean; a.stat_off = shift_mean_offset;
+  a.head_w = head ? head->w : nullptr;
+  if (head) {
+    if (!head->w || !head->out || !head->mu || !head->sc || !head->be || part || a_out || sum_reps) return MI_ERR_INVALID_ARG;
+    if (!aligned16(head->w) || !aligned16(head->mu) || !aligned16(head->sc) || !aligned16(head->be)) return MI_ERR_UNSUPPORTED;
+    a.head_b = head->b; a.head_add = head->add; a.h_mu = head->mu; a.h_sc = head->sc; a.h_be = head->be; a.head_out = head->out;
+  }
   if (a_out && (!x_mu || !aligned16(a_out))) return MI_ERR_INVALID_ARG;      // only a transformed operand has anything to keep
   a.a_out = a_out;
   a.M = M; a.N = N; a.K = K;

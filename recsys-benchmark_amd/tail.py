@@ -71,6 +71,11 @@ class _MaskRide(ctypes.Structure):       # mi_tail_mask_ride
                 ("zero_floats", ctypes.c_int64), ("affine", ctypes.c_void_p)]
 
 
+class _HeadEpi(ctypes.Structure):        # mi_tail_head_in_epilogue
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("add", ctypes.c_void_p), ("mu", ctypes.c_void_p),
+                ("sc", ctypes.c_void_p), ("be", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+
+
 class _AffineJob(ctypes.Structure):      # mi_tail_affine_job
     _fields_ = [("nlayers", ctypes.c_int32), ("widths", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -215,6 +220,9 @@ class _State:
 # first layer's statistics can then be shifted sums like the others' and the step has no finalize launch at all
 # (MI_TAIL_LEAD_RIDE=0: the first layer keeps its tile statistics and the finalize launch that carries the masks)
 LEAD_RIDE = os.environ.get("MI_TAIL_LEAD_RIDE", "1") == "1"
+# An inference forward behind a lead launch (DeepFM): the head Linear(., 1) in the epilogue of the last hidden layer's product
+# (mi_tail_fwd_gemm_head; the logits' zero fill rides in the lead launch) — MI_TAIL_HEAD_EPILOGUE=0: the head as its own launch
+HEAD_EPILOGUE = os.environ.get("MI_TAIL_HEAD_EPILOGUE", "1") == "1"
 # Labels known at forward time (DeepFM.forward(x, labels=y)): head + BCE-with-logits + the head's backward sums in one
 # launch (mi_tail_head_bce) instead of three (MI_TAIL_HEAD_LOSS=0: off)
 HEAD_LOSS = os.environ.get("MI_TAIL_HEAD_LOSS", "1") == "1"
@@ -305,9 +313,14 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
     # the keep bits and the zero fill ride in the first layer's finalize launch (no launch of their own) when that launch
     # exists (a training-mode BatchNorm on the first layer) and a LATER kernel can advance the seed
     ride = RIDE_MASKS and not merge and k >= 2 and not plan[0].fixed and not lead_ride
+    # inference (nothing kept, every layer on fixed statistics): the head runs in the last product's epilogue, its logits are
+    # zero-filled by the lead launch
+    head_epi = (HEAD_EPILOGUE and lead_ride and not grad and zeros is None and labels is None and all(L.fixed for L in plan)
+                and all(L.p == 0 for L in plan) and w_head.numel() % 4 == 0)
+    out_pad = torch.empty(((M + 3) // 4 * 4,), dtype=torch.float32, device=dev) if head_epi else None
     if lead_ride:
         # the launch in front of the tail carries the keep bits, the zero fill AND the constants of the fixed-statistics layers
-        bits, lead_job = _masks(seed, plan, M, dev, zeros, ride=True)
+        bits, lead_job = _masks(seed, plan, M, dev, out_pad if head_epi else zeros, ride=True)
         fixed_c, aff = _fixed_constants(plan, dev, s, defer=True)
         ride_struct = lead_job[0] if lead_job is not None else None
         if aff is not None:
@@ -339,6 +352,20 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
 
     for i, L in enumerate(plan):
         N, K = L.lin.out_features, L.lin.in_features
+        if head_epi and i == k - 1:        # the last hidden layer of an inference forward: product + head, z not stored
+            c = fixed_c[i]
+            hadd = None if last_add is None else _kernels._f32c(last_add).view(-1)
+            epi = _HeadEpi(w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(hadd), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(),
+                           out_pad.data_ptr())
+            _lib.check(lib.mi_tail_fwd_gemm_head(
+                prev.data_ptr(), K, _lib.ptr(prev_c[0]) if prev_c is not None else None,
+                _lib.ptr(prev_c[1]) if prev_c is not None else None, _lib.ptr(prev_c[2]) if prev_c is not None else None,
+                float(prev_p), _lib.ptr(prev_bits), Ws[i].data_ptr(), K, M, N, K, None, ctypes.byref(epi), s),
+                "mi_tail_fwd_gemm_head")
+            acts.append(x.new_empty(0))
+            Zs.append(x.new_empty(0))
+            consts.append(c)
+            continue
         Z = torch.empty((M, N), dtype=torch.float32, device=dev)
         part = shift = None
         if L.fixed:
@@ -382,7 +409,7 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
         Zs.append(Z)
         consts.append(c)
         prev, prev_c, prev_p, prev_bits = Z, c, L.p, bits[i]
-    out = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    out = out_pad[:M].view(M, 1) if head_epi else torch.empty((M, 1), dtype=torch.float32, device=dev)
     add = None if last_add is None else _kernels._f32c(last_add).view(-1)
     N = plan[-1].lin.out_features
     if pending is not None:
@@ -416,6 +443,8 @@ def _tail_forward(plan, seed, x, last_add, Ws, w_head, b_head, lead: Optional[_L
             zeros[hoff:].data_ptr(), zeros[hoff + Rh * 2 * N:].data_ptr(), Rh, zeros[loff:].data_ptr(), M, N,
             ctypes.byref(stats) if stats is not None else None, _lib.ptr(loss_seed), s), "mi_tail_head_bce")
         _HEAD_LOSS[str(dev)] = head
+    elif head_epi:
+        pass                               # (the logits came out of the last product's epilogue)
     else:
         _lib.check(lib.mi_tail_head_fwd_m(prev.data_ptr(), N, prev_c[0].data_ptr(), prev_c[1].data_ptr(), prev_c[2].data_ptr(),
                                           float(prev_p), _lib.ptr(prev_bits), w_head.data_ptr(), _lib.ptr(b_head), _lib.ptr(add),
