@@ -325,6 +325,46 @@ def test_criterion_in_the_head_launch_vs_the_three_launch_form_and_the_oracle(B,
     assert all(torch.isfinite(v.grad.to_dense() if v.grad.is_sparse else v.grad).all() for v in m.parameters() if v.grad is not None)
 
 
+@pytest.mark.parametrize("B,hidden,bn", [(64, [400, 400, 400], True), (4096, [400, 400, 400], True), (300, [64, 32], False), (7, [32], True)])
+@pytest.mark.parametrize("layout", ["split", "packed128"])
+def test_inference_forward_is_the_lookup_and_the_products_only(B, hidden, bn, layout):
+    """model.eval() under no_grad (the reference's scripts/deepfm/infer_deepfm.py:318-352, validate_epoch): DeepFM's forward
+    as the lookup launch — carrying the constants of the tail's fixed-statistics layers and the logits' zero fill in extra
+    workgroups — and one launch per hidden layer, the head Linear(., 1) in the epilogue of the last one.  Against the oracle's
+    eval forward; the launches are read off the dispatch-event ring."""
+    from recsys_benchmark_amd import mlp as _mlp_mod
+    from recsys_benchmark_amd.profiling import KernelTimer
+
+    dims, D = [7, 3, 50, 11, 4, 200, 9, 31], 16
+    torch.manual_seed(B + len(hidden))
+    model = pkg.DeepFM(dims, D, hidden, p_dropout=0.5, use_batchnorm=bn)
+    with torch.no_grad():
+        model._bias.fill_(0.15)
+        for m in model._deep_branch:
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(B)
+    x = torch.stack([torch.randint(0, d, (B,), generator=gen) for d in dims], 1)
+    ref = ro.deepfm_forward(x, p, len(hidden), bn, False)
+    model = model.to(DEV).eval()
+    if layout == "packed128":
+        model.pack_tables()
+    with torch.no_grad():
+        model(x.to(DEV))                                  # (first call: lazily created buffers)
+        with KernelTimer(32) as kt:
+            logits = model(x.to(DEV))
+    names = [k for k, _ in kt.records]
+    if _mlp_mod.FUSED_TAIL:
+        assert names[0] == "gather_fm_fwd_ride" and len(names) == 1 + len(hidden), names
+        assert all(n in ("tail_fwd_gemm", "tail_fwd_gemm_small") for n in names[1:]), names
+    assert_close(logits, ref.detach(), 1e-4, 1e-5, "eval logits")
+    _lib.check_index_errors()
+
+
 def test_empty_batch():
     p, x, g_emb, g_y = _random_case(0, [5, 6], 16, seed=1)
     emb, yfm = _kernels.gather_fm(x.to(DEV), p["offsets"].to(DEV), p["embedding._emb_module.weight"].to(DEV),
