@@ -228,8 +228,9 @@ def test_lookup_backward_in_the_dgrad_epilogue_vs_oracle_and_vs_the_two_node_pat
             assert_close(gr, p[k].grad, 2e-4, atol, f"grad {k} fused={fused}")
     # the two paths share every forward kernel: same logits up to the order of the float atomics that accumulate the
     # BatchNorm statistics above one 64-row tile; table gradients equal up to the order in which a row's duplicates are
-    # summed when densified
-    assert_close(got[True][0], got[False][0], 1e-5, 1e-6, "logits: fused epilogue vs two-node path")
+    # summed when densified.  (B = 5000 is 79 tiles met by atomics in an order that changes from launch to launch: a logit
+    # of 0.055 was seen 1.7e-6 apart between the two paths — both well inside the 1e-5 against the oracle above)
+    assert_close(got[True][0], got[False][0], 1e-5, 5e-6, "logits: fused epilogue vs two-node path")
     for k in ("embedding._emb_module.weight", "fc.weight", "_bias"):
         assert_close(got[True][1][k], got[False][1][k], 1e-5, atol, f"{k}: fused epilogue vs two-node path")
 
