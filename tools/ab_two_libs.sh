@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on ONE box: alternate the two builds of the library
+# A/B of two builds of the library on ONE box: ab_libs/old.so and ab_libs/new.so (copies of lib/libmi355x_recsys.so built from
+# the two trees; ab_libs/ is not tracked) are swapped in turn under the same bench command, three rounds.
 L=recsys-benchmark_amd/lib/libmi355x_recsys.so
 for i in 1 2 3; do
   for v in old new; do
