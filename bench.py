@@ -1209,28 +1209,36 @@ def main():
                 graphed_step(x)
 
             def timed_phases(iters=20):
-                """Per-phase device time of the sharded step (HIP events between the phases of `iters` eager-launched
-                steps; the collectives and the graph replay are the same calls the timed region makes)."""
-                names, acc = [], {}
-                for it in range(iters + 2):
-                    evs = [torch.cuda.Event(enable_timing=True)]
-                    evs[0].record()
-                    labels = []
+                """Per-phase device time of the sharded step: HIP events between the phases of `iters` steps enqueued back
+                to back like the timed region's (no host sync between steps, so the host stays ahead of the device as it
+                does there and an interval is the phase's own device time, not the host's launch latency); the collectives
+                and the graph replay are the same calls the timed region makes.  `synced`: the same with a host sync after
+                every step (each phase then starts from an idle device: what a step costs when nothing is queued behind it)."""
+                def run(sync_each):
+                    names, marks = [], []
+                    for it in range(iters + 2):
+                        evs = [torch.cuda.Event(enable_timing=True)]
+                        evs[0].record()
+                        labels = []
 
-                    def mark(name):
-                        e = torch.cuda.Event(enable_timing=True)
-                        e.record()
-                        evs.append(e)
-                        labels.append(name)
-                    next_batch()
-                    graphed_step(x, mark=mark)
+                        def mark(name):
+                            e = torch.cuda.Event(enable_timing=True)
+                            e.record()
+                            evs.append(e)
+                            labels.append(name)
+                        next_batch()
+                        graphed_step(x, mark=mark)
+                        if sync_each:
+                            torch.cuda.synchronize()
+                        marks.append(evs)
+                        names = labels
                     torch.cuda.synchronize()
-                    if it < 2:
-                        continue
-                    names = labels
-                    for k, name in enumerate(labels):
-                        acc[name] = acc.get(name, 0.0) + evs[k].elapsed_time(evs[k + 1]) * 1e3
-                return [{"phase": n, "us": round(acc[n] / iters, 2)} for n in names]
+                    acc = {}
+                    for evs in marks[2:]:
+                        for k, name in enumerate(names):
+                            acc[name] = acc.get(name, 0.0) + evs[k].elapsed_time(evs[k + 1]) * 1e3
+                    return [{"phase": n, "us": round(acc[n] / iters, 2)} for n in names]
+                return {"pipelined": run(False), "synced": run(True)}
         except Exception as e:  # noqa: BLE001 - keep the run alive: the eager step is always valid
             print(f"[bench] rank {rank}: capturing the local compute failed ({type(e).__name__}: {e}); eager",
                   file=sys.stderr, flush=True)
@@ -1503,9 +1511,14 @@ def main():
                 "direct_rccl": model.__dict__.get("_comm") is not None,
                 "bucket_capacity_per_peer": int(model.capacity(B)), "observed_max_bucket_fill": int(fill.max()),
                 "bucket_slack": model.bucket_slack, "shard_rows": int(model.num_local_rows),
-                "phases_us": sharded_phases,
-                "phases_note": "device time between HIP events placed after each phase of 20 steps; at world=1 the all-to-alls "
-                               "are one-rank copies"}
+                "phases_us": sharded_phases["pipelined"] if sharded_phases else None,
+                "phases_us_synced": sharded_phases["synced"] if sharded_phases else None,
+                "before_the_local_graph_us": (round(sum(p["us"] for p in sharded_phases["pipelined"][:4]), 2)
+                                              if sharded_phases else None),
+                "phases_note": "device time between HIP events placed after each phase of 20 steps enqueued back to back as in "
+                               "the timed region (the host stays ahead of the device); phases_us_synced: the same with a host "
+                               "sync after every step (every phase then includes the host's launch latency: rounds 1-4's "
+                               "figure); at world=1 the all-to-alls are one-rank copies"}
         if not args.no_train_step and world == 1 and not sharded:
             out["train_step"] = train_step_lines(dims, D, hidden, p_drop, B, dev, args.ids, args.layout)
         if not args.no_cpu_baseline and world == 1:
