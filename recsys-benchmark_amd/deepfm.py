@@ -7,10 +7,14 @@ _deep_branch.*` — `linear_layer` is unused by forward there too), same
 
 What runs where:
   x + offsets, embedding gather, FM 2nd order, EmbeddingBag(N,1,sum) + bias
-      -> mi_gather_fm_fwd / mi_gather_fm_bwd_{rows,dense}  (vanilla table), or
+      -> mi_gather_fm_fwd(_ride) forward; backward in the epilogue of the tail's first input-gradient product
+         (mi_tail_dgrad_gemm_fm) when the whole forward is one autograd node (_fused_step), else
+         mi_gather_fm_bwd_{rows,dense}  (vanilla table), or
          IEmbedding.forward + mi_fm_fwd / mi_fm_bwd        (compressed tables)
-  the MLP tail: Linear contractions on rocBLAS/hipBLASLt through PyTorch (a
-      real GEMM); BatchNorm1d + ReLU + Dropout fused into one HIP pass each way (mlp.py).
+  the MLP tail (a real GEMM): the library's own fp32-MFMA products with BatchNorm1d / ReLU / Dropout in
+      their operand loads and epilogues (tail.py, csrc/tail.hip) in training, eval() and no-BatchNorm stacks alike; the
+      general path (mlp.py: contractions on rocBLAS / hipBLASLt through PyTorch + fused BatchNorm passes) only for stacks
+      the fused kernels do not take (odd widths) or with MI_FUSED_TAIL=0.
 """
 from typing import Any, Dict, List, Optional, Union, cast
 

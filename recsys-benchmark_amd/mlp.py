@@ -4,9 +4,10 @@ Linear — reference: src/models/deepfm.py:53-66,100-102 and src/models/dcn.py:5
 The modules stay ordinary nn.Linear / nn.BatchNorm1d / nn.ReLU / nn.Dropout inside the same
 nn.Sequential (state_dict keys unchanged); `run_tail` walks the Sequential.
 
-A training-mode tail with a BatchNorm after every hidden Linear and a 1-output last Linear — the
+A tail of (Linear, [BatchNorm1d], ReLU, [Dropout]) groups with a 1-output last Linear — the
 reference's configs — runs on the library's own fused MFMA kernels (tail.py / csrc/tail.hip, see
-FUSED_TAIL below).  Every other pattern takes the GENERAL path of this file: each
+FUSED_TAIL below) in training, eval() and without BatchNorm alike (round 4).  The patterns those
+kernels do not take (widths that are not multiples of 8, headless stacks) use the GENERAL path of this file: each
 (Linear, [BatchNorm1d], ReLU, [Dropout]) group is the contraction on hipBLASLt/rocBLAS through
 PyTorch, then ONE fused BN+ReLU+Dropout HIP pass each way (mi_bn_relu_dropout_*).
 Launch count matters at B=4096 (every kernel is a few microseconds), so: all reduction targets
@@ -45,10 +46,11 @@ TUNE_BACKWARD_GEMMS = False
 # (Linear, BatchNorm1d, ReLU, Dropout) x k + Linear(., 1) tail runs as ONE autograd node over the fused MFMA kernels of
 # csrc/tail.hip (tail.py) — the contractions are the library's OWN kernels, BatchNorm / ReLU / Dropout sit inside their
 # operand loads and epilogues, the weight gradients are one multi-problem launch; with use_deterministic_algorithms(True)
-# there are no atomics at all (bit-reproducible steps).  Measured on MI355X, same box, A/B: DeepFM headline 0.2906 vs
-# 0.2886 ms per step for the general path below (hipBLASLt / rocBLAS products + the fused passes of csrc/mlp.hip), the
-# row-sharded step +1.2 %, DCN-Mix (C3) -1.4 % — level, without TunableOp's per-shape search at start-up.  Tails that do
-# not fit the pattern (eval mode, no BatchNorm, widths not multiples of 8, ...) take the general path by themselves.
+# there are no atomics at all (bit-reproducible steps).  Measured on MI355X, same box, A/B, round 2: DeepFM headline 0.2906
+# vs 0.2886 ms per step for the general path below (hipBLASLt / rocBLAS products + the fused passes of csrc/mlp.hip) —
+# level, without TunableOp's per-shape search at start-up; round 4: 0.226 ms (one-node step, statistics by atomics, criterion
+# in the head launch: DESIGN.md §4) against 0.289 for the general path.  Eval-mode and no-BatchNorm stacks run on the same
+# kernels with fixed per-column constants; tails that do not fit (widths not multiples of 8, ...) take the general path.
 FUSED_TAIL = os.environ.get("MI_FUSED_TAIL", "1") != "0"
 
 
