@@ -86,6 +86,68 @@ __global__ __launch_bounds__(kBlock) void k_bpr_fwd(
   }
 }
 
+// The same for rows of D = 4 LPR floats (LPR a power of two <= 64, 16-byte aligned tables): LPR lanes x float4 per sample,
+// 64 / LPR samples per wave side by side.  A quarter of the workgroups of the form above at D = 64 — the launch is a chain
+// of round trips (ids, rows, partial, ticket, partials) and the ticket is ONE word every workgroup adds to: same-address
+// atomics serialise at ~26 ns apiece, 512 of them were most of the kernel's 10 us.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_bpr_fwd_v(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, RowBounds nb, float *__restrict__ sig, float *__restrict__ part, unsigned *ticket,
+    float *__restrict__ loss, const float *__restrict__ plus, float plus_w) {
+  constexpr int SPW = kWave / LPR;
+  __shared__ float red[kWavesPerBlock];
+  __shared__ bool last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane % LPR, k = lane / LPR;
+  float acc = 0.f;
+  bool bad = false;
+  const int64_t step = (int64_t)gridDim.x * kWavesPerBlock * SPW;
+  for (int64_t b0 = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * SPW; b0 < B; b0 += step) {
+    const int64_t b = b0 + k;
+    const bool valid = b < B;
+    const int64_t ur = !valid ? 0 : (ui ? ui[b] : b), pr = !valid ? 0 : (pi ? pi[b] : b), nr = !valid ? 0 : (ni ? ni[b] : b);
+    float d = 0.f;
+    if (valid && nb.ok(ur, pr, nr)) {
+      const float4 u = ld4(U + ur * D + q * 4), p = ld4(P + pr * D + q * 4), n = ld4(Nn + nr * D + q * 4);
+      d = u.x * (p.x - n.x) + u.y * (p.y - n.y) + u.z * (p.z - n.z) + u.w * (p.w - n.w);
+    } else if (valid) {
+      bad = true;                          // (an out-of-range triple reads nothing and counts as u = p = n = 0)
+    }
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) d += __shfl_xor(d, m);
+    if (q == 0 && valid) {
+      sig[b] = 1.f / (1.f + expf(d));
+      acc += softplus(-d);
+    }
+  }
+  if (__any(bad) && lane == 0 && nb.err) atomicOr(nb.err, MI_IDX_OUT_OF_RANGE);
+  acc = wave_sum(acc);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < kWavesPerBlock; ++j) s += red[j];
+    publish_partial(part, ticket, s, last);
+  }
+  __syncthreads();
+  if (last) {
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < gridDim.x; j += kBlock) s += read_partial(part + j);
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int j = 0; j < kWavesPerBlock; ++j) t += red[j];
+      loss[0] = t / (float)B + (plus ? plus_w * plus[0] : 0.f);
+      if (plus) loss[1] = t / (float)B;
+      *ticket = 0;
+    }
+  }
+}
+
 // dU[ui[b]] += c (p - n), dP[pi[b]] += c u, dN[ni[b]] -= c u with c = -g * sig[b] / B
 // (float atomics when an index array is given — rows repeat —, plain stores otherwise)
 __global__ __launch_bounds__(kBlock) void k_bpr_bwd(
@@ -132,6 +194,52 @@ __global__ __launch_bounds__(kBlock) void k_rowsq_fwd(
     for (int j = lane; j < D; j += kWave) acc += u[j] * u[j] + p[j] * p[j] + q[j] * q[j];
   }
   if (bad && lane == 0 && nb.err) atomicOr(nb.err, MI_IDX_OUT_OF_RANGE);
+  acc = wave_sum(acc);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < kWavesPerBlock; ++j) s += red[j];
+    publish_partial(part, ticket, s, last);
+  }
+  __syncthreads();
+  if (last) {
+    float s = 0.f;
+    for (unsigned j = threadIdx.x; j < gridDim.x; j += kBlock) s += read_partial(part + j);
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int j = 0; j < kWavesPerBlock; ++j) t += red[j];
+      out[0] = t / (2.f * (float)B);
+      *ticket = 0;
+    }
+  }
+}
+
+template <int LPR>      // (the float4 form, as k_bpr_fwd_v)
+__global__ __launch_bounds__(kBlock) void k_rowsq_fwd_v(
+    const float *__restrict__ U, const int64_t *__restrict__ ui, const float *__restrict__ P,
+    const int64_t *__restrict__ pi, const float *__restrict__ Nn, const int64_t *__restrict__ ni,
+    int64_t B, int D, RowBounds nb, float *__restrict__ part, unsigned *ticket, float *__restrict__ out) {
+  constexpr int SPW = kWave / LPR;
+  __shared__ float red[kWavesPerBlock];
+  __shared__ bool last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane % LPR, k = lane / LPR;
+  float acc = 0.f;
+  bool bad = false;
+  const int64_t step = (int64_t)gridDim.x * kWavesPerBlock * SPW;
+  for (int64_t b0 = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * SPW; b0 < B; b0 += step) {
+    const int64_t b = b0 + k;
+    if (b >= B) continue;
+    const int64_t ur = ui[b], pr = pi[b], nr = ni[b];
+    if (!nb.ok(ur, pr, nr)) { bad = true; continue; }
+    const float4 u = ld4(U + ur * D + q * 4), p = ld4(P + pr * D + q * 4), n = ld4(Nn + nr * D + q * 4);
+    acc += dot4(u, u) + dot4(p, p) + dot4(n, n);
+  }
+  if (__any(bad) && lane == 0 && nb.err) atomicOr(nb.err, MI_IDX_OUT_OF_RANGE);
   acc = wave_sum(acc);
   if (lane == 0) red[wv] = acc;
   __syncthreads();
@@ -345,8 +453,24 @@ static int bpr_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, con
   // workspace[grid] is the ticket: zeroed here once per call (captured as a memset node in a graph)
   if (zero_ticket && hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
-  MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace,
-            reinterpret_cast<unsigned *>(workspace + grid), loss, plus, plus_w);
+  unsigned *ticket = reinterpret_cast<unsigned *>(workspace + grid);      // workspace[mi_bpr_workspace_elems(B) - 1], both forms
+  const int lpr = D / 4;
+  if (D % 4 == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && aligned16(U) && aligned16(P) && aligned16(Nn)) {
+    const int gv = grid_for_waves((B + 64 / lpr - 1) / (64 / lpr));
+#define BPRV(L) MI_LAUNCH("bpr_fwd", (k_bpr_fwd_v<L>), gv, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace, ticket, loss, plus, plus_w)
+    switch (lpr) {
+      case 1: BPRV(1); break;
+      case 2: BPRV(2); break;
+      case 4: BPRV(4); break;
+      case 8: BPRV(8); break;
+      case 16: BPRV(16); break;
+      case 32: BPRV(32); break;
+      default: BPRV(64); break;
+    }
+#undef BPRV
+    return launch_status();
+  }
+  MI_LAUNCH("bpr_fwd", k_bpr_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, sig, workspace, ticket, loss, plus, plus_w);
   return launch_status();
 }
 
@@ -392,8 +516,24 @@ static int rowsq_fwd_impl(bool zero_ticket, const float *U, const int64_t *ui, c
   const int grid = grid_for_waves(B);
   if (zero_ticket && hipMemsetAsync(workspace + grid, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess)
     return MI_ERR_LAUNCH;
-  MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, workspace,
-            reinterpret_cast<unsigned *>(workspace + grid), out);
+  unsigned *ticket = reinterpret_cast<unsigned *>(workspace + grid);
+  const int lpr = D / 4;
+  if (D % 4 == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && aligned16(U) && aligned16(P) && aligned16(Nn)) {
+    const int gv = grid_for_waves((B + 64 / lpr - 1) / (64 / lpr));
+#define RSQV(L) MI_LAUNCH("rowsq_fwd", (k_rowsq_fwd_v<L>), gv, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, workspace, ticket, out)
+    switch (lpr) {
+      case 1: RSQV(1); break;
+      case 2: RSQV(2); break;
+      case 4: RSQV(4); break;
+      case 8: RSQV(8); break;
+      case 16: RSQV(16); break;
+      case 32: RSQV(32); break;
+      default: RSQV(64); break;
+    }
+#undef RSQV
+    return launch_status();
+  }
+  MI_LAUNCH("rowsq_fwd", k_rowsq_fwd, grid, kBlock, stream, U, ui, P, pi, Nn, ni, B, D, nb, workspace, ticket, out);
   return launch_status();
 }
 
