@@ -1,5 +1,7 @@
 // cross.hip — the memory-bound elementwise / reduction pieces of the CrossNet backward
 // (src/models/layer_dcn.py:90-140 differentiated by hand); the contractions are in gemm.hip.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -341,8 +343,12 @@ int mi_cross_bwd_head(const float *g, const float *x0, const float *lin, const f
   if (N % 4 != 0 || N > 1024 || !aligned16(g) || !aligned16(x0) || !aligned16(lin) || !aligned16(dlin) || !aligned16(dx0) ||
       (b && !aligned16(b)))
     return MI_ERR_UNSUPPORTED;
-  int grid = (M + 15) / 16;                 // ~4 rows per wave, two in flight: the column partials amortise over them
-  if (grid > 512) grid = 512;
+  // ~4 rows per wave, two in flight: the column partials amortise over them.  Every workgroup ends with one float atomic per
+  // column on the SAME N words (same-address atomics serialise at ~26 ns apiece: 256 workgroups = 6.7 us behind the last
+  // row), so the grid is capped (MI_CROSS_BWD_GRID, default 192: profiles/r04_ab_runs.txt)
+  static const int cap = [] { const char *e = getenv("MI_CROSS_BWD_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 2048 ? v : 192; }();
+  int grid = (M + 15) / 16;
+  if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   const int nj = (N / 4 + kWave - 1) / kWave;
 #define MI_CBH(J) MI_LAUNCH("cross_bwd_head", k_cross_bwd_head<J>, grid, kBlock, stream, g, x0, lin, gate, E, b, dlin, dx0, accumulate, db, dgs, M, N)
